@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's pybind11 module ``dynamont._dynamont``
+(src/cpp/aligner_bindings.cpp:180-219), backed by the C ABI in include/dynamont_mi.h.
+
+Same names, argument meaning, return dicts and exception types/messages:
+
+    Aligner(model_file, pore, mode="basic", threads=1, band=400)
+    Aligner.align(signal, sequence, calc_probabilities=False) -> dict
+    Aligner.train(signal, sequence) -> dict
+    PoreType, pore_type(str)
+
+Additions for the GPU (a single read cannot fill an MI355X): ``align_batch``/``train_batch``
+and the staged ``Batch`` whose inputs are HBM-resident before kernels run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Sequence
+
+import numpy as np
+
+from . import _native as N
+
+ERRCAP = 4096
+
+
+class PoreType(enum.IntEnum):
+    """aligner_bindings.cpp:184-189 / include/dynamont/aligner.hpp:26-33"""
+    RNA002 = 0
+    RNA004 = 1
+    DNA_R9 = 2
+    DNA_R10_260 = 3
+    DNA_R10_400 = 4
+
+
+def _raise(code: int, msg: str):
+    if code == N.DYN_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)          # std::invalid_argument under pybind11
+    if code == N.DYN_ERR_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)            # std::runtime_error under pybind11 / device failures
+
+
+def pore_type(pore: str) -> PoreType:
+    """aligner_bindings.cpp:18-32,218"""
+    out = C.c_int()
+    err = C.create_string_buffer(ERRCAP)
+    rc = N.lib().dyn_pore_from_string(str(pore).encode(), C.byref(out), err, ERRCAP)
+    if rc != N.DYN_OK:
+        _raise(rc, err.value.decode())
+    return PoreType(out.value)
+
+
+def read_error_message(status: int, bad_char: bytes | int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    if isinstance(bad_char, int):
+        bad_char = bytes([bad_char & 0xFF])
+    N.lib().dyn_read_strerror(int(status), bad_char[:1] or b"\0", buf, 256)
+    return buf.value.decode(errors="replace")
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def _pack(signals: Sequence, sequences: Sequence[str]):
+    n = len(signals)
+    if n != len(sequences):
+        raise ValueError("signals and sequences differ in length")
+    sig_off = np.zeros(n + 1, dtype=np.uint64)
+    seq_off = np.zeros(n + 1, dtype=np.uint64)
+    arrs = []
+    for i, s in enumerate(signals):
+        a = np.ascontiguousarray(s, dtype=np.float64)  # py::array::c_style | forcecast
+        if a.ndim != 1:
+            raise ValueError("Signal must be a one-dimensional array")  # aligner_bindings.cpp:137-138
+        arrs.append(a)
+        sig_off[i + 1] = sig_off[i] + a.size
+        seq_off[i + 1] = seq_off[i] + len(sequences[i])
+    sig = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.float64)
+    if sig.size == 0:
+        sig = np.zeros(1, dtype=np.float64)[:0]
+    seqs = "".join(sequences).encode("latin-1")
+    return np.ascontiguousarray(sig), sig_off, seqs, seq_off
+
+
+class AlignBatchResult:
+    """Columnar results of one batch; ``read(i)`` gives the reference's per-read dict."""
+
+    def __init__(self, n, cap):
+        self.n = n
+        self.Z = np.zeros(n)
+        self.status = np.zeros(n, dtype=np.int32)
+        self.bad_char = np.zeros(n, dtype=np.uint8)
+        self.seg_offsets = np.zeros(n + 1, dtype=np.uint64)
+        self.n_segments = np.zeros(n, dtype=np.uint64)
+        self.sequence_positions = np.zeros(cap, dtype=np.uint64)
+        self.signal_positions = np.zeros(cap, dtype=np.uint64)
+        self.probabilities = np.zeros(cap)
+        self.states = np.zeros(cap, dtype=np.uint8)
+        self._c = N.DynAlignOut(_ptr(self.Z, N.c_double_p), _ptr(self.status, N.c_i32_p),
+                                self.bad_char.ctypes.data, _ptr(self.seg_offsets, N.c_u64_p),
+                                _ptr(self.n_segments, N.c_u64_p), _ptr(self.sequence_positions, N.c_u64_p),
+                                _ptr(self.signal_positions, N.c_u64_p), _ptr(self.probabilities, N.c_double_p),
+                                _ptr(self.states, N.c_u8_p), cap)
+
+    def error(self, i: int) -> str | None:
+        if self.status[i] == 0:
+            return None
+        return read_error_message(int(self.status[i]), int(self.bad_char[i]))
+
+    def read(self, i: int) -> dict:
+        """Per-read dict exactly as resultToPython builds it (aligner_bindings.cpp:53-84);
+        raises RuntimeError(message) for a failed read like the reference's align()."""
+        if self.status[i] != 0:
+            raise RuntimeError(self.error(i))
+        a = int(self.seg_offsets[i])
+        b = a + int(self.n_segments[i])
+        return {
+            "Z": float(self.Z[i]),
+            "sequence_positions": self.sequence_positions[a:b].copy(),
+            "signal_positions": self.signal_positions[a:b].copy(),
+            "probabilities": self.probabilities[a:b].copy(),
+            "states": [chr(c) for c in self.states[a:b]],
+            "polishes": [""] * (b - a),
+        }
+
+
+class TrainBatchResult:
+    def __init__(self, n, cap, num_kmers, pooled: bool):
+        self.n = n
+        self.num_kmers = num_kmers
+        self.Z = np.zeros(n)
+        self.status = np.zeros(n, dtype=np.int32)
+        self.bad_char = np.zeros(n, dtype=np.uint8)
+        self.transitions = np.zeros(3 * n)
+        self.em_offsets = np.zeros(n + 1, dtype=np.uint64)
+        self.em_count = np.zeros(n, dtype=np.uint64)
+        self.em_code = np.zeros(cap, dtype=np.int32)
+        self.em_mean = np.zeros(cap)
+        self.em_stdev = np.zeros(cap)
+        self.em_weight = np.zeros(cap)
+        self.em_sum = np.zeros(cap)
+        self.em_sumsq = np.zeros(cap)
+        self.trans_counts = np.zeros(2 * n)
+        self.pooled = np.zeros(3 * num_kmers) if pooled else None
+        self._c = N.DynTrainOut(_ptr(self.Z, N.c_double_p), _ptr(self.status, N.c_i32_p), self.bad_char.ctypes.data,
+                                _ptr(self.transitions, N.c_double_p), _ptr(self.em_offsets, N.c_u64_p),
+                                _ptr(self.em_count, N.c_u64_p), _ptr(self.em_code, N.c_i32_p),
+                                _ptr(self.em_mean, N.c_double_p), _ptr(self.em_stdev, N.c_double_p),
+                                _ptr(self.em_weight, N.c_double_p), _ptr(self.em_sum, N.c_double_p),
+                                _ptr(self.em_sumsq, N.c_double_p), _ptr(self.trans_counts, N.c_double_p), cap)
+
+    def error(self, i: int) -> str | None:
+        if self.status[i] == 0:
+            return None
+        return read_error_message(int(self.status[i]), int(self.bad_char[i]))
+
+    def sparse(self, i: int):
+        a = int(self.em_offsets[i])
+        b = a + int(self.em_count[i])
+        return self.em_code[a:b], self.em_mean[a:b], self.em_stdev[a:b]
+
+    def read(self, i: int, model_mean: np.ndarray, model_stdev: np.ndarray) -> dict:
+        """Dense dict of trainingResultToPython (aligner_bindings.cpp:86-107), rebuilt on demand."""
+        if self.status[i] != 0:
+            raise RuntimeError(self.error(i))
+        mean = model_mean.copy()
+        sd = model_stdev.copy()
+        code, m, s = self.sparse(i)
+        mean[code] = m
+        sd[code] = s
+        t = self.transitions[3 * i:3 * i + 3]
+        return {
+            "Z": float(self.Z[i]),
+            "transition_params": {"m1": float(t[0]), "e1": float(t[1]), "e2": float(t[2])},
+            "emission_model": [{"mean": float(a), "stdev": float(b)} for a, b in zip(mean, sd)],
+        }
+
+
+class Batch:
+    """Staged form (dyn_batch_*): inputs are validated, k-mer coded and resident in HBM after
+    construction; align()/train() only launch kernels; fetch() copies results back."""
+
+    def __init__(self, aligner: "Aligner", signals, sig_offsets, seqs: bytes, seq_offsets):
+        self._al = aligner
+        self._L = N.lib()
+        self.n = len(sig_offsets) - 1
+        self._sig_off = np.ascontiguousarray(sig_offsets, dtype=np.uint64)
+        self._seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        sig = np.ascontiguousarray(signals, dtype=np.float64)
+        self.capacity = int(self._L.dyn_segment_capacity(aligner._h, self.n, _ptr(self._seq_off, N.c_u64_p)))
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_create(aligner._h, self.n, _ptr(sig, N.c_double_p), _ptr(self._sig_off, N.c_u64_p),
+                                      seqs, _ptr(self._seq_off, N.c_u64_p), C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, aligner.last_error())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dyn_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def align(self, calc_probabilities: bool = True) -> None:
+        rc = self._L.dyn_batch_align(self._h, int(bool(calc_probabilities)))
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+
+    def train(self) -> None:
+        rc = self._L.dyn_batch_train(self._h)
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+
+    def fetch(self) -> AlignBatchResult:
+        out = AlignBatchResult(self.n, self.capacity)
+        rc = self._L.dyn_batch_fetch(self._h, C.byref(out._c))
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+        return out
+
+    def fetch_train(self, pooled: bool = False) -> TrainBatchResult:
+        out = TrainBatchResult(self.n, self.capacity, self._al.num_kmers, pooled)
+        rc = self._L.dyn_batch_fetch_train(self._h, C.byref(out._c),
+                                           _ptr(out.pooled, N.c_double_p) if pooled else None)
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+        return out
+
+    def timing(self) -> dict:
+        t = N.DynTiming()
+        self._L.dyn_batch_timing(self._h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in N.DynTiming._fields_ if k != "reserved"}
+
+    def device_results(self):
+        """(rows_ptr, capacity, state_ptr): device addresses for a gather without a host hop."""
+        rows = C.c_void_p()
+        st = C.c_void_p()
+        cap = C.c_uint64()
+        rc = self._L.dyn_batch_device_results(self._h, C.byref(rows), C.byref(cap), C.byref(st))
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+        return rows.value, cap.value, st.value
+
+    def device_pooled(self):
+        p = C.c_void_p()
+        cnt = C.c_uint64()
+        rc = self._L.dyn_batch_device_pooled(self._h, C.byref(p), C.byref(cnt))
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+        return p.value, cnt.value
+
+
+class Aligner:
+    """Mirror of ``_dynamont.Aligner`` (aligner_bindings.cpp:191-216).
+
+    ``device``: HIP device ordinal (default: current device). ``device=None`` with no GPU raises;
+    ``device="host"`` creates a handle for the host-side contract only (model/validation), every
+    compute call on it raises RuntimeError -- there is no CPU compute path.
+    """
+
+    def __init__(self, model_file: str, pore, mode: str = "basic", threads: int = 1, band: int = 400,
+                 device=None):
+        if isinstance(pore, str):
+            pore = pore_type(pore)
+        elif not isinstance(pore, (PoreType, int, np.integer)):
+            raise TypeError("pore must be a PoreType or str")
+        self._L = N.lib()
+        if device == "host":
+            dev = N.DYN_DEVICE_HOST_ONLY
+        elif device is None:
+            dev = -1
+        else:
+            dev = int(device)
+        h = C.c_void_p()
+        err = C.create_string_buffer(ERRCAP)
+        rc = self._L.dyn_aligner_create(str(model_file).encode(), int(pore), str(mode).encode(), int(threads),
+                                        int(band), dev, C.byref(h), err, ERRCAP)
+        if rc != N.DYN_OK:
+            _raise(rc, err.value.decode())
+        self._h = h
+        info = N.DynInfo()
+        self._L.dyn_aligner_info(h, C.byref(info))
+        self.info = info
+        self.pore = PoreType(info.pore)
+        self.rna = bool(info.rna)
+        self.kmer_size = int(info.kmer_size)
+        self.num_kmers = int(info.num_kmers)
+        self._model = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dyn_aligner_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def last_error(self) -> str:
+        return (self._L.dyn_aligner_last_error(self._h) or b"").decode(errors="replace")
+
+    def set_mem_budget(self, nbytes: int) -> None:
+        self._L.dyn_aligner_set_mem_budget(self._h, int(nbytes))
+
+    def model_table(self):
+        """(mean, stdev) in k-mer-code order."""
+        if self._model is None:
+            out = np.zeros(2 * self.num_kmers)
+            self._L.dyn_aligner_model(self._h, _ptr(out, N.c_double_p))
+            self._model = (out[0::2].copy(), out[1::2].copy())
+        return self._model
+
+    # -- host-side contract -------------------------------------------------------------------
+    def validate(self, signal_lengths: Sequence[int], sequences: Sequence[str]):
+        """validateInput + sequenceToKmers per read: (status[n], messages[n], kmers list)."""
+        n = len(sequences)
+        sig_off = np.zeros(n + 1, dtype=np.uint64)
+        sig_off[1:] = np.cumsum(np.asarray(signal_lengths, dtype=np.uint64))
+        seq_off = np.zeros(n + 1, dtype=np.uint64)
+        seq_off[1:] = np.cumsum(np.array([len(s) for s in sequences], dtype=np.uint64))
+        seqs = "".join(sequences).encode("latin-1")
+        status = np.zeros(n, dtype=np.int32)
+        bad = np.zeros(n, dtype=np.uint8)
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        kmers = np.zeros(max(cap, 1), dtype=np.int32)
+        rc = self._L.dyn_validate_batch(self._h, n, _ptr(sig_off, N.c_u64_p), seqs, _ptr(seq_off, N.c_u64_p),
+                                        _ptr(status, N.c_i32_p), bad.ctypes.data, _ptr(kmers, N.c_i32_p), cap)
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        msgs = [None if s == 0 else read_error_message(int(s), int(b)) for s, b in zip(status, bad)]
+        out, off = [], 0
+        for i, s in enumerate(sequences):
+            kc = max(0, len(s) - self.kmer_size + 1)
+            out.append(kmers[off:off + kc].copy() if status[i] == 0 else None)
+            off += kc
+        return status, msgs, out
+
+    # -- batch API ------------------------------------------------------------------------------
+    def batch(self, signals: Sequence, sequences: Sequence[str]) -> Batch:
+        sig, sig_off, seqs, seq_off = _pack(signals, sequences)
+        return Batch(self, sig, sig_off, seqs, seq_off)
+
+    def batch_packed(self, signals, sig_offsets, seqs: bytes, seq_offsets) -> Batch:
+        return Batch(self, signals, sig_offsets, seqs, seq_offsets)
+
+    def align_batch(self, signals: Sequence, sequences: Sequence[str], calc_probabilities: bool = True) -> AlignBatchResult:
+        with self.batch(signals, sequences) as b:
+            b.align(calc_probabilities)
+            return b.fetch()
+
+    def train_batch(self, signals: Sequence, sequences: Sequence[str], pooled: bool = False) -> TrainBatchResult:
+        with self.batch(signals, sequences) as b:
+            b.train()
+            return b.fetch_train(pooled)
+
+    # -- the reference's single-read surface ----------------------------------------------------
+    def align(self, signal, sequence: str, calc_probabilities: bool = False) -> dict:
+        """aligner_bindings.cpp:132-147,169-176 (single read = batch of one)."""
+        return self.align_batch([signal], [sequence], calc_probabilities).read(0)
+
+    def train(self, signal, sequence: str) -> dict:
+        """aligner_bindings.cpp:149-163"""
+        mean, sd = self.model_table()
+        return self.train_batch([signal], [sequence]).read(0, mean, sd)

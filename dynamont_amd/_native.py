@@ -1,0 +1,129 @@
+"""ctypes binding of libdynamont_mi.so (include/dynamont_mi.h) and its in-tree build recipe.
+
+The shared library is the product boundary; this module only declares signatures. There is
+deliberately no fallback: if the library is missing or a GPU call fails, the error propagates.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
+SOURCES = ["dynamont_mi.cpp", "pore_model.cpp", "nt_kernels.hip"]
+HEADERS = ["nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
+
+DYN_DEVICE_HOST_ONLY = -2
+DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)
+
+c_double_p = C.POINTER(C.c_double)
+c_u64_p = C.POINTER(C.c_uint64)
+c_i32_p = C.POINTER(C.c_int32)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class DynInfo(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("pore", C.c_int32), ("rna", C.c_int32), ("kmer_size", C.c_int32),
+                ("alphabet_size", C.c_int32), ("device", C.c_int32), ("num_kmers", C.c_uint64),
+                ("half_band", C.c_uint64), ("log_m1", C.c_double), ("log_e1", C.c_double), ("log_e2", C.c_double),
+                ("max_half_band", C.c_uint64)]
+
+
+class DynAlignOut(C.Structure):
+    _fields_ = [("Z", c_double_p), ("status", c_i32_p), ("bad_char", C.c_void_p), ("seg_offsets", c_u64_p),
+                ("n_segments", c_u64_p), ("sequence_positions", c_u64_p), ("signal_positions", c_u64_p),
+                ("probabilities", c_double_p), ("states", c_u8_p), ("capacity", C.c_uint64)]
+
+
+class DynTrainOut(C.Structure):
+    _fields_ = [("Z", c_double_p), ("status", c_i32_p), ("bad_char", C.c_void_p), ("transitions", c_double_p),
+                ("em_offsets", c_u64_p), ("em_count", c_u64_p), ("em_code", c_i32_p), ("em_mean", c_double_p),
+                ("em_stdev", c_double_p), ("em_weight", c_double_p), ("em_sum", c_double_p),
+                ("em_sumsq", c_double_p), ("trans_counts", c_double_p), ("capacity", C.c_uint64)]
+
+
+class DynTiming(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_backward", C.c_double), ("ms_forward", C.c_double),
+                ("ms_trace", C.c_double), ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
+                ("launches_backward", C.c_uint32), ("launches_forward", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dyn_pore_from_string": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_uint64]),
+    "dyn_aligner_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_int,
+                                     C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
+    "dyn_aligner_destroy": (None, [C.c_void_p]),
+    "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
+    "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
+    "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "dyn_aligner_last_error": (C.c_char_p, [C.c_void_p]),
+    "dyn_read_strerror": (C.c_int, [C.c_int, C.c_char, C.c_char_p, C.c_uint64]),
+    "dyn_segment_capacity": (C.c_uint64, [C.c_void_p, C.c_uint64, c_u64_p]),
+    "dyn_validate_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_u64_p, C.c_char_p, c_u64_p, c_i32_p, C.c_void_p,
+                                     c_i32_p, C.c_uint64]),
+    "dyn_align_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p, C.c_int,
+                                  C.POINTER(DynAlignOut)]),
+    "dyn_train_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
+                                  C.POINTER(DynTrainOut), c_double_p]),
+    "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
+                                   C.POINTER(C.c_void_p)]),
+    "dyn_batch_destroy": (None, [C.c_void_p]),
+    "dyn_batch_align": (C.c_int, [C.c_void_p, C.c_int]),
+    "dyn_batch_train": (C.c_int, [C.c_void_p]),
+    "dyn_batch_fetch": (C.c_int, [C.c_void_p, C.POINTER(DynAlignOut)]),
+    "dyn_batch_fetch_train": (C.c_int, [C.c_void_p, C.POINTER(DynTrainOut), c_double_p]),
+    "dyn_batch_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_u64_p, C.POINTER(C.c_void_p)]),
+    "dyn_batch_device_pooled": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_u64_p]),
+    "dyn_batch_timing": (C.c_int, [C.c_void_p, C.POINTER(DynTiming)]),
+}
+
+
+def hipcc_path() -> str:
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.sep not in p or os.path.exists(p)):
+            return p
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> dynamont_amd/libdynamont_mi.so (in-tree, so it travels)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-Wno-unused-result", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the C-ABI library. Raises if it is absent -- there is no other implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). dynamont_amd has no CPU or PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

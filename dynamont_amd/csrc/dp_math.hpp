@@ -1,0 +1,139 @@
+// dp_math.hpp -- fp64 arithmetic of one lattice cell, shared by the HIP kernels and by a
+// host-side accuracy test (tests/test_dp_math.py compiles it with g++).
+//
+// Reference arithmetic being reproduced (relative to /root/reference):
+//   log_normal_pdf  src/cpp/aligner.cpp:287-292   -0.5*z*z - log(stdev) - 0.5*log(2*pi), z = (x-mean)/stdev
+//   logPlus         src/cpp/aligner.cpp:276-285   hi + log1p(exp(lo - hi)), -inf operands pass through
+//
+// ROCm's ocml log1p(double) alone is ~135 VALU instructions (exp ~42); one logPlus per cell per
+// pass is the dominant cost of the whole path, so softplus g(d) = log1p(exp(d)), d <= 0, is
+// evaluated here in ~45 fp64 instructions with |error| <= ~1.5e-16 absolute (<= ~1 ulp of the
+// values 0.35..0.69 it returns most often), i.e. the accuracy class of glibc's exp+log1p:
+//   exp:   d = k ln2 + r, |r| <= ln2/2, exp(r) = 1 + r + r^2 Q9(r)              (Q9: degree 9)
+//   log1p: e in [0,1]; e <= sqrt2-1: 2 atanh(e/(2+e)); else ln2 + 2 atanh((e-1)/(e+3));
+//          atanh(t) = t + t s F6(s), s = t^2 <= 0.0295                           (F6: degree 6)
+// Coefficients: Chebyshev-node interpolation in 60-digit arithmetic (mpmath), rounded to fp64.
+#pragma once
+
+#include <cmath>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#include <hip/hip_runtime.h>
+#define DYN_HD __host__ __device__ __forceinline__
+#else
+#define DYN_HD inline
+#endif
+
+namespace dynmath {
+
+constexpr double NEG_INF = -__builtin_huge_val();
+
+DYN_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// 1/x to ~1 ulp for x in [2, 4]: hardware seed + two Newton steps (same structure the compiler
+// uses for fp64 division, minus scaling/fixup that this range never needs).
+DYN_HD double rcp_seed(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(x);
+#else
+  return (double)(1.0f / (float)x);
+#endif
+}
+
+DYN_HD double div_2to4(double num, double den) {
+  double r = rcp_seed(den);
+  double e = fma_(-den, r, 1.0);
+  r = fma_(r, e, r);
+  e = fma_(-den, r, 1.0);
+  r = fma_(r, e, r);
+  double q = num * r;
+  double rem = fma_(-den, q, num);
+  return fma_(rem, r, q);
+}
+
+// exp(d) for d in [-1000, 0] (callers clamp). Underflows gracefully to denormal/0 via ldexp.
+DYN_HD double exp_nonpos(double d) {
+  const double LOG2E = 0x1.71547652b82fep+0;
+  const double LN2_HI = 0x1.62e42fee00000p-1;
+  const double LN2_LO = 0x1.a39ef35793c76p-33;
+  double kf = __builtin_rint(d * LOG2E);
+  double r = fma_(-kf, LN2_HI, d);
+  r = fma_(-kf, LN2_LO, r);
+  double q = 0x1.af390ba7e6f47p-26;
+  q = fma_(q, r, 0x1.2891d4ffbb0f9p-22);
+  q = fma_(q, r, 0x1.71de0d85293b8p-19);
+  q = fma_(q, r, 0x1.a019b8ca26fcfp-16);
+  q = fma_(q, r, 0x1.a01a01a7cebcdp-13);
+  q = fma_(q, r, 0x1.6c16c1789d1d7p-10);
+  q = fma_(q, r, 0x1.11111111109a6p-7);
+  q = fma_(q, r, 0x1.5555555553d37p-5);
+  q = fma_(q, r, 0x1.5555555555556p-3);
+  q = fma_(q, r, 0x1.0000000000001p-1);
+  double p = fma_(r * r, q, r) + 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ldexp(p, (int)kf);
+#else
+  return std::ldexp(p, (int)kf);
+#endif
+}
+
+// log1p(e) for e in [0, 1].
+DYN_HD double log1p_unit(double e) {
+  const double SQRT2M1 = 0x1.a827999fcef32p-2;
+  const double LN2 = 0x1.62e42fefa39efp-1;
+  const bool big = e > SQRT2M1;
+  const double num = big ? e - 1.0 : e;
+  const double den = e + (big ? 3.0 : 2.0);
+  const double add = big ? LN2 : 0.0;
+  const double t = div_2to4(num, den);
+  const double s = t * t;
+  double f = 0x1.2b6686d1072f3p-4;
+  f = fma_(f, s, 0x1.39fd39474ad34p-4);
+  f = fma_(f, s, 0x1.7462bd8e53c17p-4);
+  f = fma_(f, s, 0x1.c71c62c63e016p-4);
+  f = fma_(f, s, 0x1.2492492e09d1ap-3);
+  f = fma_(f, s, 0x1.9999999995204p-3);
+  f = fma_(f, s, 0x1.5555555555558p-2);
+  const double a = fma_(t * s, f, t);  // atanh(t)
+  return fma_(2.0, a, add);
+}
+
+// softplus for d <= 0 (NaN and -inf map to 0 through the clamp).
+DYN_HD double softplus_nonpos(double d) {
+  d = __builtin_fmax(d, -1000.0);
+  return log1p_unit(exp_nonpos(d));
+}
+
+// aligner.cpp:276-285. -inf operands: d = -inf or NaN -> clamp -> g = +0 -> hi + 0 == hi, so
+// logPlus(x, -inf) == x and logPlus(-inf, -inf) == -inf exactly, as in the reference.
+DYN_HD double log_plus(double x, double y) {
+  const double hi = __builtin_fmax(x, y);
+  const double lo = __builtin_fmin(x, y);
+  return hi + softplus_nonpos(lo - hi);
+}
+
+// Per-k-mer emission constants kept with each band slot.
+struct Emis {
+  double mean;
+  double stdev;
+  double inv_stdev;  // 1/stdev rounded to nearest
+  double log_stdev;  // std::log(stdev) evaluated on the host by the same libm the reference uses
+};
+
+// aligner.cpp:287-292 with the same evaluation order. z = diff/stdev is formed as
+// diff*inv + one FMA residual correction, which reproduces the correctly rounded quotient
+// (Markstein) so the score is bit-identical to the CPU expression in all but vanishingly rare
+// cases, at 3 instructions instead of a ~12-instruction fp64 divide.
+DYN_HD double log_normal_pdf(double x, const Emis& p) {
+  const double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;  // 0.5*log(2*pi) = 0.91893853320467274178
+  const double diff = x - p.mean;
+  double z = diff * p.inv_stdev;
+  const double rem = fma_(-z, p.stdev, diff);
+  z = fma_(rem, p.inv_stdev, z);
+  double t = -0.5 * z;
+  t = t * z;
+  t = t - p.log_stdev;
+  return t - HALF_LOG_2PI;
+}
+
+}  // namespace dynmath

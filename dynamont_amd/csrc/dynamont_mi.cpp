@@ -1,0 +1,779 @@
+// dynamont_mi.cpp -- C-ABI entry points (include/dynamont_mi.h) and the host batch engine:
+// validation + k-mer coding per read, HBM planning, chunked kernel launches, result marshalling.
+//
+// Reference driver being replaced: NTAligner::align / NTAligner::train
+// (src/cpp/NT_aligner_api.cpp:230-312, 567-639) and the pybind marshalling around them
+// (src/cpp/aligner_bindings.cpp:53-107,132-165). Per-read failures are isolated exactly as the
+// reference's per-read try/except does (src/dynamont/segmentation/segment.py:160-187).
+//
+// There is NO CPU compute path here: without a bound GPU every compute entry point fails with
+// DYN_ERR_DEVICE.
+#include "../../include/dynamont_mi.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "nt_kernels.hpp"
+#include "pore_model.hpp"
+
+using dynhost::PoreModel;
+using dynk::ReadDesc;
+using dynk::ReadState;
+using dynk::SegRow;
+using dynmath::Emis;
+
+namespace {
+
+void copy_msg(char* buf, uint64_t cap, const std::string& s) {
+  if (!buf || !cap) return;
+  const size_t n = std::min<size_t>(cap - 1, s.size());
+  std::memcpy(buf, s.data(), n);
+  buf[n] = 0;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t want) {
+    if (want <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct dyn_aligner {
+  PoreModel model;
+  int device = -1;
+  bool host_only = false;
+  int threads = 1;
+  hipStream_t stream = nullptr;
+  DevBuf d_model;
+  uint64_t mem_budget = 0;
+  std::string last_error;
+  // grow-only lattice workspace pool, reused across batches
+  DevBuf ws, bits, pp, pathn, descs;
+};
+
+struct HostRead {
+  uint64_t S = 0, L = 0, kc = 0;
+  uint64_t sig_off = 0, flat_off = 0 /* into kmers / per-column tables */, seg_off = 0;
+  int32_t status = 0;
+  char bad = 0;
+};
+
+struct dyn_batch {
+  dyn_aligner* a = nullptr;
+  uint64_t n = 0;
+  std::vector<HostRead> reads;
+  std::vector<int32_t> kmers;  // flat, ok reads only
+  uint64_t capacity = 0;       // sum of kc over ALL reads with L >= k (segment rows)
+  uint64_t total_cols = 0;     // sum of kc over ok reads
+  uint32_t max_T = 0, max_N = 0;
+  DevBuf d_sig, d_kmers, d_par, d_state, d_rows, d_segrow, d_medhi, d_medlo;
+  DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled;
+  dyn_timing timing{};
+  bool aligned = false, trained = false;
+  int last_calc = 0;
+};
+
+namespace {
+
+#define HIP_TRY(a, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      (a)->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr; \
+      return _e == hipErrorOutOfMemory ? DYN_ERR_OUT_OF_MEMORY : DYN_ERR_DEVICE;          \
+    }                                                                                     \
+  } while (0)
+
+int need_device(dyn_aligner* a) {
+  if (a->host_only) {
+    a->last_error = "no GPU bound to this handle (created with DYN_DEVICE_HOST_ONLY); the MI355X "
+                    "build has no CPU compute path";
+    return DYN_ERR_DEVICE;
+  }
+  hipError_t e = hipSetDevice(a->device);
+  if (e != hipSuccess) {
+    a->last_error = std::string("HIP error: ") + hipGetErrorString(e) + " at hipSetDevice";
+    return DYN_ERR_DEVICE;
+  }
+  return DYN_OK;
+}
+
+// Host front half of align()/train(): validateInput then sequenceToKmers
+// (NT_aligner_api.cpp:236-238).
+void prepare_reads(const PoreModel& m, uint64_t n, const uint64_t* sig_offsets, const char* seqs,
+                   const uint64_t* seq_offsets, std::vector<HostRead>& reads,
+                   std::vector<int32_t>& kmers, uint64_t* capacity, uint64_t* total_cols) {
+  reads.resize(n);
+  uint64_t cap = 0, reserve = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    HostRead& r = reads[i];
+    r.S = sig_offsets[i + 1] - sig_offsets[i];
+    r.L = seq_offsets[i + 1] - seq_offsets[i];
+    r.sig_off = sig_offsets[i];
+    r.seg_off = cap;
+    r.kc = r.L >= (uint64_t)m.k ? r.L - (uint64_t)m.k + 1 : 0;
+    cap += r.kc;
+    r.status = m.validate(r.S, r.L);
+    if (r.status == DYN_READ_OK) reserve += r.kc;
+  }
+  kmers.resize(reserve);
+  uint64_t flat = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    HostRead& r = reads[i];
+    if (r.status != DYN_READ_OK) continue;
+    r.status = m.encode(seqs + seq_offsets[i], r.L, kmers.data() + flat, &r.bad);
+    if (r.status == DYN_READ_OK) {
+      r.flat_off = flat;
+      flat += r.kc;
+    }
+  }
+  kmers.resize(flat);
+  *capacity = cap;
+  *total_cols = flat;
+}
+
+struct Chunk { std::vector<uint32_t> idx; };
+
+uint64_t lattice_bytes_per_row(bool calc) {
+  // [T][P] slots (8 B) + decision bits + per-row path arrays
+  return calc ? (uint64_t)dynk::P * 8 + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errcap) {
+  try {
+    *pore_out = dynhost::pore_from_string(s ? s : "");
+    return DYN_OK;
+  } catch (const std::invalid_argument& e) {
+    copy_msg(err, errcap, e.what());
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
+                       uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap) {
+  *out = nullptr;
+  const std::string md = mode ? mode : "basic";
+  if (md == "resquiggle" || md == "ntk") {
+    copy_msg(err, errcap, "Aligner mode '" + md + "' (NTK) is outside the scope of the MI355X build; use 'basic'");
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  if (md != "basic" && md != "nt") {
+    copy_msg(err, errcap, "Unknown aligner mode: " + md);  // aligner_bindings.cpp:50
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  dyn_aligner* a = new dyn_aligner();
+  a->threads = threads;
+  try {
+    a->model.load(model_path ? model_path : "", pore, band);
+  } catch (const std::invalid_argument& e) {
+    copy_msg(err, errcap, e.what());
+    delete a;
+    return DYN_ERR_INVALID_ARGUMENT;
+  } catch (const std::exception& e) {
+    copy_msg(err, errcap, e.what());
+    delete a;
+    return DYN_ERR_RUNTIME;
+  }
+  if (a->model.half_band > (uint64_t)dynk::MAX_HALF_BAND) {
+    char msg[160];
+    std::snprintf(msg, sizeof msg, "band %llu exceeds this build's limit of %d (kernels hold %d band slots per row)",
+                  (unsigned long long)band, 2 * dynk::MAX_HALF_BAND + 1, dynk::P);
+    copy_msg(err, errcap, msg);
+    delete a;
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  if (device == DYN_DEVICE_HOST_ONLY) {
+    a->host_only = true;
+    *out = a;
+    return DYN_OK;
+  }
+  auto fail = [&](hipError_t e, const char* what) {
+    copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
+                              " (the MI355X build has no CPU compute path)");
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    a->d_model.release();
+    delete a;
+    return (int)DYN_ERR_DEVICE;
+  };
+  hipError_t e;
+  if (device < 0) {
+    e = hipGetDevice(&device);
+    if (e != hipSuccess) return fail(e, "hipGetDevice");
+  }
+  a->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
+  if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
+                     hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(e, "hipMemcpy(model)");
+  *out = a;
+  return DYN_OK;
+}
+
+void dyn_aligner_destroy(dyn_aligner* a) {
+  if (!a) return;
+  if (!a->host_only) {
+    (void)hipSetDevice(a->device);
+    a->d_model.release();
+    a->ws.release();
+    a->bits.release();
+    a->pp.release();
+    a->pathn.release();
+    a->descs.release();
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+  }
+  delete a;
+}
+
+int dyn_aligner_info(const dyn_aligner* a, dyn_info* info) {
+  if (!a || !info) return DYN_ERR_INVALID_ARGUMENT;
+  info->abi_version = DYN_ABI_VERSION;
+  info->pore = a->model.pore;
+  info->rna = a->model.rna ? 1 : 0;
+  info->kmer_size = a->model.k;
+  info->alphabet_size = a->model.alphabet;
+  info->device = a->host_only ? DYN_DEVICE_HOST_ONLY : a->device;
+  info->num_kmers = a->model.num_kmers;
+  info->half_band = a->model.half_band;
+  info->log_m1 = a->model.log_m1;
+  info->log_e1 = a->model.log_e1;
+  info->log_e2 = a->model.log_e2;
+  info->max_half_band = dynk::MAX_HALF_BAND;
+  return DYN_OK;
+}
+
+int dyn_aligner_model(const dyn_aligner* a, double* out2n) {
+  if (!a || !out2n) return DYN_ERR_INVALID_ARGUMENT;
+  for (uint64_t i = 0; i < a->model.num_kmers; ++i) {
+    out2n[2 * i] = a->model.mean[i];
+    out2n[2 * i + 1] = a->model.stdev[i];
+  }
+  return DYN_OK;
+}
+
+int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes) {
+  if (!a) return DYN_ERR_INVALID_ARGUMENT;
+  a->mem_budget = bytes;
+  return DYN_OK;
+}
+
+const char* dyn_aligner_last_error(const dyn_aligner* a) { return a ? a->last_error.c_str() : ""; }
+
+int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
+  std::string s;
+  switch (read_status) {
+    case DYN_READ_OK: s = ""; break;
+    case DYN_READ_SIGNAL_EMPTY: s = "Signal is empty"; break;
+    case DYN_READ_SEQ_SHORT: s = "Sequence shorter than model kmer size"; break;
+    case DYN_READ_SIGNAL_SHORT: s = "Signal too short compared to sequence"; break;
+    case DYN_READ_INVALID_NT: s = std::string("Invalid nucleotide: ") + bad_char; break;
+    case DYN_READ_Z_MISMATCH: s = "Alignment failed: alignment scores do not match"; break;
+    case DYN_READ_TRAIN_Z_MISMATCH: s = "Training failed: alignment scores do not match"; break;
+    case DYN_READ_INTERNAL: s = "Traceback left the lattice"; break;
+    default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
+  }
+  copy_msg(buf, cap, s);
+  return DYN_OK;
+}
+
+uint64_t dyn_segment_capacity(const dyn_aligner* a, uint64_t n_reads, const uint64_t* seq_offsets) {
+  uint64_t cap = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    const uint64_t L = seq_offsets[i + 1] - seq_offsets[i];
+    if (L >= (uint64_t)a->model.k) cap += L - (uint64_t)a->model.k + 1;
+  }
+  return cap;
+}
+
+int dyn_validate_batch(const dyn_aligner* a, uint64_t n_reads, const uint64_t* sig_offsets,
+                       const char* seqs, const uint64_t* seq_offsets, int32_t* status,
+                       char* bad_char, int32_t* kmers_out, uint64_t kmers_cap) {
+  if (!a) return DYN_ERR_INVALID_ARGUMENT;
+  std::vector<HostRead> reads;
+  std::vector<int32_t> kmers;
+  uint64_t cap = 0, cols = 0;
+  prepare_reads(a->model, n_reads, sig_offsets, seqs, seq_offsets, reads, kmers, &cap, &cols);
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    if (status) status[i] = reads[i].status;
+    if (bad_char) bad_char[i] = reads[i].bad;
+    if (kmers_out && reads[i].status == DYN_READ_OK) {
+      // k-mers of read i are written at the read's segment offset (capacity layout)
+      if (reads[i].seg_off + reads[i].kc > kmers_cap) return DYN_ERR_INVALID_ARGUMENT;
+      std::memcpy(kmers_out + reads[i].seg_off, kmers.data() + reads[i].flat_off, sizeof(int32_t) * reads[i].kc);
+    }
+  }
+  return DYN_OK;
+}
+
+int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                     const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                     dyn_batch** out) {
+  if (!a || !out) return DYN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  dyn_batch* b = new dyn_batch();
+  b->a = a;
+  b->n = n_reads;
+  prepare_reads(a->model, n_reads, sig_offsets, seqs, seq_offsets, b->reads, b->kmers, &b->capacity,
+                &b->total_cols);
+  for (const HostRead& r : b->reads) {
+    if (r.status != DYN_READ_OK) continue;
+    if (r.S + 1 > 0x7fffffffull || r.kc + 1 > 0x7fffffffull) {
+      a->last_error = "read too long for 32-bit lattice indices";
+      delete b;
+      return DYN_ERR_INVALID_ARGUMENT;
+    }
+    b->max_T = std::max<uint32_t>(b->max_T, (uint32_t)(r.S + 1));
+    b->max_N = std::max<uint32_t>(b->max_N, (uint32_t)(r.kc + 1));
+  }
+  auto cleanup = [&](int code) {
+    dyn_batch_destroy(b);
+    return code;
+  };
+#define B_TRY(expr)                                                                        \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      a->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr;   \
+      return cleanup(_e == hipErrorOutOfMemory ? DYN_ERR_OUT_OF_MEMORY : DYN_ERR_DEVICE);  \
+    }                                                                                      \
+  } while (0)
+  const uint64_t total_sig = n_reads ? sig_offsets[n_reads] - sig_offsets[0] : 0;
+  B_TRY(b->d_sig.ensure(std::max<uint64_t>(8, total_sig * 8)));
+  if (total_sig) B_TRY(hipMemcpyAsync(b->d_sig.p, signals + sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->stream));
+  for (HostRead& r : b->reads) r.sig_off -= n_reads ? sig_offsets[0] : 0;
+  B_TRY(b->d_kmers.ensure(std::max<uint64_t>(4, b->total_cols * 4)));
+  B_TRY(b->d_par.ensure(std::max<uint64_t>(sizeof(Emis), b->total_cols * sizeof(Emis))));
+  if (b->total_cols) {
+    B_TRY(hipMemcpyAsync(b->d_kmers.p, b->kmers.data(), b->total_cols * 4, hipMemcpyHostToDevice, a->stream));
+    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
+  }
+  B_TRY(b->d_state.ensure(std::max<uint64_t>(sizeof(ReadState), n_reads * sizeof(ReadState))));
+  B_TRY(b->d_rows.ensure(std::max<uint64_t>(sizeof(SegRow), b->capacity * sizeof(SegRow))));
+  B_TRY(hipStreamSynchronize(a->stream));
+#undef B_TRY
+  *out = b;
+  return DYN_OK;
+}
+
+void dyn_batch_destroy(dyn_batch* b) {
+  if (!b) return;
+  if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
+  for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
+                    &b->d_medlo, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
+    d->release();
+  delete b;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Shared engine of dyn_batch_align / dyn_batch_train: LPT order, HBM planning, chunked launches.
+enum class Job { AlignZ, AlignFull, Train };
+
+int run_job(dyn_batch* b, Job job) {
+  dyn_aligner* a = b->a;
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  const bool lattice = job != Job::AlignZ;
+  const bool calc = job == Job::AlignFull;
+  const PoreModel& m = a->model;
+  const int z_fail = job == Job::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
+
+  // per-read state (status of host-side failures is final; ok reads start at 0)
+  std::vector<ReadState> st(b->n);
+  for (uint64_t i = 0; i < b->n; ++i) {
+    st[i].Zb = 0.0;
+    st[i].Zf = 0.0;
+    st[i].status = b->reads[i].status;
+    st[i].n_segments = 0;
+  }
+  if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st.data(), b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
+
+  // longest reads first (they bound the tail of each launch)
+  std::vector<uint32_t> order;
+  for (uint64_t i = 0; i < b->n; ++i)
+    if (b->reads[i].status == DYN_READ_OK) order.push_back((uint32_t)i);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->reads[x].S > b->reads[y].S; });
+
+  if (calc) {
+    HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
+    HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));
+    HIP_TRY(a, b->d_medlo.ensure(std::max<uint64_t>(8, b->capacity * 8)));
+  }
+  if (job == Job::Train) {
+    HIP_TRY(a, b->d_colw.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
+    HIP_TRY(a, b->d_cols1.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
+    HIP_TRY(a, b->d_cols2.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
+    HIP_TRY(a, b->d_trans.ensure(std::max<uint64_t>(16, b->n * 16)));
+  }
+
+  // HBM budget for lattice workspaces
+  uint64_t budget = a->mem_budget;
+  if (lattice) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t pool = a->ws.bytes + a->bits.bytes + a->pp.bytes + a->pathn.bytes;
+    const uint64_t avail = (uint64_t)((double)(free_b + pool) * 0.90);
+    if (budget == 0 || budget > avail) budget = avail;
+  }
+  const uint64_t row_bytes = lattice_bytes_per_row(calc);
+
+  // greedy chunks in LPT order
+  std::vector<Chunk> chunks;
+  {
+    Chunk cur;
+    uint64_t used = 0;
+    for (uint32_t i : order) {
+      const uint64_t need = lattice ? (b->reads[i].S + 1) * row_bytes : 0;
+      if (lattice && need > budget) {
+        a->last_error = "a single read's lattice does not fit the HBM budget";
+        return DYN_ERR_OUT_OF_MEMORY;
+      }
+      if (!cur.idx.empty() && used + need > budget) {
+        chunks.push_back(std::move(cur));
+        cur = Chunk();
+        used = 0;
+      }
+      cur.idx.push_back(i);
+      used += need;
+    }
+    if (!cur.idx.empty()) chunks.push_back(std::move(cur));
+  }
+
+  dyn_timing tm{};
+  hipEvent_t ev[4];
+  for (auto& e : ev) HIP_TRY(a, hipEventCreate(&e));
+  struct EvGuard {
+    hipEvent_t* e;
+    ~EvGuard() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); }
+  } guard{ev};
+
+  std::vector<ReadDesc> descs;
+  for (const Chunk& ch : chunks) {
+    descs.clear();
+    uint64_t rows_total = 0;
+    uint32_t max_T = 0, max_N = 0;
+    for (uint32_t i : ch.idx) {
+      const HostRead& r = b->reads[i];
+      ReadDesc d{};
+      d.T = (uint32_t)(r.S + 1);
+      d.N = (uint32_t)(r.kc + 1);
+      d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
+      d.read = i;
+      d.ratio = (double)d.N / (double)d.T;
+      d.sig_off = r.sig_off;
+      d.par_off = r.flat_off;
+      d.seg_off = r.seg_off;
+      d.ws_off = rows_total * dynk::P;
+      d.bits_off = rows_total * dynk::CPL;
+      d.path_off = rows_total;
+      rows_total += d.T;
+      max_T = std::max(max_T, d.T);
+      max_N = std::max(max_N, d.N);
+      descs.push_back(d);
+      tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
+      tm.samples += r.S;
+    }
+    const int nr = (int)descs.size();
+    HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
+    if (lattice) HIP_TRY(a, a->ws.ensure(rows_total * dynk::P * 8));
+    if (calc) {
+      HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8));
+      HIP_TRY(a, a->pp.ensure(rows_total * 8));
+      HIP_TRY(a, a->pathn.ensure(rows_total * 4));
+    }
+    // the previous chunk still reads a->descs: stream order makes the copy safe
+    HIP_TRY(a, hipMemcpyAsync(a->descs.p, descs.data(), descs.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(a, hipStreamSynchronize(a->stream));  // descs is a host vector reused by the next chunk
+
+    const ReadDesc* dd = a->descs.as<ReadDesc>();
+    const double* sig = b->d_sig.as<double>();
+    const Emis* par = b->d_par.as<Emis>();
+    ReadState* dst = b->d_state.as<ReadState>();
+    HIP_TRY(a, hipEventRecord(ev[0], a->stream));
+    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, a->stream);
+    HIP_TRY(a, hipEventRecord(ev[1], a->stream));
+    if (job == Job::Train) {
+      dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
+      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->stream);
+    } else {
+      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->stream);
+    }
+    HIP_TRY(a, hipEventRecord(ev[2], a->stream));
+    if (calc) {
+      dynk::TraceBuffers tb{a->pp.as<double>(), a->pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
+                            b->d_medhi.as<double>(), b->d_medlo.as<double>()};
+      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, tb,
+                         b->d_rows.as<SegRow>(), m.k, z_fail, a->stream);
+    } else {
+      dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
+    }
+    HIP_TRY(a, hipEventRecord(ev[3], a->stream));
+    HIP_TRY(a, hipGetLastError());
+    HIP_TRY(a, hipStreamSynchronize(a->stream));
+    float ms01 = 0, ms12 = 0, ms23 = 0;
+    HIP_TRY(a, hipEventElapsedTime(&ms01, ev[0], ev[1]));
+    HIP_TRY(a, hipEventElapsedTime(&ms12, ev[1], ev[2]));
+    HIP_TRY(a, hipEventElapsedTime(&ms23, ev[2], ev[3]));
+    tm.ms_backward += ms01;
+    tm.ms_forward += ms12;
+    tm.ms_trace += ms23;
+    tm.ms_total += ms01 + ms12 + ms23;
+    tm.launches_backward += 1;
+    tm.launches_forward += 1;
+  }
+  tm.reads_ok = order.size();
+  b->timing = tm;
+  b->aligned = job != Job::Train;
+  b->trained = job == Job::Train;
+  b->last_calc = calc ? 1 : 0;
+  return DYN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dyn_batch_align(dyn_batch* b, int calc_probabilities) {
+  if (!b) return DYN_ERR_INVALID_ARGUMENT;
+  return run_job(b, calc_probabilities ? Job::AlignFull : Job::AlignZ);
+}
+
+int dyn_batch_train(dyn_batch* b) {
+  if (!b) return DYN_ERR_INVALID_ARGUMENT;
+  return run_job(b, Job::Train);
+}
+
+int dyn_batch_timing(const dyn_batch* b, dyn_timing* t) {
+  if (!b || !t) return DYN_ERR_INVALID_ARGUMENT;
+  *t = b->timing;
+  return DYN_OK;
+}
+
+int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, void** d_z_status) {
+  if (!b || !b->aligned) return DYN_ERR_INVALID_ARGUMENT;
+  if (d_rows) *d_rows = b->d_rows.p;
+  if (capacity) *capacity = b->capacity;
+  if (d_z_status) *d_z_status = b->d_state.p;
+  return DYN_OK;
+}
+
+int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out) {
+  if (!b || !out || !out->Z || !out->status) return DYN_ERR_INVALID_ARGUMENT;
+  dyn_aligner* a = b->a;
+  if (!b->aligned) {
+    a->last_error = "dyn_batch_fetch before dyn_batch_align";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  std::vector<ReadState> st(b->n);
+  if (b->n) HIP_TRY(a, hipMemcpy(st.data(), b->d_state.p, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
+  const bool want_rows = b->last_calc && (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
+  if (want_rows && out->capacity < b->capacity) {
+    a->last_error = "dyn_align_out.capacity is smaller than dyn_segment_capacity()";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<SegRow> rows;
+  if (want_rows && b->capacity) {
+    rows.resize(b->capacity);
+    HIP_TRY(a, hipMemcpy(rows.data(), b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost));
+  }
+  for (uint64_t i = 0; i < b->n; ++i) {
+    const HostRead& r = b->reads[i];
+    const bool ok = st[i].status == DYN_READ_OK;
+    out->status[i] = st[i].status;
+    out->Z[i] = ok ? st[i].Zb : 0.0;  // Result::Z = Zb (NT_aligner_api.cpp:293)
+    if (out->bad_char) out->bad_char[i] = r.bad;
+    if (out->seg_offsets) out->seg_offsets[i] = r.seg_off;
+    const uint64_t ns = (ok && b->last_calc) ? st[i].n_segments : 0;
+    if (out->n_segments) out->n_segments[i] = ns;
+    if (want_rows) {
+      for (uint64_t s = 0; s < ns; ++s) {
+        const SegRow& row = rows[r.seg_off + s];
+        if (out->sequence_positions) out->sequence_positions[r.seg_off + s] = row.sequence_pos;
+        if (out->signal_positions) out->signal_positions[r.seg_off + s] = row.signal_pos;
+        if (out->probabilities) out->probabilities[r.seg_off + s] = row.probability;
+        if (out->states) out->states[r.seg_off + s] = 'M';
+      }
+    }
+  }
+  if (out->seg_offsets) out->seg_offsets[b->n] = b->capacity;
+  return DYN_OK;
+}
+
+int dyn_align_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                    const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                    int calc_probabilities, dyn_align_out* out) {
+  dyn_batch* b = nullptr;
+  int rc = dyn_batch_create(a, n_reads, signals, sig_offsets, seqs, seq_offsets, &b);
+  if (rc != DYN_OK) return rc;
+  rc = dyn_batch_align(b, calc_probabilities);
+  if (rc == DYN_OK) rc = dyn_batch_fetch(b, out);
+  dyn_batch_destroy(b);
+  return rc;
+}
+
+// Host finalisation of runTraining (NT_aligner_api.cpp:516-535) from per-column sums, and of
+// trainTransition (:703-722) from the two linear-domain transition sums.
+int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n) {
+  if (!b || !out || !out->Z || !out->status) return DYN_ERR_INVALID_ARGUMENT;
+  dyn_aligner* a = b->a;
+  if (!b->trained) {
+    a->last_error = "dyn_batch_fetch_train before dyn_batch_train";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  const PoreModel& m = a->model;
+  std::vector<ReadState> st(b->n);
+  std::vector<double> cw(b->total_cols), c1(b->total_cols), c2(b->total_cols), tr(2 * b->n);
+  if (b->n) {
+    HIP_TRY(a, hipMemcpy(st.data(), b->d_state.p, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
+    HIP_TRY(a, hipMemcpy(tr.data(), b->d_trans.p, b->n * 16, hipMemcpyDeviceToHost));
+  }
+  if (b->total_cols) {
+    HIP_TRY(a, hipMemcpy(cw.data(), b->d_colw.p, b->total_cols * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(a, hipMemcpy(c1.data(), b->d_cols1.p, b->total_cols * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(a, hipMemcpy(c2.data(), b->d_cols2.p, b->total_cols * 8, hipMemcpyDeviceToHost));
+  }
+  const bool want_em = out->em_code && out->em_mean && out->em_stdev;
+  if (want_em && out->capacity < b->capacity) {
+    a->last_error = "dyn_train_out.capacity is smaller than dyn_segment_capacity()";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<std::pair<int32_t, uint64_t>> keyed;
+  for (uint64_t i = 0; i < b->n; ++i) {
+    const HostRead& r = b->reads[i];
+    const bool ok = st[i].status == DYN_READ_OK;
+    out->status[i] = st[i].status;
+    out->Z[i] = ok ? st[i].Zb : 0.0;
+    if (out->bad_char) out->bad_char[i] = r.bad;
+    if (out->em_offsets) out->em_offsets[i] = r.seg_off;
+    uint64_t count = 0;
+    if (out->transitions) {
+      double m1 = 0.0, e2 = 0.0;
+      if (ok) {
+        const double sm = tr[2 * i], se = tr[2 * i + 1];
+        const double tot = sm + se;
+        if (tot > 0.0 && !std::isinf(tot)) {
+          m1 = sm / tot;
+          e2 = se / tot;
+        }
+      }
+      out->transitions[3 * i] = m1;
+      out->transitions[3 * i + 1] = ok ? std::exp(m.log_e1) : 0.0;
+      out->transitions[3 * i + 2] = e2;
+    }
+    if (out->trans_counts) {
+      out->trans_counts[2 * i] = ok ? tr[2 * i] : 0.0;
+      out->trans_counts[2 * i + 1] = ok ? tr[2 * i + 1] : 0.0;
+    }
+    if (ok && (want_em || pooled3n)) {
+      // group the read's lattice columns by k-mer code, columns in ascending order
+      keyed.clear();
+      for (uint64_t c = 0; c < r.kc; ++c) keyed.emplace_back(b->kmers[r.flat_off + c], r.flat_off + c);
+      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      size_t p = 0;
+      while (p < keyed.size()) {
+        const int32_t code = keyed[p].first;
+        double w = 0.0, s1 = 0.0, s2 = 0.0;
+        for (; p < keyed.size() && keyed[p].first == code; ++p) {
+          w += cw[keyed[p].second];
+          s1 += c1[keyed[p].second];
+          s2 += c2[keyed[p].second];
+        }
+        if (pooled3n) {
+          pooled3n[code] += w;
+          pooled3n[m.num_kmers + code] += s1;
+          pooled3n[2 * m.num_kmers + code] += s2;
+        }
+        if (want_em && w > 0.0) {
+          const double mean = s1 / w;
+          double var = s2 / w - mean * mean;
+          if (var < 1e-12) var = 1e-12;
+          const uint64_t o = r.seg_off + count;
+          out->em_code[o] = code;
+          out->em_mean[o] = mean;
+          out->em_stdev[o] = std::sqrt(var);
+          if (out->em_weight) out->em_weight[o] = w;
+          if (out->em_sum) out->em_sum[o] = s1;
+          if (out->em_sumsq) out->em_sumsq[o] = s2;
+          ++count;
+        }
+      }
+    }
+    if (out->em_count) out->em_count[i] = count;
+  }
+  if (out->em_offsets) out->em_offsets[b->n] = b->capacity;
+  return DYN_OK;
+}
+
+int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                    const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                    dyn_train_out* out, double* pooled3n) {
+  dyn_batch* b = nullptr;
+  int rc = dyn_batch_create(a, n_reads, signals, sig_offsets, seqs, seq_offsets, &b);
+  if (rc != DYN_OK) return rc;
+  rc = dyn_batch_train(b);
+  if (rc == DYN_OK) rc = dyn_batch_fetch_train(b, out, pooled3n);
+  dyn_batch_destroy(b);
+  return rc;
+}
+
+int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
+  if (!b || !b->trained) return DYN_ERR_INVALID_ARGUMENT;
+  dyn_aligner* a = b->a;
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  // pooled statistics are produced on the host path of dyn_batch_fetch_train; the device copy
+  // is materialised on demand so an RCCL all-reduce can run on it in place
+  const uint64_t K = a->model.num_kmers;
+  std::vector<double> pooled(3 * K, 0.0);
+  std::vector<int32_t> status(b->n);
+  std::vector<double> Z(b->n);
+  dyn_train_out tmp{};
+  tmp.Z = Z.data();
+  tmp.status = status.data();
+  rc = dyn_batch_fetch_train(b, &tmp, pooled.data());
+  if (rc != DYN_OK) return rc;
+  HIP_TRY(a, b->d_pooled.ensure(3 * K * 8));
+  HIP_TRY(a, hipMemcpy(b->d_pooled.p, pooled.data(), 3 * K * 8, hipMemcpyHostToDevice));
+  if (d_pooled3n) *d_pooled3n = b->d_pooled.p;
+  if (count) *count = 3 * K;
+  return DYN_OK;
+}
+
+}  // extern "C"

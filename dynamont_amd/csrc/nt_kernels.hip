@@ -1,0 +1,662 @@
+// nt_kernels.hip -- hand-written gfx950 kernels of the NT resquiggling hot path.
+//
+// Reference being reproduced (paths relative to the reference checkout):
+//   computeBounds          src/cpp/NT_aligner_api.cpp:90-108
+//   forward                src/cpp/NT_aligner_api.cpp:110-152
+//   backward               src/cpp/NT_aligner_api.cpp:158-207
+//   calculatePosterior     src/cpp/NT_aligner_api.cpp:213-224
+//   calculateSegments      src/cpp/NT_aligner_api.cpp:314-377   (posterior-Viterbi fill)
+//   decodeMAP              src/cpp/NT_aligner_api.cpp:383-456   (traceback)
+//   formattedMedian        src/cpp/aligner.cpp:247-263
+//   runTraining            src/cpp/NT_aligner_api.cpp:462-561
+//   trainTransition        src/cpp/NT_aligner_api.cpp:641-725
+//
+// Design (not a translation): the reference streams eight T x B fp64 matrices per read. Here
+//   K_bwd  walks t = T-2..0 and stores ONLY backward-E (bM(t,n) = bE(t+1,n) + e(t+1,n) is one
+//          add away, NT_aligner_api.cpp:200);
+//   K_fwd  walks t = 1..T-1 and fuses forward, posterior (needs Zb, known after K_bwd),
+//          the posterior-Viterbi fill and the traceback decision
+//          (vE == vM_prev + LPE, NT_aligner_api.cpp:448); forward / Viterbi rows never leave
+//          registers; it overwrites each bE row in place with (float LPM, float LPE) for the
+//          path-probability lookup and writes 1 decision bit per cell;
+//   K_trace walks the decision bits back (one wave per read, 64 rows per LDS block) and
+//          K_median/K_final produce the per-segment median posterior.
+// HBM traffic is 24.1 B per in-band cell instead of the 64.1 B of the three-pass formulation
+// (SURVEY.md §8d), and the per-read footprint is 8 B per slot instead of 64 B per cell.
+//
+// One 64-lane wave owns one read; lane l owns slots l, l+64, ... (CPL of them), so every row
+// load/store is CPL fully coalesced 512-byte accesses. Cross-lane neighbours (n-1 for forward,
+// n+1 for backward) come from DPP wave rotates -- no LDS, no barriers in the DP loops.
+#include "nt_kernels.hpp"
+
+namespace dynk {
+
+using dynmath::NEG_INF;
+using dynmath::log_normal_pdf;
+using dynmath::log_plus;
+
+namespace {
+
+__device__ __forceinline__ int pmod(int a) {
+  int r = a % P;
+  return r < 0 ? r + P : r;
+}
+
+// size_t(t * RATIO): one IEEE fp64 multiply, then truncation (NT_aligner_api.cpp:100).
+__device__ __forceinline__ int band_mid(int t, double ratio) {
+  return (int)__dmul_rn((double)t, ratio);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// lane i receives lane i-1 (lane 0 receives lane 63)
+__device__ __forceinline__ double wave_ror1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// lane i receives lane i+1 (lane 63 receives lane 0)
+__device__ __forceinline__ double wave_rol1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// out[slot] = x[slot-1] over the P slots of a row (slot = j*64 + lane, cyclic).
+__device__ __forceinline__ void from_left(const double (&x)[CPL], double (&out)[CPL], int lane) {
+  double rot[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) rot[j] = wave_ror1(x[j]);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) out[j] = (lane == 0) ? rot[(j + CPL - 1) % CPL] : rot[j];
+}
+
+// out[slot] = x[slot+1]
+__device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)[CPL], int lane) {
+  double rot[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) rot[j] = wave_rol1(x[j]);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) out[j] = (lane == 63) ? rot[(j + 1) % CPL] : rot[j];
+}
+
+__device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, int N) {
+  Emis e;
+  if (n >= 1 && n < N) {
+    e = pr[n - 1];
+  } else {  // column without a k-mer (n <= 0 or beyond the sequence): benign finite constants
+    e.mean = 0.0;
+    e.stdev = 1.0;
+    e.inv_stdev = 1.0;
+    e.log_stdev = 0.0;
+  }
+  return e;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// per-column emission table: par[i] = model[kmers[i]]  (aligner.cpp:241-245 scoreKmer lookup)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __restrict__ model,
+                              Emis* __restrict__ par, uint64_t total) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) par[i] = model[kmers[i]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_bwd: backward recursion, t = T-2 .. 0 (NT_aligner_api.cpp:158-207)
+//   e(t+1,n)  = logN(sig[t]; kmers[n-1])                      emission of lattice cell (t+1,n)
+//   bM(t,n)   = bE(t+1,n) + e(t+1,n)                          (n > 0)            :197-200
+//   bE(t,n)   = logPlus( (bM(t+1,n+1) + e(t+1,n+1)) + m1 ,    (n+1 < N)          :192-195
+//                        (bE(t+1,n)   + e(t+1,n))   + e2 )    (n > 0)            :201
+// ---------------------------------------------------------------------------------------------
+template <bool STORE>
+__global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ descs,
+                                                  const double* __restrict__ sig,
+                                                  const Emis* __restrict__ par,
+                                                  double* __restrict__ ws,
+                                                  ReadState* __restrict__ st, double m1,
+                                                  double e2) {
+  const ReadDesc rd = descs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const double ratio = rd.ratio;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const Emis* __restrict__ pr = par + rd.par_off;
+  double* __restrict__ out = ws + rd.ws_off;
+
+  int lo = band_mid(T - 1, ratio) - bw;
+  const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
+  int n[CPL];
+  double bE[CPL], bM[CPL];
+  Emis p[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int slot = j * 64 + lane;
+    n[j] = lo + pmod(slot - lo);
+    p[j] = load_emis(pr, n[j], N);
+    bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
+    bM[j] = NEG_INF;
+    if (STORE) out[(size_t)(T - 1) * P + slot] = bE[j];
+  }
+
+  for (int thi = T - 2; thi >= 0; thi -= 64) {
+    const int base = thi - 63;
+    const int idx = base + lane;
+    const double xs = (idx >= 0) ? sg[idx] : 0.0;
+    const int ilo = base < 0 ? -base : 0;
+#pragma unroll 1
+    for (int i = 63; i >= ilo; --i) {
+      const int t = base + i;
+      const double x = readlane_f64(xs, i);
+      double Y[CPL], A[CPL], Yr[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const double e = log_normal_pdf(x, p[j]);
+        Y[j] = bM[j] + e;
+        A[j] = bE[j] + e;
+      }
+      from_right(Y, Yr, lane);
+      const int new_lo = band_mid(t, ratio) - bw;
+      if (new_lo != lo) {  // wave-uniform: the window moved down by one column
+        const int leaving = lo + P - 1;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (n[j] == leaving) {
+            n[j] = new_lo;
+            p[j] = load_emis(pr, new_lo, N);
+          }
+        }
+        lo = new_lo;
+      }
+      const int hi_n = min(lo + W - 1, N - 1);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int nn = n[j];
+        const bool valid = (nn >= 0) && (nn <= hi_n);
+        const double ext1 = (nn + 1 < N) ? Yr[j] + m1 : NEG_INF;
+        const double a = (nn > 0) ? A[j] : NEG_INF;
+        const double ne = log_plus(ext1, a + e2);
+        bE[j] = valid ? ne : NEG_INF;
+        bM[j] = valid ? a : NEG_INF;
+        if (STORE) out[(size_t)t * P + j * 64 + lane] = bE[j];
+      }
+    }
+  }
+  // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
+  if (lane == 0) st[rd.read].Zb = bE[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_fwd: forward (NT_aligner_api.cpp:110-152) fused with posterior (:213-224,297-300) and the
+// posterior-Viterbi fill (:338-363), t = 1 .. T-1:
+//   e(t,n)   = logN(sig[t-1]; kmers[n-1])
+//   fM(t,n)  = (fE(t-1,n-1) + e) + m1                                             :146
+//   fE(t,n)  = logPlus( (fM(t-1,n) + e) + e1 , (fE(t-1,n) + e) + e2 ), e1 = log 1 = 0   :147-149
+//   LPM      = (fM + bM) - Zb,  LPE = (fE + bE) - Zb                              :222
+//   vM(t,n)  = vE(t-1,n-1) + LPM ;  vE(t,n) = max(vM(t-1,n), vE(t-1,n)) + LPE     :360-361
+//   bit(t,n) = ( vE(t,n) == vM(t-1,n) + LPE )                                     :448
+// ---------------------------------------------------------------------------------------------
+template <bool POST>
+__global__ __launch_bounds__(64) void k_forward(const ReadDesc* __restrict__ descs,
+                                                 const double* __restrict__ sig,
+                                                 const Emis* __restrict__ par,
+                                                 double* __restrict__ ws,
+                                                 uint64_t* __restrict__ bits,
+                                                 ReadState* __restrict__ st, double m1,
+                                                 double e2) {
+  const ReadDesc rd = descs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const double ratio = rd.ratio;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const Emis* __restrict__ pr = par + rd.par_off;
+  double* __restrict__ lat = ws + rd.ws_off;
+  float2* __restrict__ lat_lp = reinterpret_cast<float2*>(lat);
+  uint64_t* __restrict__ bt = bits + rd.bits_off;
+  const double Z = POST ? st[rd.read].Zb : 0.0;
+
+  int lo = band_mid(0, ratio) - bw;  // = -bw
+  int n[CPL];
+  double fM[CPL], fE[CPL], e[CPL];
+  double vM[CPL], vE[CPL], bcur[CPL], bnext[CPL];
+  Emis p[CPL];
+  const double x0 = sg[0];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int slot = j * 64 + lane;
+    n[j] = lo + pmod(slot - lo);
+    p[j] = load_emis(pr, n[j], N);
+    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
+    fM[j] = NEG_INF;
+    e[j] = log_normal_pdf(x0, p[j]);      // e(1, n)
+    if (POST) {
+      vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
+      vM[j] = NEG_INF;
+      bcur[j] = lat[(size_t)1 * P + slot];
+      bnext[j] = (T > 2) ? lat[(size_t)2 * P + slot] : NEG_INF;
+    }
+  }
+
+  for (int tb = 1; tb < T; tb += 64) {
+    const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
+    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    const int iend = min(64, T - tb);
+#pragma unroll 1
+    for (int i = 0; i < iend; ++i) {
+      const int t = tb + i;
+      const double xn = readlane_f64(xs, i);
+      double fEl[CPL], vEl[CPL], bnn[CPL];
+      from_left(fE, fEl, lane);
+      if (POST) {
+        from_left(vE, vEl, lane);
+        const bool have = (t + 2 < T);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+          bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64 + lane] : NEG_INF;
+      }
+      const int new_lo = band_mid(t, ratio) - bw;
+      if (new_lo != lo) {  // wave-uniform: the window moved up by one column
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (n[j] == lo) {
+            n[j] = lo + P;
+            p[j] = load_emis(pr, lo + P, N);
+          }
+        }
+        lo = new_lo;
+      }
+      const int lo_n = max(lo, 1);
+      const int hi_n = min(lo + W - 1, N - 1);
+      uint64_t mybits = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int nn = n[j];
+        const bool valid = (nn >= lo_n) && (nn <= hi_n);
+        const double ee = e[j];
+        double fMn = (fEl[j] + ee) + m1;
+        double fEn = log_plus(fM[j] + ee, (fE[j] + ee) + e2);
+        fMn = valid ? fMn : NEG_INF;
+        fEn = valid ? fEn : NEG_INF;
+        const double en = log_normal_pdf(xn, p[j]);  // e(t+1, n)
+        if (POST) {
+          const double bMt = bnext[j] + en;          // bM(t,n) = bE(t+1,n) + e(t+1,n)
+          const double LPM = (fMn + bMt) - Z;
+          const double LPE = (fEn + bcur[j]) - Z;
+          double vMn = vEl[j] + LPM;
+          const double vmx = fmax(vM[j], vE[j]);
+          double vEn = vmx + LPE;
+          const bool bit = (vEn == vM[j] + LPE);
+          vMn = valid ? vMn : NEG_INF;
+          vEn = valid ? vEn : NEG_INF;
+          const uint64_t b = __ballot(bit);
+          if (lane == j) mybits = b;
+          lat_lp[(size_t)t * P + j * 64 + lane] = make_float2((float)LPM, (float)LPE);
+          vM[j] = vMn;
+          vE[j] = vEn;
+          bcur[j] = bnext[j];
+          bnext[j] = bnn[j];
+        }
+        fM[j] = fMn;
+        fE[j] = fEn;
+        e[j] = en;
+      }
+      if (POST && lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
+    }
+  }
+  // Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285)
+  const int nf = band_mid(T - 1, ratio);
+  const int sf = pmod(nf);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j)
+    if (j == (sf >> 6) && lane == (sf & 63)) st[rd.read].Zf = fE[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Z check of align()/train() (NT_aligner_api.cpp:285-291 / 619-625) for the calc=false path.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool z_ok(const ReadDesc& rd, const ReadState& s) {
+  const double size = (double)((uint64_t)rd.T * (uint64_t)(2 * rd.bw + 3));
+  if (isinf(s.Zf) || isinf(s.Zb)) return false;
+  return !(fabs(s.Zf - s.Zb) / size > 1e-8);
+}
+
+__global__ void k_zcheck(const ReadDesc* __restrict__ descs, int n_reads,
+                         ReadState* __restrict__ st, int fail_status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_reads) return;
+  const ReadDesc rd = descs[i];
+  ReadState s = st[rd.read];
+  if (s.status != 0) return;
+  if (!z_ok(rd, s)) st[rd.read].status = fail_status;
+  st[rd.read].n_segments = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_trace: decodeMAP (NT_aligner_api.cpp:383-456). Start in state E at (T-1, N-1); walk the
+// decision bits. Each lattice row 1..T-1 holds exactly one path cell, so the walk is recorded
+// as pathn[row] (column, bit31 = state M) and pp[row] = exp(LP of that cell); a segment is the
+// run of rows that share a column, its M cell is the lowest row (segrow).
+// 64 rows of bits are staged in LDS per step so the serial walk pays LDS, not HBM, latency.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace(const ReadDesc* __restrict__ descs,
+                                               const double* __restrict__ ws,
+                                               const uint64_t* __restrict__ bits,
+                                               ReadState* __restrict__ st, TraceBuffers tb,
+                                               int fail_status) {
+  __shared__ uint64_t sb[64 * CPL];
+  const ReadDesc rd = descs[blockIdx.x];
+  const int lane = threadIdx.x;
+  ReadState s = st[rd.read];
+  if (s.status != 0) return;
+  if (!z_ok(rd, s)) {
+    if (lane == 0) {
+      st[rd.read].status = fail_status;
+      st[rd.read].n_segments = 0;
+    }
+    return;
+  }
+  const int T = (int)rd.T, N = (int)rd.N;
+  const float2* __restrict__ lp = reinterpret_cast<const float2*>(ws + rd.ws_off);
+  const uint64_t* __restrict__ bt = bits + rd.bits_off;
+  double* __restrict__ pp = tb.pp + rd.path_off;
+  uint32_t* __restrict__ pathn = tb.pathn + rd.path_off;
+  uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+
+  int t = T - 1, n = N - 1;
+  int slot = n % P;
+  int stM = 0;
+  while (t > 0 && n > 0) {
+    const int base = t - 63;
+    const int row = base + lane;
+    if (row >= 1) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) sb[lane * CPL + j] = bt[(size_t)row * CPL + j];
+    }
+    __syncthreads();
+    int my_n = 0, my_slot = 0, my_st = -1;
+    for (int i = 63; i >= 0; --i) {
+      if (t == 0 || n == 0) break;
+      if (lane == i) {
+        my_n = n;
+        my_slot = slot;
+        my_st = stM;
+      }
+      if (stM) {  // M(t,n) -> E(t-1,n-1)
+        --n;
+        slot = slot ? slot - 1 : P - 1;
+        stM = 0;
+      } else {    // E(t,n) -> M or E at (t-1,n)
+        const uint64_t w = sb[i * CPL + (slot >> 6)];
+        const uint32_t wl = __builtin_amdgcn_readfirstlane((uint32_t)w);
+        const uint32_t wh = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
+        const int sh = slot & 63;
+        stM = (sh < 32 ? (wl >> sh) : (wh >> (sh - 32))) & 1;
+      }
+      --t;
+    }
+    if (my_st >= 0) {
+      const float2 v = lp[(size_t)row * P + my_slot];
+      pp[row] = exp((double)(my_st ? v.x : v.y));
+      pathn[row] = (uint32_t)my_n | (my_st ? 0x80000000u : 0u);
+      if (my_st) segrow[my_n - 1] = (uint32_t)row;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const bool complete = (t == 0 && n == 0);
+    st[rd.read].status = complete ? 0 : 7;
+    st[rd.read].n_segments = complete ? (uint32_t)(N - 1) : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_median: formattedMedian (aligner.cpp:247-263) by rank counting. One thread per path row;
+// the segment of column n spans rows [segrow[n-1], segrow[n]) (last column: up to T-1).
+// Ties are broken by row so ranks are a permutation.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                         TraceBuffers tb) {
+  const ReadDesc rd = descs[blockIdx.y];
+  if (st[rd.read].status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (t >= T) return;
+  const double* __restrict__ pp = tb.pp + rd.path_off;
+  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+  const int n = (int)(tb.pathn[rd.path_off + t] & 0x7fffffffu);
+  const int a = (int)segrow[n - 1];
+  const int b = (n < N - 1) ? (int)segrow[n] : T;
+  const int L = b - a;
+  const double x = pp[t];
+  int rank = 0;
+  for (int u = a; u < b; ++u) {
+    const double y = pp[u];
+    rank += (y < x) || (y == x && u < t);
+  }
+  const int mid = L >> 1;
+  if (rank == mid) tb.med_hi[rd.seg_off + n - 1] = x;
+  if (!(L & 1) && rank == mid - 1) tb.med_lo[rd.seg_off + n - 1] = x;
+}
+
+// K_final: one output row per segment (NT_aligner_api.cpp:420-430).
+__global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                        TraceBuffers tb, SegRow* __restrict__ rows, int kmer_size) {
+  const ReadDesc rd = descs[blockIdx.y];
+  if (st[rd.read].status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // segment index = column - 1
+  if (i >= N - 1) return;
+  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+  const int a = (int)segrow[i];
+  const int b = (i + 1 < N - 1) ? (int)segrow[i + 1] : T;
+  const int L = b - a;
+  const double hi = tb.med_hi[rd.seg_off + i];
+  SegRow r;
+  r.signal_pos = (uint32_t)(a - 1);
+  r.sequence_pos = (uint32_t)(i + kmer_size / 2);
+  r.probability = (L & 1) ? hi : (tb.med_lo[rd.seg_off + i] + hi) / 2.0;
+  rows[rd.seg_off + i] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_fwd_train: forward fused with the Baum-Welch statistics of runTraining / trainTransition.
+// Per lattice cell (t >= 1, n >= 1), with gamma_M = exp(LPM), gamma_E = exp(LPE):
+//   w[kmer] += gamma_M + gamma_E ; s1 += gamma*x ; s2 += gamma*x*x      NT_aligner_api.cpp:505-512
+// Transition expectations (:683,:690) are rewritten through the recursions they sum over:
+//   fE(t,n)+m1+e(t+1,n+1)+bM(t+1,n+1) = fM(t+1,n+1)+bM(t+1,n+1)  ->  sum exp(LPM) over cells
+//   fE(t,n)+e2+e(t+1,n)+bE(t+1,n)     = second logPlus operand of fE(t+1,n) + bE(t+1,n)
+// so both are plain sums of per-cell posteriors (linear domain, relative to Zb).
+// Column sums stay in registers while the column is in the band and are flushed once per column.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_forward_train(const ReadDesc* __restrict__ descs,
+                                                       const double* __restrict__ sig,
+                                                       const Emis* __restrict__ par,
+                                                       const double* __restrict__ ws,
+                                                       ReadState* __restrict__ st,
+                                                       TrainBuffers tb, double m1, double e2) {
+  const ReadDesc rd = descs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const double ratio = rd.ratio;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const Emis* __restrict__ pr = par + rd.par_off;
+  const double* __restrict__ lat = ws + rd.ws_off;
+  double* __restrict__ cw = tb.col_w + rd.par_off;
+  double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
+  double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
+  const double Z = st[rd.read].Zb;
+
+  int lo = band_mid(0, ratio) - bw;
+  int n[CPL];
+  double fM[CPL], fE[CPL], e[CPL], bcur[CPL], bnext[CPL];
+  double aw[CPL], a1[CPL], a2[CPL];
+  Emis p[CPL];
+  double sumM = 0.0, sumE2 = 0.0;
+  const double x0 = sg[0];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int slot = j * 64 + lane;
+    n[j] = lo + pmod(slot - lo);
+    p[j] = load_emis(pr, n[j], N);
+    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
+    fM[j] = NEG_INF;
+    e[j] = log_normal_pdf(x0, p[j]);
+    bcur[j] = lat[(size_t)1 * P + slot];
+    bnext[j] = (T > 2) ? lat[(size_t)2 * P + slot] : NEG_INF;
+    aw[j] = a1[j] = a2[j] = 0.0;
+  }
+
+  double xcur = x0;  // sample of row t
+  for (int tb0 = 1; tb0 < T; tb0 += 64) {
+    const int idx = tb0 + lane;
+    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    const int iend = min(64, T - tb0);
+#pragma unroll 1
+    for (int i = 0; i < iend; ++i) {
+      const int t = tb0 + i;
+      const double xn = readlane_f64(xs, i);
+      double fEl[CPL], bnn[CPL];
+      from_left(fE, fEl, lane);
+      const bool have = (t + 2 < T);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64 + lane] : NEG_INF;
+      const int new_lo = band_mid(t, ratio) - bw;
+      if (new_lo != lo) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (n[j] == lo) {
+            if (n[j] >= 1 && n[j] < N) {  // column leaves the band for good: flush its sums
+              cw[n[j] - 1] = aw[j];
+              cs1[n[j] - 1] = a1[j];
+              cs2[n[j] - 1] = a2[j];
+            }
+            aw[j] = a1[j] = a2[j] = 0.0;
+            n[j] = lo + P;
+            p[j] = load_emis(pr, lo + P, N);
+          }
+        }
+        lo = new_lo;
+      }
+      const int lo_n = max(lo, 1);
+      const int hi_n = min(lo + W - 1, N - 1);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int nn = n[j];
+        const bool valid = (nn >= lo_n) && (nn <= hi_n);
+        const double ee = e[j];
+        double fMn = (fEl[j] + ee) + m1;
+        const double op2 = (fE[j] + ee) + e2;
+        double fEn = log_plus(fM[j] + ee, op2);
+        fMn = valid ? fMn : NEG_INF;
+        fEn = valid ? fEn : NEG_INF;
+        const double en = log_normal_pdf(xn, p[j]);
+        const double bMt = bnext[j] + en;
+        const double gM = valid ? exp((fMn + bMt) - Z) : 0.0;
+        const double gE = valid ? exp((fEn + bcur[j]) - Z) : 0.0;
+        const double gT = valid ? exp((op2 + bcur[j]) - Z) : 0.0;
+        const double g = gM + gE;
+        aw[j] += g;
+        a1[j] += g * xcur;
+        a2[j] += g * xcur * xcur;
+        sumM += gM;
+        sumE2 += gT;
+        fM[j] = fMn;
+        fE[j] = fEn;
+        e[j] = en;
+        bcur[j] = bnext[j];
+        bnext[j] = bnn[j];
+      }
+      xcur = xn;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    if (n[j] >= 1 && n[j] < N && n[j] >= lo) {
+      cw[n[j] - 1] = aw[j];
+      cs1[n[j] - 1] = a1[j];
+      cs2[n[j] - 1] = a2[j];
+    }
+  }
+  // wave reduction of the two transition sums
+  for (int off = 32; off >= 1; off >>= 1) {
+    sumM += __shfl_xor(sumM, off);
+    sumE2 += __shfl_xor(sumE2, off);
+  }
+  const int nf = band_mid(T - 1, ratio);
+  const int sf = pmod(nf);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j)
+    if (j == (sf >> 6) && lane == (sf & 63)) st[rd.read].Zf = fE[j];
+  if (lane == 0) {
+    tb.trans[2 * rd.read] = sumM;
+    tb.trans[2 * rd.read + 1] = sumE2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
+                        hipStream_t s) {
+  if (!total) return;
+  const int block = 256;
+  const uint64_t want = (total + block - 1) / block;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(k_prep_params, dim3(grid), dim3(block), 0, s, kmers, model, par, total);
+}
+
+void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
+                     double* ws, ReadState* st, double m1, double e2, bool store, hipStream_t s) {
+  if (n_reads <= 0) return;
+  if (store)
+    hipLaunchKernelGGL(k_backward<true>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, m1, e2);
+  else
+    hipLaunchKernelGGL(k_backward<false>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, m1, e2);
+}
+
+void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
+                    double* ws, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
+                    hipStream_t s) {
+  if (n_reads <= 0) return;
+  if (post)
+    hipLaunchKernelGGL(k_forward<true>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, bits, st, m1, e2);
+  else
+    hipLaunchKernelGGL(k_forward<false>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, bits, st, m1, e2);
+}
+
+void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
+                          const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
+                          hipStream_t s) {
+  if (n_reads <= 0) return;
+  hipLaunchKernelGGL(k_forward_train, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, tb, m1, e2);
+}
+
+void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,
+                   hipStream_t s) {
+  if (n_reads <= 0) return;
+  hipLaunchKernelGGL(k_zcheck, dim3((n_reads + 255) / 256), dim3(256), 0, s, descs, n_reads, st,
+                     z_fail_status);
+}
+
+void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
+                  const double* ws, const uint64_t* bits, ReadState* st, TraceBuffers tb,
+                  SegRow* rows, int kmer_size, int z_fail_status, hipStream_t s) {
+  if (n_reads <= 0) return;
+  hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, ws, bits, st, tb, z_fail_status);
+  hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb);
+  hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb, rows,
+                     kmer_size);
+}
+
+}  // namespace dynk

@@ -1,0 +1,217 @@
+/*
+ * dynamont_mi.h -- C ABI of the MI355X-native NT ("basic" mode) resquiggling core.
+ *
+ * This is the drop-in boundary for the one hot path of rnajena/dynamont that this repository
+ * accelerates. The reference has no C ABI of its own: its boundary is the pybind11 class
+ * `_dynamont.Aligner` (src/cpp/aligner_bindings.cpp:180-219) over the virtual C++ interface
+ * dynamont::Aligner::{align,train} (include/dynamont/aligner.hpp:72-81). Every entry point
+ * below names the reference interface it replaces. All citations are relative to the
+ * reference checkout.
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the ABI; functions return
+ * a dyn_status; message texts equal the reference's exception texts (callers print them
+ * into the `.errors` file, segment.py:172-176, so they are observable output).
+ * A handle is bound to ONE GPU (one process per GPU; shard reads across handles/ranks).
+ * A handle is not re-entrant: serialise calls per handle (the reference keeps one Aligner per
+ * worker process, segment.py:34-45).
+ */
+#ifndef DYNAMONT_MI_H
+#define DYNAMONT_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYN_ABI_VERSION 1
+
+/* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
+ * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
+ * entry point fails with DYN_ERR_DEVICE -- there is no CPU compute path in this library. */
+#define DYN_DEVICE_HOST_ONLY (-2)
+
+/* dynamont::PoreType (include/dynamont/aligner.hpp:26-33), same numbering as the pybind enum
+ * (aligner_bindings.cpp:184-189). */
+enum dyn_pore {
+  DYN_PORE_RNA002 = 0,
+  DYN_PORE_RNA004 = 1,
+  DYN_PORE_DNA_R9 = 2,
+  DYN_PORE_DNA_R10_260 = 3,
+  DYN_PORE_DNA_R10_400 = 4
+};
+
+/* Call-level status. INVALID_ARGUMENT corresponds to std::invalid_argument (-> Python
+ * ValueError), RUNTIME to std::runtime_error (-> Python RuntimeError) in the reference. */
+enum dyn_status {
+  DYN_OK = 0,
+  DYN_ERR_INVALID_ARGUMENT = 1,
+  DYN_ERR_RUNTIME = 2,
+  DYN_ERR_DEVICE = 3,      /* HIP runtime failure / no GPU / kernel image missing */
+  DYN_ERR_OUT_OF_MEMORY = 4
+};
+
+/* Per-read status: a failing read never aborts its batch (segment.py:160-187). */
+enum dyn_read_status {
+  DYN_READ_OK = 0,
+  DYN_READ_SIGNAL_EMPTY = 1,     /* "Signal is empty"                        aligner.cpp:149-152 */
+  DYN_READ_SEQ_SHORT = 2,        /* "Sequence shorter than model kmer size"  aligner.cpp:154-157 */
+  DYN_READ_SIGNAL_SHORT = 3,     /* "Signal too short compared to sequence"  aligner.cpp:159-163 */
+  DYN_READ_INVALID_NT = 4,       /* "Invalid nucleotide: X"                  aligner.cpp:180-196 */
+  DYN_READ_Z_MISMATCH = 5,       /* "Alignment failed: alignment scores do not match"  NT_aligner_api.cpp:288-291 */
+  DYN_READ_TRAIN_Z_MISMATCH = 6, /* "Training failed: alignment scores do not match"   NT_aligner_api.cpp:622-625 */
+  DYN_READ_INTERNAL = 7          /* traceback left the lattice (cannot happen once the Z check passed) */
+};
+
+typedef struct dyn_aligner dyn_aligner;
+typedef struct dyn_batch dyn_batch;
+
+typedef struct dyn_info {
+  int32_t abi_version;
+  int32_t pore;
+  int32_t rna;             /* 1 for RNA pores (aligner.cpp:62-86) */
+  int32_t kmer_size;
+  int32_t alphabet_size;   /* inferred from the model file (aligner.cpp:118) */
+  int32_t device;
+  uint64_t num_kmers;      /* alphabet_size ** kmer_size */
+  uint64_t half_band;      /* band / 2 (aligner.cpp:21) */
+  double log_m1, log_e1, log_e2; /* NT_aligner_api.cpp:84-86 */
+  uint64_t max_half_band;  /* largest half band this build's kernels support */
+} dyn_info;
+
+/* One output row per segment (= one CSV line of segmentation_to_string, utils.py:193-232).
+ * state is always 'M' on the NT path (NT_aligner_api.cpp:424-430) and is not stored per row. */
+typedef struct dyn_segment_row {
+  uint32_t signal_pos;   /* Segment::signalPosition   */
+  uint32_t sequence_pos; /* Segment::sequencePosition */
+  double probability;    /* Segment::probability      */
+} dyn_segment_row;
+
+/* Caller-allocated result arrays for dyn_align_batch / dyn_batch_fetch.
+ * Segment arrays must hold dyn_segment_capacity() entries; read i's segments start at
+ * seg_offsets[i] and there are n_segments[i] of them (0 when calc_probabilities == 0 or the
+ * read failed). Any pointer except Z/status may be NULL to skip that column. */
+typedef struct dyn_align_out {
+  double* Z;                  /* [n_reads]  Result::Z (= backward score)        */
+  int32_t* status;            /* [n_reads]  dyn_read_status                      */
+  char* bad_char;             /* [n_reads]  offending base for DYN_READ_INVALID_NT, else 0 */
+  uint64_t* seg_offsets;      /* [n_reads+1]                                     */
+  uint64_t* n_segments;       /* [n_reads]                                       */
+  uint64_t* sequence_positions; /* [capacity]  aligner_bindings.cpp:59,72        */
+  uint64_t* signal_positions;   /* [capacity]  aligner_bindings.cpp:60,73        */
+  double* probabilities;        /* [capacity]  aligner_bindings.cpp:61,74        */
+  uint8_t* states;              /* [capacity]  'M'                               */
+  uint64_t capacity;
+} dyn_align_out;
+
+/* Per-read training results (replaces dynamont::TrainingResult, aligner.hpp:48-53, whose
+ * pybind form is a list of num_kmers dicts per read, aligner_bindings.cpp:86-107). The emission
+ * update is returned SPARSE: only k-mers with weight > 0 (all others keep the loaded model,
+ * NT_aligner_api.cpp:531-534). Read i's entries start at em_offsets[i]; there are em_count[i]. */
+typedef struct dyn_train_out {
+  double* Z;              /* [n_reads] */
+  int32_t* status;        /* [n_reads] */
+  char* bad_char;         /* [n_reads] or NULL */
+  double* transitions;    /* [3*n_reads] m1, e1, e2 as probabilities (NT_aligner_api.cpp:703-722) */
+  uint64_t* em_offsets;   /* [n_reads+1] */
+  uint64_t* em_count;     /* [n_reads] */
+  int32_t* em_code;       /* [capacity] k-mer code */
+  double* em_mean;        /* [capacity] */
+  double* em_stdev;       /* [capacity] */
+  double* em_weight;      /* [capacity] or NULL: expected count w (sufficient statistic)  */
+  double* em_sum;         /* [capacity] or NULL: sum of gamma*x                            */
+  double* em_sumsq;       /* [capacity] or NULL: sum of gamma*x*x                          */
+  double* trans_counts;   /* [2*n_reads] or NULL: expected #(E->M) and #(E->E) transitions (linear) */
+  uint64_t capacity;      /* >= dyn_segment_capacity() */
+} dyn_train_out;
+
+/* Kernel timings of the last dyn_batch_align / dyn_batch_train on a batch, measured with HIP
+ * events on the stream the kernels were launched on. */
+typedef struct dyn_timing {
+  double ms_total;       /* first launch -> last launch complete */
+  double ms_backward;    /* K_bwd  */
+  double ms_forward;     /* K_fwd (forward + posterior + posterior-Viterbi, fused) */
+  double ms_trace;       /* K_trace + K_median + K_final */
+  uint64_t cells;        /* in-band lattice cells processed: sum over ok reads of T*min(2bw+1,N) */
+  uint64_t samples;      /* sum of signal lengths over ok reads */
+  uint64_t reads_ok;
+  uint32_t launches_backward, launches_forward; /* >1 when the batch was split to fit HBM */
+  uint32_t reserved;
+} dyn_timing;
+
+/* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
+ * message "Unknown pore type: <s>". */
+int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errcap);
+
+/* PyAligner ctor -> makeAligner -> NTAligner ctor (aligner_bindings.cpp:34-51,112-130;
+ * NT_aligner_api.cpp:11-19; aligner.cpp:13-36,88-143). mode must be "basic" or "nt"
+ * ("resquiggle"/"ntk" are out of scope, any other value -> "Unknown aligner mode: <m>").
+ * device < 0 -> current HIP device. */
+int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
+                       uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap);
+void dyn_aligner_destroy(dyn_aligner* a);
+int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
+/* Dense model table in k-mer-code order, (mean, stdev) interleaved, 2*num_kmers doubles. */
+int dyn_aligner_model(const dyn_aligner* a, double* out2n);
+/* Upper limit on HBM used for lattice workspaces (bytes; 0 = 90 % of free memory). */
+int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
+/* Message of the last failing call on this handle (thread-unsafe like the handle itself). */
+const char* dyn_aligner_last_error(const dyn_aligner* a);
+/* Reference exception text for a per-read status (bad_char fills "Invalid nucleotide: X"). */
+int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap);
+
+/* Number of segment rows to allocate: sum over reads of max(0, len(seq_i) - k + 1). */
+uint64_t dyn_segment_capacity(const dyn_aligner* a, uint64_t n_reads, const uint64_t* seq_offsets);
+
+/* Host front half of align()/train() only: validateInput (aligner.cpp:145-164) then
+ * sequenceToKmers (aligner.cpp:166-205) per read. status/bad_char: [n_reads]. kmers_out
+ * (optional): k-mer codes of read i at kmers_out[seg_offset_i ...] in the dyn_segment_capacity()
+ * layout (prefix sums of max(0, len_i - k + 1)). Needs no GPU. */
+int dyn_validate_batch(const dyn_aligner* a, uint64_t n_reads, const uint64_t* sig_offsets,
+                       const char* seqs, const uint64_t* seq_offsets, int32_t* status,
+                       char* bad_char, int32_t* kmers_out, uint64_t kmers_cap);
+
+/* NTAligner::align for a batch of reads held in HOST memory (NT_aligner_api.cpp:230-312):
+ * signals = concatenated fp64 samples, read i = [sig_offsets[i], sig_offsets[i+1]);
+ * seqs = concatenated bases (aligner orientation), read i = [seq_offsets[i], seq_offsets[i+1]).
+ * Equivalent to create + align + fetch + destroy of a dyn_batch. */
+int dyn_align_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                    const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                    int calc_probabilities, dyn_align_out* out);
+
+/* NTAligner::train for a batch (NT_aligner_api.cpp:567-639, 462-561, 641-725).
+ * pooled3n (optional, 3*num_kmers doubles, caller-zeroed or accumulated across calls) receives
+ * the batch-pooled sufficient statistics sum_i (w, s1, s2) in k-mer-code order -- the quantity
+ * a multi-GPU job all-reduces (BASELINE.json config 5). */
+int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                    const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                    dyn_train_out* out, double* pooled3n);
+
+/* ---- staged form: inputs resident in HBM before the timed region (bench.py, pipelining) ---- */
+
+/* Validate (aligner.cpp:145-164), k-mer-code (aligner.cpp:166-205), and upload one batch. */
+int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                     const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                     dyn_batch** out);
+void dyn_batch_destroy(dyn_batch* b);
+/* Run the kernels (stream-ordered, returns after the stream is idle). */
+int dyn_batch_align(dyn_batch* b, int calc_probabilities);
+int dyn_batch_train(dyn_batch* b);
+/* Copy results of the last dyn_batch_align to the host. */
+int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out);
+int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n);
+/* Device-resident results of the last dyn_batch_align, for an RCCL gather without a host hop:
+ * rows = dyn_segment_row[capacity] (read i at seg_offsets[i], as in dyn_align_out);
+ * z_status = per read {double Z; int32 status; uint32 n_segments}. Pointers stay valid until the
+ * next call on the batch. */
+int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, void** d_z_status);
+/* Device-resident pooled sufficient statistics (3*num_kmers doubles) of the last
+ * dyn_batch_train, for an RCCL all-reduce. */
+int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count);
+int dyn_batch_timing(const dyn_batch* b, dyn_timing* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAMONT_MI_H */
