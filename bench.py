@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path (NTAligner::align with calc_probabilities=true for every
+read: backward, fused forward+posterior+posterior-Viterbi, traceback, medians) over one batch
+of synthetic reads whose inputs are ALREADY resident in HBM (dyn_batch_create ran before the
+timed region); the step ends with the segment rows in HBM and, for N > 1, gathered to rank 0
+over RCCL. `value` = signal samples of all ranks / max-over-ranks time.
+
+N = 1 workload: BASELINE.json configs[1] -- 1 024 synthetic RNA004 reads x ~20 k samples,
+synthetic 9-mer model, --mode basic, band 400. Weak scaling: every rank gets its own 1 024 reads.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+SURVEY_BYTES_PER_CELL = 64.125   # three-pass fp64 formulation, whole align()
+KFWD_BYTES_PER_CELL = 16.125     # this design, dominant kernel: read bE 8 B + write (LPM,LPE) 8 B + 1 bit
+KBWD_BYTES_PER_CELL = 8.0        # this design: write bE
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg2_small"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU sample (0 = 2 per core)")
+    ap.add_argument("--reads", type=int, default=0, help="experiment only: override reads per GPU (not a bench line)")
+    return ap.parse_args()
+
+
+def start_cpu_baseline(args, model_path, workdir):
+    """Launch the CPU baseline as a child process BEFORE this process touches the GPU."""
+    cores = min(os.cpu_count() or 1, 16)
+    n = args.cpu_reads or 2 * cores
+    out = os.path.join(workdir, "cpu_baseline.json")
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--model", model_path,
+           "--workload", args.workload, "--reads", str(n), "--procs", str(cores), "--out", out]
+    return subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), out
+
+
+def load_traffic():
+    """HBM bytes per K_fwd launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    n_gpus = world
+
+    from dynamont_amd import synth
+    cfgname = "cfg2" if args.workload == "cfg2_small" else args.workload
+    cfg = dict(synth.CONFIGS[cfgname])
+    if args.workload == "cfg2_small":
+        cfg["n_reads"] = 64
+    if args.reads:
+        cfg["n_reads"] = args.reads
+    pore = cfg["pore"]
+    _, rna, k = synth.PORES[pore]
+    workdir = tempfile.mkdtemp(prefix=f"dyn_bench_r{rank}_")
+    model_path = synth.write_model(os.path.join(workdir, f"syn{k}.model"), k, seed=7, stdev=0.25 if k == 5 else 0.15)
+
+    cpu_proc = cpu_out = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu_proc, cpu_out = start_cpu_baseline(args, model_path, workdir)
+        # the CPU sample uses every host core: let it finish before timing the GPU
+        _, err = cpu_proc.communicate()
+        if cpu_proc.returncode != 0:
+            print("cpu baseline failed:\n" + err.decode(errors="replace")[-2000:], file=sys.stderr)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: dynamont_amd has no CPU compute path")
+    torch.cuda.set_device(local_rank)
+    if n_gpus > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from dynamont_amd import Aligner
+
+    _, mean, sd = synth.read_model_file(model_path)
+    reads = synth.make_reads(cfg["seed"] + 1000 * rank, cfg["n_reads"], pore, mean, sd, cfg["n_bases"])
+    sig, sig_off, seqs, seq_off = synth.pack_reads(reads)
+    n_samples = int(sig_off[-1])
+
+    al = Aligner(model_path, pore, mode="basic", band=400, device=local_rank)
+    t0 = time.perf_counter()
+    batch = al.batch_packed(sig, sig_off, seqs, seq_off)  # validate + k-mer code + H2D: outside the timed region
+    t_upload = time.perf_counter() - t0
+
+    gather_buf = None
+    rows_t = None
+
+    def wrap_rows():
+        ptr, cap, _ = batch.device_results()
+
+        class _Rows:
+            __cuda_array_interface__ = {"shape": (cap * 16,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Rows(), device=f"cuda:{local_rank}")
+
+    def step():
+        nonlocal gather_buf, rows_t
+        batch.align(True)
+        if n_gpus > 1:
+            if rows_t is None:
+                rows_t = wrap_rows()
+                if rank == 0:
+                    gather_buf = [torch.empty_like(rows_t) for _ in range(n_gpus)]
+            dist.gather(rows_t, gather_buf if rank == 0 else None, dst=0)
+
+    def sync():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    kern = {"ms_backward": 0.0, "ms_forward": 0.0, "ms_trace": 0.0, "ms_total": 0.0}
+    for _ in range(args.steps):
+        step()
+        tm = batch.timing()
+        for key in kern:
+            kern[key] += tm[key]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if n_gpus > 1:
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([n_samples, len(reads)], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_samples, total_reads = float(tot[0].item()), float(tot[1].item())
+    else:
+        total_samples, total_reads = float(n_samples), float(len(reads))
+
+    # one un-timed pass for the host-visible rates and a sanity check of the result
+    t0 = time.perf_counter()
+    batch.align(True)
+    res = batch.fetch()
+    t_fetch_incl = time.perf_counter() - t0
+    ok = int((res.status == 0).sum())
+    tm = batch.timing()
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = elapsed * 1e3 / steps
+        value = total_samples * steps / elapsed / 1e6
+        cells = tm["cells"]
+        ms_fwd = kern["ms_forward"] / steps if args.steps else tm["ms_forward"]
+        ms_bwd = kern["ms_backward"] / steps if args.steps else tm["ms_backward"]
+        ms_all = kern["ms_total"] / steps if args.steps else tm["ms_total"]
+        achieved = cells * KFWD_BYTES_PER_CELL / (ms_fwd * 1e-3) / 1e9
+        traffic = load_traffic()
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_forward<POST> (forward + posterior + posterior-Viterbi, fused)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": (traffic or {}).get("k_forward_bytes_per_launch"),
+            "bytes_per_cell": KFWD_BYTES_PER_CELL, "cells_per_launch": cells,
+            "avg_launch_ms": round(ms_fwd, 3),
+            "k_backward": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "avg_launch_ms": round(ms_bwd, 3),
+                           "achieved": round(cells * KBWD_BYTES_PER_CELL / (ms_bwd * 1e-3) / 1e9, 1)},
+            # SURVEY.md §8(d) prices the whole align() of the three-pass formulation at 64.125 B/cell;
+            # this design moves 24.125 B/cell, so the survey-normalised figure exceeds real traffic.
+            "survey_8d_whole_path": {"bytes_per_cell": SURVEY_BYTES_PER_CELL, "ms_all_kernels": round(ms_all, 3),
+                                     "achieved": round(cells * SURVEY_BYTES_PER_CELL / (ms_all * 1e-3) / 1e9, 1),
+                                     "frac": round(cells * SURVEY_BYTES_PER_CELL / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        }
+        line = {
+            "metric": "signal samples resquiggled/sec", "value": round(value, 3), "unit": "Msamp/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['n_reads']} synthetic {pore} reads x ~{n_samples // len(reads)} samples per GPU, "
+                                   f"synthetic {k}-mer model, --mode basic, band 400, calc_probabilities=true",
+                       "reads_per_gpu": cfg["n_reads"], "samples_per_gpu": n_samples,
+                       "parallelism": f"reads sharded x{n_gpus}" + (", RCCL gather of segment rows to rank 0" if n_gpus > 1 else "")},
+            "reads_per_s": round(total_reads * steps / elapsed, 1),
+            "reads_ok": ok,
+            "kernel_ms": {k_: round(v / steps, 3) for k_, v in kern.items()},
+            "host_rates": {"fetch_inclusive_Msamp_s": round(n_samples / t_fetch_incl / 1e6, 3),
+                           "pcie_inclusive_Msamp_s": round(n_samples / (t_fetch_incl + t_upload) / 1e6, 3)},
+            "roofline": roofline,
+        }
+        if cpu_out and os.path.exists(cpu_out):
+            line["cpu_baseline"] = json.load(open(cpu_out))
+        elif n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    batch.close()
+    if n_gpus > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,11 +29,22 @@
 // n+1 for backward) come from DPP wave rotates -- no LDS, no barriers in the DP loops.
 #include "nt_kernels.hpp"
 
+// Placement: the SPI packs single-wave workgroups onto one SIMD for as long as its registers
+// allow (measured: a 184-VGPR build of K_bwd ran 1 024 reads as 2 waves on each of 512 SIMDs and
+// took 2x the time of 512 reads; tools/ubench + DESIGN.md). The DP waves are pure fp64 issue
+// streams with 7-way ILP that saturate a SIMD on their own, so they are compiled for exactly one
+// wave per SIMD: the dispatcher must then spread the reads over all 1 024 SIMDs, and the whole
+// 512-entry register file is available to keep the interleaved chains out of AGPR spills.
+#define DYN_ONE_WAVE_PER_SIMD __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+
 namespace dynk {
 
 using dynmath::NEG_INF;
 using dynmath::log_normal_pdf;
 using dynmath::log_plus;
+using dynmath::EmisV;
+using dynmath::log_normal_pdf_vec;
+using dynmath::log_plus_vec;
 
 namespace {
 
@@ -91,11 +102,11 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   Emis e;
   if (n >= 1 && n < N) {
     e = pr[n - 1];
-  } else {  // column without a k-mer (n <= 0 or beyond the sequence): benign finite constants
+  } else {  // column without a k-mer (n <= 0 or n >= N): log-density -inf (log_stdev = +inf)
     e.mean = 0.0;
     e.stdev = 1.0;
     e.inv_stdev = 1.0;
-    e.log_stdev = 0.0;
+    e.log_stdev = -NEG_INF;
   }
   return e;
 }
@@ -118,9 +129,11 @@ __global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __r
 //   bM(t,n)   = bE(t+1,n) + e(t+1,n)                          (n > 0)            :197-200
 //   bE(t,n)   = logPlus( (bM(t+1,n+1) + e(t+1,n+1)) + m1 ,    (n+1 < N)          :192-195
 //                        (bE(t+1,n)   + e(t+1,n))   + e2 )    (n > 0)            :201
+// Columns without a k-mer (n <= 0, n >= N) carry emission -inf, which realises the n > 0 and
+// n+1 < N guards arithmetically; the only mask left is the upper band edge.
 // ---------------------------------------------------------------------------------------------
 template <bool STORE>
-__global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ descs,
+__global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ descs,
                                                   const double* __restrict__ sig,
                                                   const Emis* __restrict__ par,
                                                   double* __restrict__ ws,
@@ -132,21 +145,21 @@ __global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ de
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ out = ws + rd.ws_off;
+  double* __restrict__ out = ws + rd.ws_off + lane;
 
   int lo = band_mid(T - 1, ratio) - bw;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
   int n[CPL];
   double bE[CPL], bM[CPL];
-  Emis p[CPL];
+  EmisV<CPL> p;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int slot = j * 64 + lane;
     n[j] = lo + pmod(slot - lo);
-    p[j] = load_emis(pr, n[j], N);
+    p.set(j, load_emis(pr, n[j], N));
     bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
     bM[j] = NEG_INF;
-    if (STORE) out[(size_t)(T - 1) * P + slot] = bE[j];
+    if (STORE) out[(size_t)(T - 1) * P + j * 64] = bE[j];
   }
 
   for (int thi = T - 2; thi >= 0; thi -= 64) {
@@ -158,13 +171,12 @@ __global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ de
     for (int i = 63; i >= ilo; --i) {
       const int t = base + i;
       const double x = readlane_f64(xs, i);
-      double Y[CPL], A[CPL], Yr[CPL];
+      double e[CPL], Y[CPL], A[CPL], Yr[CPL], x1[CPL], x2[CPL], ne[CPL];
+      log_normal_pdf_vec<CPL>(x, p, e);
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const double e = log_normal_pdf(x, p[j]);
-        Y[j] = bM[j] + e;
-        A[j] = bE[j] + e;
-      }
+      for (int j = 0; j < CPL; ++j) Y[j] = bM[j] + e[j];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) A[j] = bE[j] + e[j];
       from_right(Y, Yr, lane);
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved down by one column
@@ -173,22 +185,24 @@ __global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ de
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
-            p[j] = load_emis(pr, new_lo, N);
+            p.set(j, load_emis(pr, new_lo, N));
           }
         }
         lo = new_lo;
       }
-      const int hi_n = min(lo + W - 1, N - 1);
+      const int hi_n = lo + W - 1;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) A[j] = (n[j] <= hi_n) ? A[j] : NEG_INF;  // bM(t,n)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) x2[j] = A[j] + e2;
+      log_plus_vec<CPL>(x1, x2, ne);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        const int nn = n[j];
-        const bool valid = (nn >= 0) && (nn <= hi_n);
-        const double ext1 = (nn + 1 < N) ? Yr[j] + m1 : NEG_INF;
-        const double a = (nn > 0) ? A[j] : NEG_INF;
-        const double ne = log_plus(ext1, a + e2);
-        bE[j] = valid ? ne : NEG_INF;
-        bM[j] = valid ? a : NEG_INF;
-        if (STORE) out[(size_t)t * P + j * 64 + lane] = bE[j];
+        bE[j] = ne[j];
+        bM[j] = A[j];
+        if (STORE) out[(size_t)t * P + j * 64] = ne[j];
       }
     }
   }
@@ -205,9 +219,11 @@ __global__ __launch_bounds__(64) void k_backward(const ReadDesc* __restrict__ de
 //   LPM      = (fM + bM) - Zb,  LPE = (fE + bE) - Zb                              :222
 //   vM(t,n)  = vE(t-1,n-1) + LPM ;  vE(t,n) = max(vM(t-1,n), vE(t-1,n)) + LPE     :360-361
 //   bit(t,n) = ( vE(t,n) == vM(t-1,n) + LPE )                                     :448
+// Masks: emission -inf for k-mer-less columns covers n < 1 and n >= N; a column's state is reset
+// to -inf when it leaves the band; the upper band edge masks the value taken from column n-1.
 // ---------------------------------------------------------------------------------------------
 template <bool POST>
-__global__ __launch_bounds__(64) void k_forward(const ReadDesc* __restrict__ descs,
+__global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ descs,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par,
                                                  double* __restrict__ ws,
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64) void k_forward(const ReadDesc* __restrict__ des
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ lat = ws + rd.ws_off;
+  double* __restrict__ lat = ws + rd.ws_off + lane;
   float2* __restrict__ lat_lp = reinterpret_cast<float2*>(lat);
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
@@ -229,23 +245,23 @@ __global__ __launch_bounds__(64) void k_forward(const ReadDesc* __restrict__ des
   int n[CPL];
   double fM[CPL], fE[CPL], e[CPL];
   double vM[CPL], vE[CPL], bcur[CPL], bnext[CPL];
-  Emis p[CPL];
+  EmisV<CPL> p;
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int slot = j * 64 + lane;
     n[j] = lo + pmod(slot - lo);
-    p[j] = load_emis(pr, n[j], N);
+    p.set(j, load_emis(pr, n[j], N));
     fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     fM[j] = NEG_INF;
-    e[j] = log_normal_pdf(x0, p[j]);      // e(1, n)
     if (POST) {
       vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
       vM[j] = NEG_INF;
-      bcur[j] = lat[(size_t)1 * P + slot];
-      bnext[j] = (T > 2) ? lat[(size_t)2 * P + slot] : NEG_INF;
+      bcur[j] = lat[(size_t)1 * P + j * 64];
+      bnext[j] = (T > 2) ? lat[(size_t)2 * P + j * 64] : NEG_INF;
     }
   }
+  log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
 
   for (int tb = 1; tb < T; tb += 64) {
     const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
@@ -261,56 +277,73 @@ __global__ __launch_bounds__(64) void k_forward(const ReadDesc* __restrict__ des
         from_left(vE, vEl, lane);
         const bool have = (t + 2 < T);
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
-          bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64 + lane] : NEG_INF;
+        for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
       }
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved up by one column
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          if (n[j] == lo) {
+          if (n[j] == lo) {  // column lo leaves the band; its slot becomes column lo+P
             n[j] = lo + P;
-            p[j] = load_emis(pr, lo + P, N);
+            p.set(j, load_emis(pr, lo + P, N));
+            fM[j] = NEG_INF;
+            fE[j] = NEG_INF;
+            e[j] = NEG_INF;
+            if (POST) {
+              vM[j] = NEG_INF;
+              vE[j] = NEG_INF;
+            }
           }
         }
         lo = new_lo;
       }
-      const int lo_n = max(lo, 1);
-      const int hi_n = min(lo + W - 1, N - 1);
-      uint64_t mybits = 0;
+      const int hi_n = lo + W - 1;
+      double a1[CPL], a2[CPL], fMn[CPL], fEn[CPL], en[CPL];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int nn = n[j];
-        const bool valid = (nn >= lo_n) && (nn <= hi_n);
-        const double ee = e[j];
-        double fMn = (fEl[j] + ee) + m1;
-        double fEn = log_plus(fM[j] + ee, (fE[j] + ee) + e2);
-        fMn = valid ? fMn : NEG_INF;
-        fEn = valid ? fEn : NEG_INF;
-        const double en = log_normal_pdf(xn, p[j]);  // e(t+1, n)
-        if (POST) {
-          const double bMt = bnext[j] + en;          // bM(t,n) = bE(t+1,n) + e(t+1,n)
-          const double LPM = (fMn + bMt) - Z;
-          const double LPE = (fEn + bcur[j]) - Z;
-          double vMn = vEl[j] + LPM;
-          const double vmx = fmax(vM[j], vE[j]);
-          double vEn = vmx + LPE;
-          const bool bit = (vEn == vM[j] + LPE);
-          vMn = valid ? vMn : NEG_INF;
-          vEn = valid ? vEn : NEG_INF;
-          const uint64_t b = __ballot(bit);
-          if (lane == j) mybits = b;
-          lat_lp[(size_t)t * P + j * 64 + lane] = make_float2((float)LPM, (float)LPE);
-          vM[j] = vMn;
-          vE[j] = vEn;
+      for (int j = 0; j < CPL; ++j) fEl[j] = (n[j] <= hi_n) ? fEl[j] : NEG_INF;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) a1[j] = fM[j] + e[j];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) a2[j] = (fE[j] + e[j]) + e2;
+      log_plus_vec<CPL>(a1, a2, fEn);
+      log_normal_pdf_vec<CPL>(xn, p, en);  // e(t+1, n)
+      if (POST) {
+        double LPM[CPL], LPE[CPL], vMn[CPL], vEn[CPL], alt[CPL];
+        uint64_t bj[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) LPM[j] = (fMn[j] + (bnext[j] + en[j])) - Z;  // bM(t,n) = bE(t+1,n) + e(t+1,n)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) LPE[j] = (fEn[j] + bcur[j]) - Z;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) vMn[j] = vEl[j] + LPM[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) vEn[j] = fmax(vM[j], vE[j]) + LPE[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
+        uint64_t mybits = bj[0];
+#pragma unroll
+        for (int j = 1; j < CPL; ++j) mybits = (lane == j) ? bj[j] : mybits;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) lat_lp[(size_t)t * P + j * 64] = make_float2((float)LPM[j], (float)LPE[j]);
+        if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          vM[j] = vMn[j];
+          vE[j] = vEn[j];
           bcur[j] = bnext[j];
           bnext[j] = bnn[j];
         }
-        fM[j] = fMn;
-        fE[j] = fEn;
-        e[j] = en;
       }
-      if (POST && lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        fM[j] = fMn[j];
+        fE[j] = fEn[j];
+        e[j] = en[j];
+      }
     }
   }
   // Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285)
@@ -348,7 +381,7 @@ __global__ void k_zcheck(const ReadDesc* __restrict__ descs, int n_reads,
 // run of rows that share a column, its M cell is the lowest row (segrow).
 // 64 rows of bits are staged in LDS per step so the serial walk pays LDS, not HBM, latency.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trace(const ReadDesc* __restrict__ descs,
+__global__ DYN_ONE_WAVE_PER_SIMD void k_trace(const ReadDesc* __restrict__ descs,
                                                const double* __restrict__ ws,
                                                const uint64_t* __restrict__ bits,
                                                ReadState* __restrict__ st, TraceBuffers tb,
@@ -478,7 +511,7 @@ __global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __r
 // so both are plain sums of per-cell posteriors (linear domain, relative to Zb).
 // Column sums stay in registers while the column is in the band and are flushed once per column.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_forward_train(const ReadDesc* __restrict__ descs,
+__global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict__ descs,
                                                        const double* __restrict__ sig,
                                                        const Emis* __restrict__ par,
                                                        const double* __restrict__ ws,

@@ -1,0 +1,121 @@
+"""CPU: the C-ABI library loads, exports every declared symbol, and its host-side contract
+(model loader, validation, k-mer coding, error texts) matches the oracle and the goldens.
+No compute call is possible without a GPU -- and that must fail loudly, never fall back."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from dynamont_amd import Aligner, PoreType, pore_type, synth
+from dynamont_amd import _native as N
+from oracle.pyoracle import Oracle
+
+pytestmark = pytest.mark.usefixtures("native_lib", "oracle_built")
+
+
+def test_every_declared_symbol_is_exported(native_lib):
+    hdr = open(os.path.join(ROOT, "include", "dynamont_mi.h")).read()
+    declared = set(re.findall(r"\b(dyn_[a-z_]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    for name in declared:
+        assert getattr(native_lib, name) is not None
+
+
+def test_header_cites_the_reference_interfaces():
+    hdr = open(os.path.join(ROOT, "include", "dynamont_mi.h")).read()
+    for needle in ("aligner_bindings.cpp", "NT_aligner_api.cpp", "aligner.cpp", "aligner.hpp"):
+        assert needle in hdr
+
+
+def test_pore_type_surface():
+    assert [p.name for p in PoreType] == ["RNA002", "RNA004", "DNA_R9", "DNA_R10_260", "DNA_R10_400"]
+    for s, v in (("rna002", 0), ("rna004", 1), ("dna_r9", 2), ("dna_r10_260bps", 3), ("dna_r10_400bps", 4)):
+        assert pore_type(s) == PoreType(v)
+    with pytest.raises(ValueError, match="Unknown pore type: foo"):
+        pore_type("foo")
+
+
+def test_constructor_errors_match_reference(models):
+    d = json.load(open(os.path.join(GOLDEN, "g5_failures.json")))
+    for c in d["ctor"]:
+        path = {"syn5": models["syn5"], "syn9": models["syn9"]}.get(c["model"], c["model"])
+        with pytest.raises(RuntimeError) as e:
+            Aligner(path, PoreType(c["pore"]), device="host")
+        assert str(e.value) == c["message"]
+    with pytest.raises(ValueError, match="Unknown aligner mode: fancy"):
+        Aligner(models["syn5"], "rna002", mode="fancy", device="host")
+    with pytest.raises(ValueError, match="Unknown pore type: nope"):
+        Aligner(models["syn5"], "nope", device="host")
+    with pytest.raises(ValueError, match="outside the scope"):
+        Aligner(models["syn5"], "rna002", mode="resquiggle", device="host")
+    with pytest.raises(ValueError, match="exceeds this build's limit"):
+        Aligner(models["syn5"], "rna002", band=2000, device="host")
+
+
+@pytest.mark.parametrize("pore,key", [("rna002", "syn5"), ("rna004", "syn9"), ("dna_r9", "syn5"),
+                                      ("dna_r10_260bps", "syn9"), ("dna_r10_400bps", "syn9")])
+def test_model_loader_matches_oracle(models, pore, key):
+    al = Aligner(models[key], pore, device="host")
+    orc = Oracle(models[key], synth.PORES[pore][0])
+    m, s = al.model_table()
+    om, os_ = orc.table()
+    assert np.array_equal(m, om) and np.array_equal(s, os_)
+    assert al.kmer_size == orc.k and al.num_kmers == orc.num_kmers
+    assert al.rna == synth.PORES[pore][1]
+    # and the generator's code-order view agrees with both (RNA k-mers are reversed on load)
+    _, fm, fs = synth.read_model_file(models[key])
+    gm, gs = synth.code_order_table(fm, fs, al.kmer_size, al.rna)
+    assert np.array_equal(gm, m) and np.array_equal(gs, s)
+    # default log transitions (NT_aligner_api.cpp:36-86)
+    want = {"rna002": (0.019889650396799997, 0.9801103496029998), "dna_r9": (1.0, 1.0)}.get(
+        pore, (0.031111753637096777, 0.9688882463622581))
+    assert al.info.log_m1 == np.log(want[0]) and al.info.log_e2 == np.log(want[1]) and al.info.log_e1 == 0.0
+    assert al.info.half_band == 200
+
+
+def test_validation_and_messages_match_goldens(models):
+    d = json.load(open(os.path.join(GOLDEN, "g5_failures.json")))
+    al = Aligner(models["syn5"], "rna002", device="host")
+    cases = d["align"]
+    status, msgs, kmers = al.validate([len(c["signal"]) for c in cases], [c["sequence"] for c in cases])
+    orc = Oracle(models["syn5"], 0)
+    for c, st, msg, km in zip(cases, status, msgs, kmers):
+        if c["ok"]:
+            assert st == 0 and msg is None
+            assert np.array_equal(km, orc.kmers(c["sequence"]))
+        else:
+            assert st != 0 and msg == c["message"], (c["name"], msg)
+
+
+def test_kmer_coding_random(models):
+    rng = np.random.default_rng(5)
+    for pore, key in (("rna004", "syn9"), ("dna_r9", "syn5")):
+        al = Aligner(models[key], pore, device="host")
+        orc = Oracle(models[key], synth.PORES[pore][0])
+        seqs = ["".join(rng.choice(list("ACGTacgtUu"), size=int(n))) for n in rng.integers(al.kmer_size, 300, 20)]
+        st, _, km = al.validate([10 ** 6] * len(seqs), seqs)
+        assert (st == 0).all()
+        for s, k in zip(seqs, km):
+            assert np.array_equal(k, orc.kmers(s))
+
+
+def test_compute_without_gpu_fails_loudly(models):
+    al = Aligner(models["syn5"], "rna002", device="host")
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        al.align(np.zeros(100), "ACGTACGTAC", True)
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        al.train(np.zeros(100), "ACGTACGTAC")
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU compute path"):
+            Aligner(models["syn5"], "rna002")
+
+
+def test_signal_must_be_one_dimensional(models):
+    al = Aligner(models["syn5"], "rna002", device="host")
+    with pytest.raises(ValueError, match="Signal must be a one-dimensional array"):
+        al.align(np.zeros((4, 4)), "ACGTACGTAC")

@@ -1,0 +1,87 @@
+"""CPU: accuracy of the per-cell fp64 arithmetic (dynamont_amd/csrc/dp_math.hpp), compiled for
+the host with g++. softplus vs 40-digit mpmath; log_normal_pdf bit-identical to the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import pyoracle
+
+SRC = r'''
+#include "%s/dynamont_amd/csrc/dp_math.hpp"
+extern "C" {
+void eval_softplus(const double* d, double* out, long n) { for (long i = 0; i < n; ++i) out[i] = dynmath::softplus_nonpos(d[i]); }
+void eval_logplus(const double* x, const double* y, double* out, long n) { for (long i = 0; i < n; ++i) out[i] = dynmath::log_plus(x[i], y[i]); }
+void eval_pdf(const double* x, const double* mean, const double* sd, double* out, long n) {
+  for (long i = 0; i < n; ++i) { dynmath::Emis p{mean[i], sd[i], 1.0 / sd[i], std::log(sd[i])}; out[i] = dynmath::log_normal_pdf(x[i], p); } }
+}
+''' % ROOT
+
+dp = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def mathlib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dpmath")
+    src = d / "t.cpp"
+    src.write_text(SRC)
+    so = d / "libt.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    return C.CDLL(str(so))
+
+
+def test_softplus_accuracy(mathlib):
+    rng = np.random.default_rng(0)
+    d = np.concatenate([-np.abs(rng.standard_normal(1500)) * 3, -rng.uniform(0, 45, 1500),
+                        -10.0 ** rng.uniform(-12, 2.9, 1500), [0.0, -0.8813735870195429, -1e-300, -745.0, -1000.0]])
+    out = np.empty_like(d)
+    mathlib.eval_softplus(d.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(d)))
+    mp.mp.dps = 40
+    worst = max(abs(mp.mpf(float(y)) - mp.log1p(mp.exp(mp.mpf(float(x))))) for x, y in zip(d, out))
+    assert worst < 2.0e-16, worst
+
+
+def test_logplus_special_values(mathlib):
+    inf = np.inf
+    x = np.array([-inf, 3.0, -inf, -5.0, 1e4, -2000.0])
+    y = np.array([-inf, -inf, -7.5, -5.0, 1e4 - 800.0, 2000.0])
+    out = np.empty_like(x)
+    mathlib.eval_logplus(x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(x)))
+    assert out[0] == -inf and out[1] == 3.0 and out[2] == -7.5      # aligner.cpp:278-281
+    assert abs(out[3] - (-5.0 + np.log(2.0))) < 1e-15
+    assert out[4] == 1e4 and out[5] == 2000.0
+
+
+def test_logplus_matches_oracle_closely(mathlib, oracle_built):
+    L = C.CDLL(pyoracle.ORACLE_SO)
+    L.nto_log_plus.restype = C.c_double
+    L.nto_log_plus.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-5000, 100, 20000)
+    y = x + rng.uniform(-60, 60, 20000)
+    out = np.empty_like(x)
+    mathlib.eval_logplus(x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(x)))
+    ref = np.array([L.nto_log_plus(a, b) for a, b in zip(x, y)])
+    assert np.abs(out - ref).max() <= 2 * np.spacing(np.abs(ref)).max()
+    assert np.mean(out == ref) > 0.95
+
+
+def test_log_normal_pdf_bit_identical(mathlib, oracle_built):
+    L = C.CDLL(pyoracle.ORACLE_SO)
+    L.nto_log_normal_pdf.restype = C.c_double
+    L.nto_log_normal_pdf.argtypes = [C.c_double] * 3
+    rng = np.random.default_rng(2)
+    n = 50000
+    x = rng.standard_normal(n) * 2
+    mean = rng.standard_normal(n)
+    sd = rng.uniform(0.05, 0.5, n)
+    sd[: n // 2] = 0.15
+    sd[n // 2: n // 2 + 10000] = 0.25
+    out = np.empty(n)
+    mathlib.eval_pdf(x.ctypes.data_as(dp), mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(n))
+    ref = np.array([L.nto_log_normal_pdf(a, b, c) for a, b, c in zip(x, mean, sd)])
+    assert np.array_equal(out, ref)

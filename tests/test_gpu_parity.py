@@ -1,0 +1,229 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against
+  * the golden vectors generated from the compiled reference (G1-G5, G7),
+  * the CPU oracle on the same seeded inputs,
+  * size-independent properties at BASELINE.json's full sizes.
+Bar (BASELINE.json north_star): start/end/basepos/state bit-exact, posterior within 1e-4
+(observed ~2e-8: path posteriors are stored as fp32 log-probabilities), Z within 1e-9 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_matches_golden, golden, model_for
+from dynamont_amd import Aligner, synth
+from oracle.pyoracle import Oracle
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib", "oracle_built")]
+
+PROB_TOL = 1e-4   # north_star tolerance
+PROB_TIGHT = 1e-6  # what the fp32 LP storage actually delivers, guarded so regressions show
+
+
+@pytest.fixture(scope="module")
+def al5(models):
+    return Aligner(models["syn5"], "rna002", device=0)
+
+
+@pytest.fixture(scope="module")
+def al9(models):
+    return Aligner(models["syn9"], "rna004", device=0)
+
+
+def test_native_library_is_what_runs(native_lib):
+    # the extension must be the in-tree .so, loaded in this process
+    maps = open("/proc/self/maps").read()
+    assert "dynamont_amd/libdynamont_mi.so" in maps
+
+
+def test_g1_cfg1(models, al5, tmp_path):
+    g = golden("g1_cfg1.npz")
+    res = al5.align(g["syn_signal"], str(g["syn_sequence"]), True)
+    assert_matches_golden(res, g, "syn_", PROB_TIGHT)
+    assert res["signal_positions"].dtype == np.uint64 and res["sequence_positions"].dtype == np.uint64
+    assert res["polishes"] == [""] * len(res["states"])
+    real = tmp_path / "rna002_5mer.model"
+    with open(real, "w") as w:
+        w.write("kmer\tlevel_mean\tlevel_stdv\n")
+        for n, m, s in zip(synth.kmer_strings(5), g["real_model_mean"], g["real_model_stdev"]):
+            w.write(f"{n}\t{float(m)!r}\t{float(s)!r}\n")
+    res = Aligner(str(real), "rna002", device=0).align(g["real_signal"], str(g["real_sequence"]), True)
+    assert_matches_golden(res, g, "real_", PROB_TIGHT)
+    # calc_probabilities=False: Z only, no segments (NT_aligner_api.cpp:293-295)
+    z = al5.align(g["syn_signal"], str(g["syn_sequence"]))
+    assert len(z["probabilities"]) == 0 and abs(z["Z"] - float(g["syn_Z"])) <= 1e-9 * abs(float(g["syn_Z"]))
+
+
+def test_g2_rna004_batch(models, al9):
+    g = golden("g2_rna004.npz")
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(int(g["seed"]), int(g["n_reads"]), "rna004", mean, sd, (200, 2000))
+    res = al9.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    assert (res.status == 0).all()
+    for i in range(len(reads)):
+        assert_matches_golden(res.read(i), g, f"r{i}_", PROB_TIGHT)
+
+
+def test_g3_short_reads_bandwidth_clamp_and_bands(models):
+    g = golden("g3_short.npz")
+    groups = {}
+    for i in range(int(g["n_cases"])):
+        p = f"c{i}_"
+        band = int(g[p + "band"]) if p + "band" in g else 400
+        groups.setdefault((str(g[p + "pore"]), band), []).append(p)
+    for (pore, band), ps in groups.items():
+        al = Aligner(model_for(models, pore), pore, band=band, device=0)
+        res = al.align_batch([g[p + "signal"] for p in ps], [str(g[p + "sequence"]) for p in ps], True)
+        for j, p in enumerate(ps):
+            assert_matches_golden(res.read(j), g, p, PROB_TIGHT)
+
+
+def test_g4_dna_long_reads(models):
+    g = golden("g4_dna_long.npz")
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(int(g["seed"]), int(g["n_reads"]), "dna_r10_400bps", mean, sd, (7000, 8000))
+    al = Aligner(models["syn9"], "dna_r10_400bps", device=0)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    for i in range(len(reads)):
+        assert_matches_golden(res.read(i), g, f"r{i}_", PROB_TIGHT)
+
+
+def test_g5_failures_are_isolated_per_read(al5):
+    d = json.load(open(os.path.join(GOLDEN, "g5_failures.json")))
+    cases = [c for c in d["align"] if c["name"] != "calc_false"]
+    res = al5.align_batch([np.array(c["signal"]) for c in cases], [c["sequence"] for c in cases], True)
+    for i, c in enumerate(cases):
+        if c["ok"]:
+            r = res.read(i)
+            assert abs(r["Z"] - c["Z"]) <= 1e-9 * max(1.0, abs(c["Z"])) and len(r["states"]) == c["nseg"]
+        else:
+            assert res.error(i) == c["message"]
+            with pytest.raises(RuntimeError) as e:
+                res.read(i)
+            assert str(e.value) == c["message"]
+    # single-read surface raises like the reference's Aligner.align
+    bad = next(c for c in cases if c["name"] == "base_N")
+    with pytest.raises(RuntimeError, match="Invalid nucleotide: N"):
+        al5.align(np.array(bad["signal"]), bad["sequence"], True)
+
+
+@pytest.mark.parametrize("pore,nb", [("rna002", (30, 300)), ("rna004", (100, 700)), ("dna_r9", (20, 250)),
+                                     ("dna_r10_260bps", (300, 900)), ("dna_r10_400bps", (450, 600))])
+def test_random_reads_against_oracle(models, pore, nb):
+    path = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(path)
+    reads = synth.make_reads(4242, 12, pore, mean, sd, nb)
+    # a noise read and a read with an outlier burst as well
+    rng = np.random.default_rng(9)
+    reads[1].signal[:] = rng.standard_normal(len(reads[1].signal))
+    reads[2].signal[50:60] += 25.0
+    al = Aligner(path, pore, device=0)
+    orc = Oracle(path, synth.PORES[pore][0])
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    for i, r in enumerate(reads):
+        try:
+            want = orc.align(r.signal, r.sequence, True)
+        except RuntimeError as e:
+            assert res.error(i) == str(e)
+            continue
+        got = res.read(i)
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
+        assert np.array_equal(got["signal_positions"], want["signal_positions"])
+        assert got["states"] == want["states"]
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+
+
+def test_order_and_chunking_invariance(models, al9):
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(77, 24, "rna004", mean, sd, (150, 900))
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    base = al9.align_batch(sigs, seqs, True)
+    perm = np.random.default_rng(3).permutation(len(reads))
+    shuf = al9.align_batch([sigs[i] for i in perm], [seqs[i] for i in perm], True)
+    small = Aligner(models["syn9"], "rna004", device=0)
+    small.set_mem_budget(80 << 20)  # forces several launches (each read needs 20-30 MB)
+    with small.batch(sigs, seqs) as b:
+        b.align(True)
+        chunked = b.fetch()
+        assert b.timing()["launches_forward"] > 1
+    for j, i in enumerate(perm):
+        a, s, c = base.read(int(i)), shuf.read(j), chunked.read(int(i))
+        for other in (s, c):
+            assert np.array_equal(a["signal_positions"], other["signal_positions"])
+            assert np.array_equal(a["probabilities"], other["probabilities"])  # bitwise: deterministic kernels
+            assert a["Z"] == other["Z"]
+
+
+def test_cfg2_full_size_properties_and_spot_parity(models, al9):
+    """BASELINE configs[1]: 1 024 RNA004 reads x ~20 k samples. Size-independent properties on
+    all reads, full parity against the oracle on three of them."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    cfg = synth.CONFIGS["cfg2"]
+    reads = synth.make_reads(cfg["seed"], cfg["n_reads"], cfg["pore"], mean, sd, cfg["n_bases"])
+    sig, so, sq, qo = synth.pack_reads(reads)
+    with al9.batch_packed(sig, so, sq, qo) as b:
+        b.align(True)
+        res = b.fetch()
+        tm = b.timing()
+    assert (res.status == 0).all()
+    assert tm["samples"] == int(so[-1]) and tm["reads_ok"] == len(reads)
+    k = al9.kmer_size
+    for i, r in enumerate(reads):
+        a, n = int(res.seg_offsets[i]), int(res.n_segments[i])
+        assert n == len(r.sequence) - k + 1
+        sp = res.signal_positions[a:a + n]
+        assert sp[0] == 0 and np.all(np.diff(sp.astype(np.int64)) >= 2) and sp[-1] <= len(r.signal) - 2
+        assert np.array_equal(res.sequence_positions[a:a + n], np.arange(n, dtype=np.uint64) + k // 2)
+        p = res.probabilities[a:a + n]
+        assert np.all((p >= 0) & (p <= 1.0 + 1e-6))
+    assert np.all(np.isfinite(res.Z))
+    orc = Oracle(models["syn9"], 1)
+    for i in (0, 511, 1023):
+        want = orc.align(reads[i].signal, reads[i].sequence, True)
+        got = res.read(i)
+        assert np.array_equal(got["signal_positions"], want["signal_positions"])
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+
+
+def test_g7_train_against_reference_golden(models):
+    g = golden("g7_train.npz")
+    for i in range(int(g["n_cases"])):
+        p = f"t{i}_"
+        pore = str(g[p + "pore"])
+        al = Aligner(model_for(models, pore), pore, device=0)
+        res = al.train_batch([g[p + "signal"]], [str(g[p + "sequence"])])
+        assert res.status[0] == 0
+        zg = float(g[p + "Z"])
+        assert abs(res.Z[0] - zg) <= 1e-9 * max(1.0, abs(zg))
+        assert np.abs(res.transitions[:3] - g[p + "trans"]).max() <= 1e-9
+        code, mean, sd = res.sparse(0)
+        assert np.array_equal(code.astype(np.int64), g[p + "codes"])
+        assert np.abs(mean - g[p + "mean"]).max() <= 1e-9
+        assert np.abs(sd - g[p + "stdev"]).max() <= 1e-7   # sqrt(var) amplifies cancellation in s2/w - mean^2
+        # dense dict form of the reference binding
+        dense = al.train(g[p + "signal"], str(g[p + "sequence"]))
+        assert len(dense["emission_model"]) == al.num_kmers and dense["transition_params"]["e1"] == 1.0
+
+
+def test_train_batch_against_oracle_and_pooled_stats(models, al9):
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(5, 6, "rna004", mean, sd, (120, 500))
+    res = al9.train_batch([r.signal for r in reads], [r.sequence for r in reads], pooled=True)
+    orc = Oracle(models["syn9"], 1)
+    K = al9.num_kmers
+    pooled = np.zeros(3 * K)
+    for i, r in enumerate(reads):
+        want = orc.train(r.signal, r.sequence)
+        assert abs(res.Z[i] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+        assert abs(res.transitions[3 * i] - want["m1"]) <= 1e-9 and abs(res.transitions[3 * i + 2] - want["e2"]) <= 1e-9
+        code, m, s = res.sparse(i)
+        touched = np.nonzero(want["weight"] > 0)[0]
+        assert np.array_equal(code, touched)
+        assert np.abs(m - want["mean"][touched]).max() <= 1e-9
+        assert np.abs(s - want["stdev"][touched]).max() <= 1e-7
+        pooled[:K] += want["weight"]
+        pooled[K:2 * K] += want["sum"]
+        pooled[2 * K:] += want["sumsq"]
+    assert np.allclose(res.pooled, pooled, rtol=1e-9, atol=1e-9)
