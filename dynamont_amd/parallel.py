@@ -1,0 +1,85 @@
+"""Multi-GPU plumbing: reads are independent, so a job shards them across one
+process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
+There is no data-path collective. The only exchanges are
+
+  * gather_rows      per-read segment rows -> rank 0 (BASELINE.json config 4),
+  * allreduce_sum    pooled sufficient statistics (w, s1, s2)[numKmers] (config 5).
+
+This module never touches the DP itself; tensors are plain byte/float64 buffers.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced [lo, hi) of ``n_items`` for ``rank`` (first n%world ranks get one more)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_cost(costs, world: int) -> list[list[int]]:
+    """Greedy longest-first assignment of items to ranks by cost (signal length): keeps the
+    per-GPU lattice work even when read lengths differ (config 3)."""
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    load = np.zeros(world)
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        out[r].append(int(i))
+        load[r] += float(costs[i])
+    return out
+
+
+class Comm:
+    """Thin wrapper so callers do not depend on torch when running single-process."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.active = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.active else 0
+        self.world = dist.get_world_size() if self.active else 1
+        self.device = device if device is not None else "cpu"
+
+    def allreduce_sum(self, x: np.ndarray) -> np.ndarray:
+        """Sum of a float64 vector over ranks (sufficient statistics are linear-domain sums, so a
+        plain sum all-reduce is exact up to fp64 association)."""
+        if not self.active:
+            return x
+        t = self.torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allreduce_sum_tensor(self, t):
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def gather_rows(self, rows_u8, dst: int = 0):
+        """Variable-length gather of a uint8 tensor to ``dst``: sizes are exchanged first
+        (all_gather), payloads are padded to the maximum for the gather. Returns the list of
+        per-rank tensors on ``dst`` and None elsewhere."""
+        torch, dist = self.torch, self.dist
+        if not self.active:
+            return [rows_u8]
+        n = torch.tensor([rows_u8.numel()], dtype=torch.int64, device=rows_u8.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(sizes)
+        pad = rows_u8 if rows_u8.numel() == cap else torch.cat(
+            [rows_u8, torch.zeros(cap - rows_u8.numel(), dtype=torch.uint8, device=rows_u8.device)])
+        bufs = [torch.empty(cap, dtype=torch.uint8, device=rows_u8.device) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(pad, bufs, dst=dst)
+        if self.rank != dst:
+            return None
+        return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def rows_from_bytes(buf: np.ndarray) -> np.ndarray:
+    """View gathered bytes as the C ABI's dyn_segment_row records."""
+    dt = np.dtype([("signal_pos", "<u4"), ("sequence_pos", "<u4"), ("probability", "<f8")])
+    return np.frombuffer(np.ascontiguousarray(buf).tobytes(), dtype=dt)

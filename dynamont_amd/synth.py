@@ -159,3 +159,53 @@ def pack_reads(reads: list[SynthRead]):
     signals = np.concatenate([r.signal for r in reads]) if reads else np.zeros(0)
     seqs = "".join(r.sequence for r in reads).encode()
     return np.ascontiguousarray(signals, dtype=np.float64), sig_off, seqs, seq_off
+
+
+def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, seed: int = 0,
+                  drop_polya_every: int = 3, lead: int = 37, sm: float = 90.0, sd: float = 15.0):
+    """Write reads as the vendor-free containers of ``dynamont_amd.pod5_io``: ``<name>.dynraw.npz``
+    (int16 ADC + calibration) and ``<name>.dynbam.tsv`` (the BAM fields segment.py:222-256 reads).
+
+    Reads are given in aligner orientation. For RNA pores the basecall is stored 5'->3' (reversed)
+    and every ``drop_polya_every``-th read loses its polyA pad, which the harness must re-add
+    (segment.py:155-158). ``lead`` untrimmed samples precede each signal (tag ts).
+    Returns (raw_path, basecalls_path, expected) where expected[i] = (normalised float64 signal the
+    harness must reconstruct, aligner-orientation sequence)."""
+    import os
+    _, rna, _k = PORES[pore]
+    rng = np.random.default_rng(seed)
+    scale, offset = 0.1755, -240.0
+    adcs, offs, ids, rows, expected = [], [0], [], [], []
+    for i, r in enumerate(reads):
+        pa = r.signal * sd + sm
+        adc = np.rint(pa / scale - offset).astype(np.int16)
+        pre = rng.integers(300, 900, size=lead).astype(np.int16)
+        full = np.concatenate([pre, adc])
+        rid = f"read-{seed}-{i:05d}"
+        ids.append(rid)
+        adcs.append(full)
+        offs.append(offs[-1] + len(full))
+        seq = r.sequence
+        if rna:
+            bam_seq = seq[::-1]
+            if drop_polya_every and i % drop_polya_every == 1 and bam_seq.endswith("A" * 9):
+                bam_seq = bam_seq[:-9]
+        else:
+            bam_seq = seq
+        qs = float(np.round(rng.uniform(8.0, 20.0), 3))
+        rows.append(f"{rid}\t{bam_seq}\t{qs}\t*\t{len(full)}\t{lead}\t*\t{name}.dynraw.npz\t{sm}\t{sd}\n")
+        # what the harness reconstructs: float64((adc+offset)*scale in float32), -sm, /sd
+        pa32 = (adc.astype(np.float32) + np.float32(offset)) * np.float32(scale)
+        x = pa32.astype(np.float64)
+        x -= sm
+        x /= sd
+        expected.append((x, seq if not rna else ("A" * 9 + bam_seq[::-1] if not bam_seq[::-1].startswith("A" * 9) else bam_seq[::-1])))
+    os.makedirs(outdir, exist_ok=True)
+    raw = os.path.join(outdir, f"{name}.dynraw.npz")
+    np.savez(raw, read_ids=np.array(ids), offsets=np.array(offs, dtype=np.int64), adc=np.concatenate(adcs),
+             cal_scale=np.full(len(reads), scale), cal_offset=np.full(len(reads), offset))
+    bam = os.path.join(outdir, f"{name}.dynbam.tsv")
+    with open(bam, "w") as w:
+        w.write("query_name\tsequence\tqs\tpi\tns\tts\tsp\tfn\tsm\tsd\n")
+        w.writelines(rows)
+    return raw, bam, expected

@@ -1,0 +1,136 @@
+"""zstd level-3 stream writer for the CSV output (reference: ``zstd.ZstdCompressor(level=3)
+.stream_writer``, segment.py:74-79). Uses the ``zstandard`` package when it is installed and the
+system ``libzstd.so.1`` through ctypes otherwise (the package is absent from the ROCm image)."""
+from __future__ import annotations
+
+import ctypes as C
+import ctypes.util
+
+try:  # pragma: no cover - not installed in the build image
+    import zstandard as _zstandard
+except Exception:  # noqa: BLE001
+    _zstandard = None
+
+
+class _InBuf(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+class _OutBuf(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+_ZSTD_c_compressionLevel = 100
+_ZSTD_e_continue, _ZSTD_e_flush, _ZSTD_e_end = 0, 1, 2
+_lib = None
+
+
+def _libzstd():
+    global _lib
+    if _lib is None:
+        name = ctypes.util.find_library("zstd") or "libzstd.so.1"
+        L = C.CDLL(name)
+        L.ZSTD_createCCtx.restype = C.c_void_p
+        L.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+        L.ZSTD_CCtx_setParameter.restype = C.c_size_t
+        L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ZSTD_compressStream2.restype = C.c_size_t
+        L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(_OutBuf), C.POINTER(_InBuf), C.c_int]
+        L.ZSTD_isError.restype = C.c_uint
+        L.ZSTD_isError.argtypes = [C.c_size_t]
+        L.ZSTD_getErrorName.restype = C.c_char_p
+        L.ZSTD_getErrorName.argtypes = [C.c_size_t]
+        L.ZSTD_CStreamOutSize.restype = C.c_size_t
+        L.ZSTD_createDCtx.restype = C.c_void_p
+        L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+        L.ZSTD_decompressStream.restype = C.c_size_t
+        L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(_OutBuf), C.POINTER(_InBuf)]
+        L.ZSTD_DStreamOutSize.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+class ZstdWriter:
+    """File-like ``write(bytes)`` / ``close()`` producing one zstd frame at the given level."""
+
+    def __init__(self, raw, level: int = 3):
+        self._raw = raw
+        self._backend = None
+        if _zstandard is not None:
+            self._backend = _zstandard.ZstdCompressor(level=level).stream_writer(raw, closefd=False)
+            return
+        L = self._L = _libzstd()
+        self._ctx = L.ZSTD_createCCtx()
+        rc = L.ZSTD_CCtx_setParameter(self._ctx, _ZSTD_c_compressionLevel, level)
+        self._check(rc)
+        self._cap = int(L.ZSTD_CStreamOutSize())
+        self._out = C.create_string_buffer(self._cap)
+
+    def _check(self, rc):
+        if self._L.ZSTD_isError(rc):
+            raise OSError("zstd: " + self._L.ZSTD_getErrorName(rc).decode())
+
+    def _pump(self, data: bytes, mode: int):
+        src = C.create_string_buffer(data, len(data)) if data else None
+        ib = _InBuf(C.cast(src, C.c_void_p) if src else None, len(data), 0)
+        while True:
+            ob = _OutBuf(C.cast(self._out, C.c_void_p), self._cap, 0)
+            remaining = self._L.ZSTD_compressStream2(self._ctx, C.byref(ob), C.byref(ib), mode)
+            self._check(remaining)
+            if ob.pos:
+                self._raw.write(self._out.raw[:ob.pos])
+            done = (ib.pos == ib.size) if mode == _ZSTD_e_continue else (remaining == 0)
+            if done:
+                break
+
+    def write(self, data: bytes) -> int:
+        if self._backend is not None:
+            return self._backend.write(data)
+        if data:
+            self._pump(bytes(data), _ZSTD_e_continue)
+        return len(data)
+
+    def flush(self):
+        if self._backend is not None:
+            self._backend.flush()
+        else:
+            self._pump(b"", _ZSTD_e_flush)
+
+    def close(self):
+        if self._backend is not None:
+            self._backend.close()
+            self._backend = None
+            return
+        if getattr(self, "_ctx", None):
+            self._pump(b"", _ZSTD_e_end)
+            self._L.ZSTD_freeCCtx(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def decompress(data: bytes) -> bytes:
+    """Whole-buffer decompression of (possibly multi-frame) zstd data; used by tests/tools."""
+    if _zstandard is not None:
+        return _zstandard.ZstdDecompressor().decompressobj().decompress(data)
+    L = _libzstd()
+    ctx = L.ZSTD_createDCtx()
+    cap = int(L.ZSTD_DStreamOutSize())
+    out = C.create_string_buffer(cap)
+    src = C.create_string_buffer(data, len(data))
+    ib = _InBuf(C.cast(src, C.c_void_p), len(data), 0)
+    chunks = []
+    try:
+        while ib.pos < ib.size:
+            ob = _OutBuf(C.cast(out, C.c_void_p), cap, 0)
+            rc = L.ZSTD_decompressStream(ctx, C.byref(ob), C.byref(ib))
+            if L.ZSTD_isError(rc):
+                raise OSError("zstd: " + L.ZSTD_getErrorName(rc).decode())
+            chunks.append(out.raw[:ob.pos])
+    finally:
+        L.ZSTD_freeDCtx(ctx)
+    return b"".join(chunks)

@@ -1,0 +1,99 @@
+"""GPU (-m gpu): the CLI counterparts end to end on the synthetic container --
+dynamont-resquiggle (CSV bytes, .errors lines) and dynamont-train (model files, params.csv) --
+against the same pipeline evaluated with the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import model_for
+from dynamont_amd import synth, zstd_io
+from dynamont_amd.segmentation import segment as seg
+from dynamont_amd.segmentation import train as trn
+from dynamont_amd.segmentation import utils as U
+from oracle.pyoracle import Oracle
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib", "oracle_built")]
+
+
+@pytest.mark.parametrize("pore", ["rna004", "dna_r10_260bps"])
+def test_resquiggle_cli_end_to_end(models, tmp_path, pore):
+    model = model_for(models, pore)
+    pid, rna, k = synth.PORES[pore]
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(71, 9, pore, mean, sd, (60, 260))
+    raw, bam, expected = synth.write_dataset(str(tmp_path / "in"), "ds", reads, pore, seed=9)
+    # corrupt one basecall with an N and make one signal too short -> per-read error lines
+    lines = open(bam).read().splitlines()
+    f = lines[3].split("\t"); f[1] = f[1][:20] + "N" + f[1][21:]; lines[3] = "\t".join(f)
+    f = lines[6].split("\t"); f[4] = str(int(f[5]) + 30); lines[6] = "\t".join(f)   # ns = ts + 30 samples
+    open(bam, "w").write("\n".join(lines) + "\n")
+    out = tmp_path / "out" / "res.csv"
+    seg.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore,
+              "--model_path", model, "--batch-reads", "4"])
+    got = zstd_io.decompress(open(str(out) + ".zst", "rb").read())
+    orc = Oracle(model, pid)
+    want = [seg.CSV_HEADER]
+    errors = []
+    for job in seg.generate_jobs(str(tmp_path / "in"), bam, 0):
+        signal, read = seg.prepare_job(job, rna)
+        _, _, _, start, _, _, readid, signalid = job
+        try:
+            res = orc.align(signal, read, True)
+            res["polishes"] = [""] * len(res["states"])
+            want.append(U.segmentation_to_string(res, readid, signalid, start, len(signal) + start, read, k, rna))
+        except RuntimeError as e:
+            errors.append(f"error: native, {e}\tT: {len(signal)}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
+    seg.close_raw_cache()
+    want = b"".join(want)
+    assert len(errors) == 2
+    assert open(str(tmp_path / "out" / "res.errors")).read().splitlines() == errors
+    # integer / text columns byte-identical; posterior column within 1e-4 (formatted %.6f)
+    gl, wl = got.decode().splitlines(), want.decode().splitlines()
+    assert len(gl) == len(wl) and gl[0] == wl[0]
+    for a, b in zip(gl[1:], wl[1:]):
+        fa, fb = a.split(","), b.split(",")
+        assert fa[:8] == fb[:8] and fa[9] == fb[9]
+        assert abs(float(fa[8]) - float(fb[8])) <= 1e-4
+    assert sum(a == b for a, b in zip(gl, wl)) >= 0.99 * len(gl)
+
+
+@pytest.mark.parametrize("aggregate", ["pooled", "window-mean"])
+def test_train_cli(models, tmp_path, aggregate):
+    pore = "rna002"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(72, 8, pore, mean, sd, (80, 200))
+    raw, bam, expected = synth.write_dataset(str(tmp_path / "in"), "tr", reads, pore, seed=4)
+    # qs filter (default 10) would drop some reads: raise all qualities
+    lines = open(bam).read().splitlines()
+    for i in range(1, len(lines)):
+        f = lines[i].split("\t"); f[2] = "15.0"; lines[i] = "\t".join(f)
+    open(bam, "w").write("\n".join(lines) + "\n")
+    outdir = tmp_path / f"train_{aggregate}"
+    trn.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(outdir), "-p", pore, "--model_path", model,
+              "--batch_size", "4", "--max_batches", "2", "--aggregate", aggregate, "--no-timestamp"])
+    files = sorted(os.listdir(outdir))
+    assert files == ["params.csv", "trained_0_0.model", "trained_0_1.model", "trained_0_2.model"]
+    rows = open(outdir / "params.csv").read().splitlines()
+    assert rows[0] == "epoch,batch,read,e1,m1,e2,Zchange"
+    assert rows[1].startswith("0,1,4,") and rows[2].startswith("0,2,8,")
+    assert all(len(r.split(",")) == 7 for r in rows[1:])
+    assert float(rows[1].split(",")[-1]) > 0       # an EM step on its own batch raises the likelihood
+    m0, m1 = U.read_kmer_model(str(outdir / "trained_0_0.model")), U.read_kmer_model(str(outdir / "trained_0_1.model"))
+    assert list(m0) == list(m1) and m0 != m1
+    if aggregate == "pooled":
+        # first batch against the oracle's pooled statistics
+        orc = Oracle(model, 0)
+        K = orc.num_kmers
+        w, s1, s2 = np.zeros(K), np.zeros(K), np.zeros(K)
+        items = [it for it in trn.read_items(str(tmp_path / "in"), bam, pore, 10.0) if not isinstance(it, str)][:4]
+        for signal, seq, _ in items:
+            t = orc.train(np.asarray(signal, dtype=np.float64), seq, dense=False)
+            w += t["weight"]; s1 += t["sum"]; s2 += t["sumsq"]
+        hit = np.nonzero(w > 0)[0]
+        for c in hit[:50]:
+            name = U.kmer_of_code(int(c), 5, True)
+            assert abs(m1[name][0] - s1[c] / w[c]) <= 1e-9
+            var = max(s2[c] / w[c] - (s1[c] / w[c]) ** 2, 1e-12)
+            assert abs(m1[name][1] - np.sqrt(var)) <= 1e-7

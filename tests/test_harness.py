@@ -1,0 +1,190 @@
+"""CPU: the harness rows P1-P5 -- counterparts of the reference's
+segmentation/{utils,segment,train}.py -- against (a) the golden bytes produced by the
+reference's own functions (tests/golden/g6_harness.npz) and (b) the known-answer vectors of the
+reference's own tests, restated here as data (tests/test_segment.py:179-200,154-157,
+tests/test_utils.py:7-128, tests/test_managed_list.py of the reference)."""
+import io
+import os
+import queue
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden, model_for
+from dynamont_amd import synth, zstd_io
+from dynamont_amd.segmentation import segment as seg
+from dynamont_amd.segmentation import train as trn
+from dynamont_amd.segmentation import utils as U
+from oracle.pyoracle import Oracle
+
+
+def hampel_loop(x, W=3, ns=3.0):
+    """Explicit sliding-window restatement (the shape of the reference test's inline checker)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = x.copy()
+    if x.size <= W:
+        return out
+    n = x.size - W - (W % 2 == 0)
+    for i in range(n):
+        w = x[i:i + W]
+        med = np.median(w)
+        mad = np.median(np.abs(w - med))
+        c = W // 2 + i
+        if abs(x[c] - med) > ns * 1.4826 * mad:
+            out[c] = med
+    return out
+
+
+def test_hampel_known_answers_from_reference_tests():
+    a = np.array([1, 1, 1, 10, 1, 1, 1], dtype=float)
+    U.hampel(a)
+    assert np.array_equal(a, np.ones(7))                      # reference tests/test_utils.py:7-14
+    b = np.array([1, 1, 50, 1, 1, 1, 75, 1], dtype=float)     # reference tests/test_segment.py:179-200
+    want = hampel_loop(b)
+    U.hampel(b)
+    assert np.array_equal(b, want)
+    assert b[-2] == 75.0  # index len-2 is never filtered
+
+
+def test_hampel_matches_reference_outputs():
+    g = golden("g6_harness.npz")
+    for i in range(int(g["n_hampel"])):
+        x = g[f"h{i}_in"].copy()
+        U.hampel(x, int(g[f"h{i}_W"]), float(g[f"h{i}_ns"]))
+        assert np.array_equal(x, g[f"h{i}_out"]), i
+        assert np.array_equal(hampel_loop(g[f"h{i}_in"], int(g[f"h{i}_W"]), float(g[f"h{i}_ns"])), g[f"h{i}_out"])
+
+
+def test_segmentation_to_string_bytes_match_reference(models, oracle_built):
+    g = golden("g6_harness.npz")
+    for i in range(int(g["n_csv"])):
+        p = f"csv{i}_"
+        pore = str(g[p + "pore"])
+        pid, rna, k = synth.PORES[pore]
+        seq = str(g[p + "sequence"])
+        res = Oracle(model_for(models, pore), pid).align(g[p + "signal"], seq, True)
+        res["polishes"] = [""] * len(res["states"])
+        start = int(g[p + "start"])
+        got = U.segmentation_to_string(res, f"read-{i}", f"sig-{i}", start, len(g[p + "signal"]) + start, seq, k, rna)
+        assert got == g[p + "bytes"].tobytes()
+        first = got.split(b"\n")[0].split(b",")
+        assert first[2] == str(start).encode() and first[7] == b"M" and first[9] == b"NA"
+
+
+def test_model_io_and_small_helpers(tmp_path):
+    m = {"AAAAA": (0.5, 0.25), "AAAAC": (1.25, 0.125)}
+    f = tmp_path / "m.model"
+    U.write_kmer_model(str(f), m)
+    assert f.read_text() == "kmer\tlevel_mean\tlevel_stdv\nAAAAA\t0.5\t0.25\nAAAAC\t1.25\t0.125\n"
+    assert U.read_kmer_model(str(f)) == m
+    assert U.cnt_nts("AACGTT") == {"A": 2, "C": 1, "G": 1, "T": 2}
+    assert U.cnt_nts_ratios("AACG") == {"A": 0.5, "C": 0.25, "G": 0.25, "T": 0.0}
+    e = U.SegmentationError("r1")
+    assert str(e) == "No segmentation calculated for r1" and e.read == "r1"
+    assert U.get_model("rna004").endswith("models/rna/rna004/rna004_9mer.model")
+    assert U.get_model("/x/custom.model").endswith("/x/custom.model")
+    assert U.kmer_of_code(1, 5, False) == "AAAAC" and U.kmer_of_code(1, 5, True) == "CAAAA"
+
+
+def test_managed_list_semantics():
+    ml = trn.ManagedList([1.0], max_size=3)
+    for v in (2.0, 3.0, 4.0):
+        ml.add(v)
+    assert ml.get_list() == [2.0, 3.0, 4.0] and ml.mean() == 3.0 and ml.median() == 3.0
+    assert repr(ml) == "ManagedList([2.0, 3.0, 4.0])"
+    empty = trn.ManagedList([])
+    assert empty.mean() is None and empty.median() is None
+    tab = trn.ManagedTable(np.array([1.0, 2.0]), np.array([0.1, 0.2]), max_size=2)
+    tab.add(np.array([3.0, 2.0]), np.array([0.3, 0.2]))
+    m, s = tab.mean()
+    assert np.allclose(m, [2.0, 2.0]) and np.allclose(s, [0.2, 0.2])
+    tab.add(np.array([5.0, 2.0]), np.array([0.5, 0.2]))   # evicts the initial entry
+    assert np.allclose(tab.mean()[0], [4.0, 2.0])
+
+
+def test_cli_surfaces():
+    a = seg.parse(["-r", "raw", "-b", "x.bam", "-o", "out", "--mode", "basic", "-p", "rna004"])
+    assert a.processes > 0 and a.qscore == 0.0 and a.model_path is None and a.mode == "basic"
+    with pytest.raises(SystemExit):
+        seg.parse(["-r", "raw", "-b", "x.bam", "-o", "out", "--mode", "fancy", "-p", "rna004"])
+    t = trn.parse(["-r", "raw", "-b", "x.bam", "-o", "out", "-p", "rna002"])
+    assert t.batch_size == 24 and t.epochs == 1 and t.qscore == 10.0 and t.max_batches is None
+
+
+class FakeReader:
+    def __init__(self, name, fail_close=False):
+        self.name, self.closed, self.fail_close = name, False, fail_close
+
+    def close(self):
+        self.closed = True
+        if self.fail_close:
+            raise RuntimeError("close failed")
+
+
+def test_raw_cache_lru(monkeypatch):
+    opened = []
+
+    def fake_open(path):
+        r = FakeReader(path, fail_close=(path == "b"))
+        opened.append(r)
+        return r
+
+    monkeypatch.setattr(seg, "open_pod5", fake_open)
+    monkeypatch.setattr(seg, "RAW_CACHE", None)
+    monkeypatch.setattr(seg, "RAW_CACHE_SIZE", 2)
+    ra = seg.get_raw("a")
+    assert seg.get_raw("a") is ra and len(opened) == 1           # hit
+    rb = seg.get_raw("b")
+    seg.get_raw("a")                                              # move-to-end: b is now oldest
+    seg.get_raw("c")                                              # evicts b; its close error is swallowed
+    assert rb.closed and not ra.closed and list(seg.RAW_CACHE) == ["a", "c"]
+    seg.close_raw_cache()
+    assert ra.closed and len(seg.RAW_CACHE) == 0
+
+
+def test_listener_protocol_and_zstd(tmp_path):
+    out = tmp_path / "results.csv.zst"
+    q = queue.Queue()
+    for item in (b"r1,s1,0,5,2,A,ACG,M,0.500000,NA\n", "error: native, Signal is empty\tT: 0\tN: 9\tRid: r2\tSid: s2",
+                 b"r3,s3,1,2,3,C,CCC,M,1.000000,NA\n", "kill"):
+        q.put(item)
+    seg.listener(q, str(out))
+    data = zstd_io.decompress(out.read_bytes())
+    assert data == (b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
+                    b"r1,s1,0,5,2,A,ACG,M,0.500000,NA\nr3,s3,1,2,3,C,CCC,M,1.000000,NA\n")
+    assert (tmp_path / "results.errors").read_text() == "error: native, Signal is empty\tT: 0\tN: 9\tRid: r2\tSid: s2\n"
+    assert out.read_bytes()[:4] == b"\x28\xb5\x2f\xfd"  # zstd frame magic
+
+
+def test_zstd_roundtrip_large():
+    rng = np.random.default_rng(0)
+    payload = b"".join(b"%d,%f\n" % (i, x) for i, x in enumerate(rng.standard_normal(20000)))
+    buf = io.BytesIO()
+    with zstd_io.ZstdWriter(buf, level=3) as w:
+        for i in range(0, len(payload), 7777):
+            w.write(payload[i:i + 7777])
+    assert zstd_io.decompress(buf.getvalue()) == payload and len(buf.getvalue()) < len(payload)
+
+
+@pytest.mark.parametrize("pore", ["rna004", "dna_r10_400bps"])
+def test_job_generation_and_preprocessing(models, tmp_path, pore):
+    _, mean, sd = synth.read_model_file(model_for(models, pore))
+    reads = synth.make_reads(31, 5, pore, mean, sd, (40, 90))
+    raw, bam, expected = synth.write_dataset(str(tmp_path), "ds", reads, pore, seed=3)
+    jobs = list(seg.generate_jobs(str(tmp_path), bam, 0))
+    assert len(jobs) == 5 and all(j[0] == raw for j in jobs)
+    assert all(j[3] == 37 for j in jobs)                       # start = sp + ts
+    rna = synth.PORES[pore][1]
+    for job, (x, seq) in zip(jobs, expected):
+        signal, read = seg.prepare_job(job, rna)
+        assert signal.dtype == np.float64 and len(signal) == job[4] - job[3]
+        assert np.array_equal(signal, hampel_loop(x))          # -= shift, /= scale, Hampel(3, 3 sigma)
+        assert read == seq
+        if rna:
+            assert read.startswith("AAAAAAAAA")
+    # quality filter
+    qs = [float(l.split("\t")[2]) for l in open(bam).read().splitlines()[1:]]
+    kept = list(seg.generate_jobs(str(tmp_path), bam, 12.0))
+    assert len(kept) == sum(q >= 12.0 for q in qs)
+    seg.close_raw_cache()
