@@ -61,8 +61,12 @@ def test_resquiggle_cli_end_to_end(models, tmp_path, pore):
 @pytest.mark.parametrize("aggregate", ["pooled", "window-mean"])
 def test_train_cli(models, tmp_path, aggregate):
     pore = "rna002"
-    model = model_for(models, pore)
-    _, mean, sd = synth.read_model_file(model)
+    # the reference skips per-read updates whose polyA k-mer mean is < 0.5 (train.py:198-199); real
+    # models have it near 0.9, the seeded synthetic one does not, so pin it for this test
+    kmers, mean, sd = synth.read_model_file(model_for(models, pore))
+    mean[kmers.index("AAAAA")] = 1.2
+    model = str(tmp_path / "polyA_ok.model")
+    U.write_kmer_model(model, {k_: (float(m), float(s)) for k_, m, s in zip(kmers, mean, sd)})
     reads = synth.make_reads(72, 8, pore, mean, sd, (80, 200))
     raw, bam, expected = synth.write_dataset(str(tmp_path / "in"), "tr", reads, pore, seed=4)
     # qs filter (default 10) would drop some reads: raise all qualities
