@@ -80,22 +80,39 @@ __device__ __forceinline__ double wave_rol1(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// out[slot] = x[slot-1] over the P slots of a row (slot = j*64 + lane, cyclic).
-__device__ __forceinline__ void from_left(const double (&x)[CPL], double (&out)[CPL], int lane) {
+// Lane mask that the optimiser cannot see through: all ones in `which` lane, zero elsewhere.
+// (With a visible `lane == 63 ? a : b` hipcc merges the 7 per-register selects into a 7-way
+// indexed lookup: 12 v_cndmask + 6 v_cmp per cell instead of 2 v_bfi.)
+__device__ __forceinline__ int opaque_lane_mask(int lane, int which) {
+  int m = (lane == which) ? -1 : 0;
+  asm volatile("" : "+v"(m));
+  return m;
+}
+
+// bitwise (m ? a : b) on both halves of a double: two v_bfi_b32
+__device__ __forceinline__ double bit_select(int m, double a, double b) {
+  int lo, hi;  // v_bfi_b32 D = (S0 & S1) | (~S0 & S2); hipcc does not form it from either C idiom
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"(__double2loint(a)), "v"(__double2loint(b)));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"(__double2hiint(a)), "v"(__double2hiint(b)));
+  return __hiloint2double(hi, lo);
+}
+
+// out[slot] = x[slot-1] over the P slots of a row (slot = j*64 + lane, cyclic). m0 = mask of lane 0.
+__device__ __forceinline__ void from_left(const double (&x)[CPL], double (&out)[CPL], int m0) {
   double rot[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) rot[j] = wave_ror1(x[j]);
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) out[j] = (lane == 0) ? rot[(j + CPL - 1) % CPL] : rot[j];
+  for (int j = 0; j < CPL; ++j) out[j] = bit_select(m0, rot[(j + CPL - 1) % CPL], rot[j]);
 }
 
-// out[slot] = x[slot+1]
-__device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)[CPL], int lane) {
+// out[slot] = x[slot+1]. m63 = mask of lane 63.
+__device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)[CPL], int m63) {
   double rot[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) rot[j] = wave_rol1(x[j]);
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) out[j] = (lane == 63) ? rot[(j + 1) % CPL] : rot[j];
+  for (int j = 0; j < CPL; ++j) out[j] = bit_select(m63, rot[(j + 1) % CPL], rot[j]);
 }
 
 __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, int N) {
@@ -146,6 +163,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
   double* __restrict__ out = ws + rd.ws_off + lane;
+  const int m63 = opaque_lane_mask(lane, 63);
 
   int lo = band_mid(T - 1, ratio) - bw;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
@@ -177,7 +195,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       for (int j = 0; j < CPL; ++j) Y[j] = bM[j] + e[j];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) A[j] = bE[j] + e[j];
-      from_right(Y, Yr, lane);
+      from_right(Y, Yr, m63);
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved down by one column
         const int leaving = lo + P - 1;
@@ -240,6 +258,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   float2* __restrict__ lat_lp = reinterpret_cast<float2*>(lat);
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
+  const int m0 = opaque_lane_mask(lane, 0);
 
   int lo = band_mid(0, ratio) - bw;  // = -bw
   int n[CPL];
@@ -272,9 +291,9 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       const int t = tb + i;
       const double xn = readlane_f64(xs, i);
       double fEl[CPL], vEl[CPL], bnn[CPL];
-      from_left(fE, fEl, lane);
+      from_left(fE, fEl, m0);
       if (POST) {
-        from_left(vE, vEl, lane);
+        from_left(vE, vEl, m0);
         const bool have = (t + 2 < T);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
@@ -324,7 +343,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
-        uint64_t mybits = bj[0];
+        uint64_t mybits = bj[0];  // lane j keeps ballot j
 #pragma unroll
         for (int j = 1; j < CPL; ++j) mybits = (lane == j) ? bj[j] : mybits;
 #pragma unroll
@@ -528,6 +547,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
   const double Z = st[rd.read].Zb;
+  const int m0 = opaque_lane_mask(lane, 0);
 
   int lo = band_mid(0, ratio) - bw;
   int n[CPL];
@@ -559,7 +579,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
       const int t = tb0 + i;
       const double xn = readlane_f64(xs, i);
       double fEl[CPL], bnn[CPL];
-      from_left(fE, fEl, lane);
+      from_left(fE, fEl, m0);
       const bool have = (t + 2 < T);
 #pragma unroll
       for (int j = 0; j < CPL; ++j)
