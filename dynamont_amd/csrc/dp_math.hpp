@@ -226,6 +226,90 @@ DYN_HD void softplus_nonpos_vec(double (&d)[M], double (&g)[M]) {
   for (int j = 0; j < M; ++j) g[j] = fma_(c[j], LN2, f[j] + f[j]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table-driven softplus. g(d) = log1p(exp(d)) satisfies g1 = s (the logistic function) and every
+// higher derivative is a polynomial in s:  with u = s(1-s), w = 1-2s
+//   g2 = u,  g3 = u w,  g4 = u (1-6u),  g5 = u w (1-12u),  |g6| <= 1/4      (gk = k-th derivative)
+// A table of (g, s) at the nodes d_i = -i/128, i = 0..5120 (81 936 bytes, one copy in the LDS of
+// each CU) plus the degree-5 Taylor polynomial about the NEAREST node (|r| <= 1/256) gives
+// |error| <= 1/4 (1/256)^6 / 720 = 1.2e-18 + the rounding of g_i and of the last FMA, i.e. the
+// same <= ~1 ulp class as the polynomial form above at 24 instead of 45 fp64 instructions.
+// d <= -40 (incl. -inf and NaN, clamped) maps to the last node, which holds (0, 0): g = 0 exactly.
+// ---------------------------------------------------------------------------------------------
+struct SoftplusNode {
+  double g, s;
+};
+constexpr int SP_STEPS = 128;                   // nodes per unit of d
+constexpr int SP_RANGE = 40;                    // table covers d in [-40, 0]
+constexpr int SP_NODES = SP_STEPS * SP_RANGE + 1;
+
+// Host-side generator (long double arithmetic, rounded once to double).
+inline void softplus_build_table(SoftplusNode* t) {
+  for (int i = 0; i < SP_NODES; ++i) {
+    const long double d = -(long double)i / SP_STEPS;
+    const long double e = expl(d);
+    t[i].g = (i == SP_NODES - 1) ? 0.0 : (double)log1pl(e);
+    t[i].s = (i == SP_NODES - 1) ? 0.0 : (double)(e / (1.0L + e));
+  }
+}
+
+template <int M>
+DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNode* __restrict__ tab) {
+  double kf[M], r[M], g0[M], s[M], u[M], w[M], uw[M], p[M], q[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -(double)SP_RANGE);  // also NaN -> -40
+#pragma unroll
+  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * -(double)SP_STEPS);
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);          // exact
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const SoftplusNode nd = tab[(int)kf[j]];
+    g0[j] = nd.g;
+    s[j] = nd.s;
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = 1.0 - s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) u[j] = s[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = w[j] - s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0, 1.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = (uw[j] * q[j]) * (1.0 / 120.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0, 1.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = (u[j] * q[j]) * (1.0 / 24.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], uw[j] * (1.0 / 6.0));
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], u[j] * 0.5);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], s[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) g[j] = fma_(p[j], r[j], g0[j]);
+}
+
+// out[j] = logPlus(x[j], y[j]) with the table-driven softplus
+template <int M>
+DYN_HD void log_plus_table_vec(const double (&x)[M], const double (&y)[M], double (&out)[M],
+                               const SoftplusNode* __restrict__ tab) {
+  double hi[M], d[M], g[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) hi[j] = __builtin_fmax(x[j], y[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(x[j], y[j]) - hi[j];
+  softplus_table_vec<M>(d, g, tab);
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = hi[j] + g[j];
+}
+
 // out[j] = logPlus(x[j], y[j])
 template <int M>
 DYN_HD void log_plus_vec(const double (&x)[M], const double (&y)[M], double (&out)[M]) {

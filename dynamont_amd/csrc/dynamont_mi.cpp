@@ -69,6 +69,7 @@ struct dyn_aligner {
   int threads = 1;
   hipStream_t stream = nullptr;
   DevBuf d_model;
+  DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
   uint64_t mem_budget = 0;
   std::string last_error;
   // grow-only lattice workspace pool, reused across batches
@@ -220,6 +221,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
                               " (the MI355X build has no CPU compute path)");
     if (a->stream) (void)hipStreamDestroy(a->stream);
     a->d_model.release();
+    a->d_sptab.release();
     delete a;
     return (int)DYN_ERR_DEVICE;
   };
@@ -235,6 +237,13 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
                      hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy(model)");
+  {
+    std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES);
+    dynmath::softplus_build_table(tab.data());
+    if ((e = a->d_sptab.ensure(sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess) return fail(e, "hipMalloc(softplus table)");
+    if ((e = hipMemcpy(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
+      return fail(e, "hipMemcpy(softplus table)");
+  }
   *out = a;
   return DYN_OK;
 }
@@ -244,6 +253,7 @@ void dyn_aligner_destroy(dyn_aligner* a) {
   if (!a->host_only) {
     (void)hipSetDevice(a->device);
     a->d_model.release();
+    a->d_sptab.release();
     a->ws.release();
     a->bits.release();
     a->pp.release();
@@ -523,13 +533,13 @@ int run_job(dyn_batch* b, Job job) {
     const Emis* par = b->d_par.as<Emis>();
     ReadState* dst = b->d_state.as<ReadState>();
     HIP_TRY(a, hipEventRecord(ev[0], a->stream));
-    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, a->stream);
+    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     HIP_TRY(a, hipEventRecord(ev[1], a->stream));
     if (job == Job::Train) {
       dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->stream);
+      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     } else {
-      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->stream);
+      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     }
     HIP_TRY(a, hipEventRecord(ev[2], a->stream));
     if (calc) {

@@ -35,7 +35,12 @@
 // streams with 7-way ILP that saturate a SIMD on their own, so they are compiled for exactly one
 // wave per SIMD: the dispatcher must then spread the reads over all 1 024 SIMDs, and the whole
 // 512-entry register file is available to keep the interleaved chains out of AGPR spills.
-#define DYN_ONE_WAVE_PER_SIMD __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define DYN_ONE_WAVE_PER_SIMD __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+
+// The DP kernels run FOUR reads per 256-thread workgroup (one wave each, one per SIMD of a CU):
+// the four waves never synchronise after the prologue, they only share the 82 KB softplus table
+// that the workgroup stages into the CU's LDS once (dp_math.hpp, softplus_table_vec).
+#define DYN_READS_PER_GROUP 4
 
 namespace dynk {
 
@@ -45,6 +50,9 @@ using dynmath::log_plus;
 using dynmath::EmisV;
 using dynmath::log_normal_pdf_vec;
 using dynmath::log_plus_vec;
+using dynmath::log_plus_table_vec;
+using dynmath::SoftplusNode;
+using dynmath::SP_NODES;
 
 namespace {
 
@@ -128,6 +136,16 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   return e;
 }
 
+// Stage the softplus table into LDS (all 256 threads), then tell the caller which read this
+// wave owns (-1: none; the wave must still have taken part in the barrier).
+__device__ __forceinline__ int stage_table_and_pick_read(SoftplusNode* s_tab, const SoftplusNode* __restrict__ tab,
+                                                         int n_reads) {
+  for (int i = threadIdx.x; i < SP_NODES; i += 256) s_tab[i] = tab[i];
+  __syncthreads();
+  const int r = blockIdx.x * DYN_READS_PER_GROUP + (threadIdx.x >> 6);
+  return r < n_reads ? r : -1;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -155,9 +173,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
                                                   const Emis* __restrict__ par,
                                                   double* __restrict__ ws,
                                                   ReadState* __restrict__ st, double m1,
-                                                  double e2) {
-  const ReadDesc rd = descs[blockIdx.x];
-  const int lane = threadIdx.x;
+                                                  double e2, const SoftplusNode* __restrict__ sp_tab,
+                                                  int n_reads) {
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
+  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
+  if (ridx < 0) return;
+  const ReadDesc rd = descs[ridx];
+  const int lane = threadIdx.x & 63;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
@@ -215,7 +237,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x2[j] = A[j] + e2;
-      log_plus_vec<CPL>(x1, x2, ne);
+      log_plus_table_vec<CPL>(x1, x2, ne, s_tab);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         bE[j] = ne[j];
@@ -247,9 +269,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
                                                  double* __restrict__ ws,
                                                  uint64_t* __restrict__ bits,
                                                  ReadState* __restrict__ st, double m1,
-                                                 double e2) {
-  const ReadDesc rd = descs[blockIdx.x];
-  const int lane = threadIdx.x;
+                                                 double e2, const SoftplusNode* __restrict__ sp_tab,
+                                                 int n_reads) {
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
+  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
+  if (ridx < 0) return;
+  const ReadDesc rd = descs[ridx];
+  const int lane = threadIdx.x & 63;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
@@ -326,7 +352,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       for (int j = 0; j < CPL; ++j) a1[j] = fM[j] + e[j];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) a2[j] = (fE[j] + e[j]) + e2;
-      log_plus_vec<CPL>(a1, a2, fEn);
+      log_plus_table_vec<CPL>(a1, a2, fEn, s_tab);
       log_normal_pdf_vec<CPL>(xn, p, en);  // e(t+1, n)
       if (POST) {
         double LPM[CPL], LPE[CPL], vMn[CPL], vEn[CPL], alt[CPL];
@@ -400,7 +426,7 @@ __global__ void k_zcheck(const ReadDesc* __restrict__ descs, int n_reads,
 // run of rows that share a column, its M cell is the lowest row (segrow).
 // 64 rows of bits are staged in LDS per step so the serial walk pays LDS, not HBM, latency.
 // ---------------------------------------------------------------------------------------------
-__global__ DYN_ONE_WAVE_PER_SIMD void k_trace(const ReadDesc* __restrict__ descs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_trace(const ReadDesc* __restrict__ descs,
                                                const double* __restrict__ ws,
                                                const uint64_t* __restrict__ bits,
                                                ReadState* __restrict__ st, TraceBuffers tb,
@@ -535,9 +561,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
                                                        const Emis* __restrict__ par,
                                                        const double* __restrict__ ws,
                                                        ReadState* __restrict__ st,
-                                                       TrainBuffers tb, double m1, double e2) {
-  const ReadDesc rd = descs[blockIdx.x];
-  const int lane = threadIdx.x;
+                                                       TrainBuffers tb, double m1, double e2,
+                                                       const SoftplusNode* __restrict__ sp_tab, int n_reads) {
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
+  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
+  if (ridx < 0) return;
+  const ReadDesc rd = descs[ridx];
+  const int lane = threadIdx.x & 63;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
@@ -670,29 +700,33 @@ void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint
 }
 
 void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                     double* ws, ReadState* st, double m1, double e2, bool store, hipStream_t s) {
+                     double* ws, ReadState* st, double m1, double e2, bool store,
+                     const SoftplusNode* sp_tab, hipStream_t s) {
   if (n_reads <= 0) return;
+  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
   if (store)
-    hipLaunchKernelGGL(k_backward<true>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, m1, e2);
+    hipLaunchKernelGGL(k_backward<true>, grid, block, 0, s, descs, sig, par, ws, st, m1, e2, sp_tab, n_reads);
   else
-    hipLaunchKernelGGL(k_backward<false>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, m1, e2);
+    hipLaunchKernelGGL(k_backward<false>, grid, block, 0, s, descs, sig, par, ws, st, m1, e2, sp_tab, n_reads);
 }
 
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                     double* ws, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
-                    hipStream_t s) {
+                    const SoftplusNode* sp_tab, hipStream_t s) {
   if (n_reads <= 0) return;
+  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
   if (post)
-    hipLaunchKernelGGL(k_forward<true>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, bits, st, m1, e2);
+    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, ws, bits, st, m1, e2, sp_tab, n_reads);
   else
-    hipLaunchKernelGGL(k_forward<false>, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, bits, st, m1, e2);
+    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, ws, bits, st, m1, e2, sp_tab, n_reads);
 }
 
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                           const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
-                          hipStream_t s) {
+                          const SoftplusNode* sp_tab, hipStream_t s) {
   if (n_reads <= 0) return;
-  hipLaunchKernelGGL(k_forward_train, dim3(n_reads), dim3(64), 0, s, descs, sig, par, ws, st, tb, m1, e2);
+  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
+  hipLaunchKernelGGL(k_forward_train, grid, block, 0, s, descs, sig, par, ws, st, tb, m1, e2, sp_tab, n_reads);
 }
 
 void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,

@@ -65,14 +65,16 @@ struct TrainBuffers {
 
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
                         hipStream_t s);
+// sp_tab: device copy of dynmath::softplus_build_table (SP_NODES entries)
 void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                     double* ws, ReadState* st, double m1, double e2, bool store, hipStream_t s);
+                     double* ws, ReadState* st, double m1, double e2, bool store,
+                     const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                     double* ws, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
-                    hipStream_t s);
+                    const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                           const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
-                          hipStream_t s);
+                          const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
                   const double* ws, const uint64_t* bits, ReadState* st, TraceBuffers tb,
                   SegRow* rows, int kmer_size, int z_fail_status, hipStream_t s);
