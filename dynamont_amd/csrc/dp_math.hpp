@@ -310,6 +310,67 @@ DYN_HD void log_plus_table_vec(const double (&x)[M], const double (&y)[M], doubl
   for (int j = 0; j < M; ++j) out[j] = hi[j] + g[j];
 }
 
+// Two-phase form of the table-driven logPlus so that independent work (the next row's emission)
+// can be placed between issuing the LDS lookups and consuming them:
+//   SoftplusLookup<M> L;  log_plus_issue(x, y, L, tab);   ...independent code...   log_plus_finish(L, out);
+template <int M>
+struct SoftplusLookup {
+  double hi[M], r[M], g0[M], s[M];
+};
+
+template <int M>
+DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusLookup<M>& L,
+                           const SoftplusNode* __restrict__ tab) {
+  double d[M], kf[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) L.hi[j] = __builtin_fmax(x[j], y[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(x[j], y[j]) - L.hi[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -(double)SP_RANGE);  // also NaN -> -40
+#pragma unroll
+  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * -(double)SP_STEPS);
+#pragma unroll
+  for (int j = 0; j < M; ++j) L.r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);  // exact
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const SoftplusNode nd = tab[(int)kf[j]];
+    L.g0[j] = nd.g;
+    L.s[j] = nd.s;
+  }
+}
+
+template <int M>
+DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
+  double u[M], w[M], uw[M], p[M], q[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) u[j] = L.s[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0, 1.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = (uw[j] * q[j]) * (1.0 / 120.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0, 1.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = (u[j] * q[j]) * (1.0 / 24.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], uw[j] * (1.0 / 6.0));
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], u[j] * 0.5);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.s[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
+}
+
 // out[j] = logPlus(x[j], y[j])
 template <int M>
 DYN_HD void log_plus_vec(const double (&x)[M], const double (&y)[M], double (&out)[M]) {

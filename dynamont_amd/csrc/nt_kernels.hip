@@ -52,6 +52,9 @@ using dynmath::log_normal_pdf_vec;
 using dynmath::log_plus_vec;
 using dynmath::log_plus_table_vec;
 using dynmath::SoftplusNode;
+using dynmath::SoftplusLookup;
+using dynmath::log_plus_issue;
+using dynmath::log_plus_finish;
 using dynmath::SP_NODES;
 
 namespace {
@@ -123,6 +126,8 @@ __device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)
   for (int j = 0; j < CPL; ++j) out[j] = bit_select(m63, rot[(j + 1) % CPL], rot[j]);
 }
 
+// n is wave-uniform at the re-assignment sites: the load then becomes an s_load (lgkmcnt), which
+// keeps it out of the vector-memory counter the DMA ring waits on.
 __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, int N) {
   Emis e;
   if (n >= 1 && n < N) {
@@ -136,13 +141,69 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   return e;
 }
 
+// ---- LDS-DMA row ring (k_forward) -------------------------------------------------------------
+// K_fwd must read one [448]-double bE row per lattice row while it overwrites an older row. With
+// the rows prefetched into VGPRs the single wave of a SIMD stalled on s_waitcnt for 43 % of its
+// life (compiler-placed vmcnt(0) behind the previous row's stores, prefetch registers spilled to
+// AGPRs mid-row). The rows now go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, 3 full +
+// 1 half-wave instruction per 3584-byte row), RING_D rows ahead, and are picked up with ds_read_b64
+// behind a hand-counted s_waitcnt. Validated in isolation by tools/ubench/lds_dma_test.hip.
+constexpr int RING_D = 4;
+constexpr int ROW_BYTES = P * 8;
+// vmcnt(N) lets the N youngest vector-memory operations stay in flight. Only the DMA instructions
+// themselves are counted (4 per row, RING_D-1 younger rows => 12): loads retire in issue order, so
+// the wait is correct whatever the compiler does with the stores, sample and parameter loads
+// that share the counter (they can only make it stricter).
+constexpr int RING_WAIT = 4 * (RING_D - 1);
+
+// row_lane_ptr = &row[lane*2]; `offset:` advances both the global and the LDS address.
+__device__ __forceinline__ void ring_dma_row(const double* row_lane_ptr, unsigned lds_slot_addr) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off\n\t"
+      "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+      "s_mov_b32 exec_hi, 0\n\t"
+      "global_load_lds_dwordx4 %0, off offset:3072\n\t"
+      "s_mov_b32 exec_hi, -1\n\t"
+      ::"v"(row_lane_ptr), "s"(__builtin_amdgcn_readfirstlane(lds_slot_addr))
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// the wave's copy of one row: cell (j, lane) sits at slot*8 = (j*64 + lane)*8
+__device__ __forceinline__ void ring_read_row(unsigned lds_lane_addr, double (&b)[CPL]) {
+  static_assert(CPL == 7, "ring_read_row is written for 7 cells per lane");
+  asm volatile(
+      "ds_read_b64 %0, %7\n\t"
+      "ds_read_b64 %1, %7 offset:512\n\t"
+      "ds_read_b64 %2, %7 offset:1024\n\t"
+      "ds_read_b64 %3, %7 offset:1536\n\t"
+      "ds_read_b64 %4, %7 offset:2048\n\t"
+      "ds_read_b64 %5, %7 offset:2560\n\t"
+      "ds_read_b64 %6, %7 offset:3072\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6])
+      : "v"(lds_lane_addr)
+      : "memory");
+}
+
 // Stage the softplus table into LDS (all 256 threads), then tell the caller which read this
 // wave owns (-1: none; the wave must still have taken part in the barrier).
 __device__ __forceinline__ int stage_table_and_pick_read(SoftplusNode* s_tab, const SoftplusNode* __restrict__ tab,
                                                          int n_reads) {
   for (int i = threadIdx.x; i < SP_NODES; i += 256) s_tab[i] = tab[i];
   __syncthreads();
-  const int r = blockIdx.x * DYN_READS_PER_GROUP + (threadIdx.x >> 6);
+  // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
+  // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /
+  // parameter access becomes a vector load.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = blockIdx.x * DYN_READS_PER_GROUP + wave;
   return r < n_reads ? r : -1;
 }
 
@@ -190,7 +251,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   int lo = band_mid(T - 1, ratio) - bw;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
   int n[CPL];
-  double bE[CPL], bM[CPL];
+  double bE[CPL], bM[CPL], e[CPL];
   EmisV<CPL> p;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
@@ -207,12 +268,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
     const int idx = base + lane;
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
     const int ilo = base < 0 ? -base : 0;
+    log_normal_pdf_vec<CPL>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
 #pragma unroll 1
     for (int i = 63; i >= ilo; --i) {
       const int t = base + i;
-      const double x = readlane_f64(xs, i);
-      double e[CPL], Y[CPL], A[CPL], Yr[CPL], x1[CPL], x2[CPL], ne[CPL];
-      log_normal_pdf_vec<CPL>(x, p, e);
+      // e[] = e(t+1, n) was computed during the previous row's table lookups (software pipeline)
+      double Y[CPL], A[CPL], Yr[CPL], x1[CPL], x2[CPL], ne[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) Y[j] = bM[j] + e[j];
 #pragma unroll
@@ -221,11 +282,14 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved down by one column
         const int leaving = lo + P - 1;
+        // uniform address, outside the per-lane branch: a scalar load (lgkmcnt). A vector load here
+        // makes hipcc guard every later read of p with s_waitcnt vmcnt(0) in EVERY row.
+        const Emis fresh = load_emis(pr, new_lo, N);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
-            p.set(j, load_emis(pr, new_lo, N));
+            p.set(j, fresh);
           }
         }
         lo = new_lo;
@@ -237,7 +301,16 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x2[j] = A[j] + e2;
-      log_plus_table_vec<CPL>(x1, x2, ne, s_tab);
+      SoftplusLookup<CPL> L;
+      log_plus_issue<CPL>(x1, x2, L, s_tab);
+      // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
+      // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: that one
+      //  emission is computed after the block switch below)
+      if (i > 0) {
+        const double xnext = readlane_f64(xs, i - 1);
+        log_normal_pdf_vec<CPL>(xnext, p, e);
+      }
+      log_plus_finish<CPL>(L, ne);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         bE[j] = ne[j];
@@ -266,7 +339,8 @@ template <bool POST>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ descs,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par,
-                                                 double* __restrict__ ws,
+                                                 const double* __restrict__ ws_rd,
+                                                 float2* __restrict__ ws_wr,
                                                  uint64_t* __restrict__ bits,
                                                  ReadState* __restrict__ st, double m1,
                                                  double e2, const SoftplusNode* __restrict__ sp_tab,
@@ -280,8 +354,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ lat = ws + rd.ws_off + lane;
-  float2* __restrict__ lat_lp = reinterpret_cast<float2*>(lat);
+  // ws_rd / ws_wr are the SAME workspace: row t+2 (bE) is read while row t is overwritten in
+  // place with (float LPM, float LPE). They are separate __restrict__ parameters on purpose: with a
+  // pointer derived from the load pointer hipcc orders every prefetch behind the previous row's
+  // stores (s_waitcnt vmcnt(0) at the top of each row = 43 % of the wave's lifetime spent waiting).
+  // No address is ever read after it has been written within one launch.
+  const double* __restrict__ lat = ws_rd + rd.ws_off + lane;
+  float2* __restrict__ lat_lp = ws_wr + rd.ws_off + lane;
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
   const int m0 = opaque_lane_mask(lane, 0);
@@ -303,10 +382,18 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
       vM[j] = NEG_INF;
       bcur[j] = lat[(size_t)1 * P + j * 64];
-      bnext[j] = (T > 2) ? lat[(size_t)2 * P + j * 64] : NEG_INF;
+      bnext[j] = NEG_INF;
     }
   }
   log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
+  // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
+  __shared__ __attribute__((aligned(16))) double s_ring[DYN_READS_PER_GROUP][RING_D][P];
+  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][0];
+  const unsigned ring_lane = ring_base + lane * 8;
+  const double* __restrict__ dma_src = ws_rd + rd.ws_off + lane * 2;
+  if (POST) {
+    for (int r = 2; r <= RING_D + 1 && r < T; ++r) ring_dma_row(dma_src + (size_t)r * P, ring_base + (r % RING_D) * ROW_BYTES);
+  }
 
   for (int tb = 1; tb < T; tb += 64) {
     const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
@@ -316,21 +403,29 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
     for (int i = 0; i < iend; ++i) {
       const int t = tb + i;
       const double xn = readlane_f64(xs, i);
-      double fEl[CPL], vEl[CPL], bnn[CPL];
-      from_left(fE, fEl, m0);
+      double fEl[CPL], vEl[CPL];
       if (POST) {
-        from_left(vE, vEl, m0);
-        const bool have = (t + 2 < T);
+        // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D
+        if (t + 1 < T) {
+          if (t + RING_D < T) wait_vmcnt<RING_WAIT>(); else wait_vmcnt<0>();
+          ring_read_row(ring_lane + ((t + 1) % RING_D) * ROW_BYTES, bnext);
+          if (t + 1 + RING_D < T)
+            ring_dma_row(dma_src + (size_t)(t + 1 + RING_D) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
+        } else {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
+          for (int j = 0; j < CPL; ++j) bnext[j] = NEG_INF;
+        }
       }
+      from_left(fE, fEl, m0);
+      if (POST) from_left(vE, vEl, m0);
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved up by one column
+        const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load (see k_backward)
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == lo) {  // column lo leaves the band; its slot becomes column lo+P
             n[j] = lo + P;
-            p.set(j, load_emis(pr, lo + P, N));
+            p.set(j, fresh);
             fM[j] = NEG_INF;
             fE[j] = NEG_INF;
             e[j] = NEG_INF;
@@ -352,8 +447,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       for (int j = 0; j < CPL; ++j) a1[j] = fM[j] + e[j];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) a2[j] = (fE[j] + e[j]) + e2;
-      log_plus_table_vec<CPL>(a1, a2, fEn, s_tab);
-      log_normal_pdf_vec<CPL>(xn, p, en);  // e(t+1, n)
+      SoftplusLookup<CPL> L;
+      log_plus_issue<CPL>(a1, a2, L, s_tab);
+      log_normal_pdf_vec<CPL>(xn, p, en);  // e(t+1, n): independent work under the LDS latency
+      log_plus_finish<CPL>(L, fEn);
       if (POST) {
         double LPM[CPL], LPE[CPL], vMn[CPL], vEn[CPL], alt[CPL];
         uint64_t bj[CPL];
@@ -380,7 +477,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
           vM[j] = vMn[j];
           vE[j] = vEn[j];
           bcur[j] = bnext[j];
-          bnext[j] = bnn[j];
         }
       }
 #pragma unroll
@@ -716,9 +812,9 @@ void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const
   if (n_reads <= 0) return;
   const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
   if (post)
-    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, ws, bits, st, m1, e2, sp_tab, n_reads);
+    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, (const double*)ws, reinterpret_cast<float2*>(ws), bits, st, m1, e2, sp_tab, n_reads);
   else
-    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, ws, bits, st, m1, e2, sp_tab, n_reads);
+    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, (const double*)ws, reinterpret_cast<float2*>(ws), bits, st, m1, e2, sp_tab, n_reads);
 }
 
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
