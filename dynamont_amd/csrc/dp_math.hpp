@@ -384,6 +384,46 @@ DYN_HD void log_plus_vec(const double (&x)[M], const double (&y)[M], double (&ou
   for (int j = 0; j < M; ++j) out[j] = hi[j] + g[j];
 }
 
+// exp(d) for M independent arguments, d clamped to [-1000, 700] (posterior exponents are <= ~0).
+// Same reduction and degree-9 kernel as exp_nonpos above, written stage-by-stage across cells.
+template <int M>
+DYN_HD void exp_vec(double (&d)[M], double (&out)[M]) {
+  const double LOG2E = 0x1.71547652b82fep+0;
+  const double LN2_HI = 0x1.62e42fee00000p-1;
+  const double LN2_LO = 0x1.a39ef35793c76p-33;
+  double kf[M], r[M], q[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(__builtin_fmax(d[j], -1000.0), 700.0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * LOG2E);
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_HI, d[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_LO, r[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(0x1.af390ba7e6f47p-26, r[j], 0x1.2891d4ffbb0f9p-22);
+#define DYN_STEP(c) _Pragma("unroll") for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], c);
+  DYN_STEP(0x1.71de0d85293b8p-19)
+  DYN_STEP(0x1.a019b8ca26fcfp-16)
+  DYN_STEP(0x1.a01a01a7cebcdp-13)
+  DYN_STEP(0x1.6c16c1789d1d7p-10)
+  DYN_STEP(0x1.11111111109a6p-7)
+  DYN_STEP(0x1.5555555553d37p-5)
+  DYN_STEP(0x1.5555555555556p-3)
+  DYN_STEP(0x1.0000000000001p-1)
+#undef DYN_STEP
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(r[j] * r[j], q[j], r[j]) + 1.0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    out[j] = __builtin_amdgcn_ldexp(q[j], (int)kf[j]);
+#else
+    out[j] = std::ldexp(q[j], (int)kf[j]);
+#endif
+  }
+}
+
 // Structure-of-arrays emission constants of the M cells of a lane.
 template <int M>
 struct EmisV {

@@ -668,7 +668,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  const double* __restrict__ lat = ws + rd.ws_off;
+  const double* __restrict__ lat = ws + rd.ws_off + lane;
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
@@ -679,21 +679,21 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   int n[CPL];
   double fM[CPL], fE[CPL], e[CPL], bcur[CPL], bnext[CPL];
   double aw[CPL], a1[CPL], a2[CPL];
-  Emis p[CPL];
+  EmisV<CPL> p;
   double sumM = 0.0, sumE2 = 0.0;
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int slot = j * 64 + lane;
     n[j] = lo + pmod(slot - lo);
-    p[j] = load_emis(pr, n[j], N);
+    p.set(j, load_emis(pr, n[j], N));
     fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
     fM[j] = NEG_INF;
-    e[j] = log_normal_pdf(x0, p[j]);
-    bcur[j] = lat[(size_t)1 * P + slot];
-    bnext[j] = (T > 2) ? lat[(size_t)2 * P + slot] : NEG_INF;
+    bcur[j] = lat[(size_t)1 * P + j * 64];
+    bnext[j] = (T > 2) ? lat[(size_t)2 * P + j * 64] : NEG_INF;
     aw[j] = a1[j] = a2[j] = 0.0;
   }
+  log_normal_pdf_vec<CPL>(x0, p, e);
 
   double xcur = x0;  // sample of row t
   for (int tb0 = 1; tb0 < T; tb0 += 64) {
@@ -708,10 +708,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
       from_left(fE, fEl, m0);
       const bool have = (t + 2 < T);
 #pragma unroll
-      for (int j = 0; j < CPL; ++j)
-        bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64 + lane] : NEG_INF;
+      for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {
+        const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == lo) {
@@ -722,37 +722,49 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
             }
             aw[j] = a1[j] = a2[j] = 0.0;
             n[j] = lo + P;
-            p[j] = load_emis(pr, lo + P, N);
+            p.set(j, fresh);
+            fM[j] = NEG_INF;
+            fE[j] = NEG_INF;
+            e[j] = NEG_INF;
           }
         }
         lo = new_lo;
       }
-      const int lo_n = max(lo, 1);
-      const int hi_n = min(lo + W - 1, N - 1);
+      const int hi_n = lo + W - 1;
+      double x1[CPL], op2[CPL], fMn[CPL], fEn[CPL], en[CPL], aM[CPL], aE[CPL], aT[CPL], gM[CPL], gE[CPL], gT[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) fEl[j] = (n[j] <= hi_n) ? fEl[j] : NEG_INF;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) x1[j] = fM[j] + e[j];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) op2[j] = (fE[j] + e[j]) + e2;
+      SoftplusLookup<CPL> L;
+      log_plus_issue<CPL>(x1, op2, L, s_tab);
+      log_normal_pdf_vec<CPL>(xn, p, en);
+      log_plus_finish<CPL>(L, fEn);
+      // posteriors: state M, state E, and the E->E transition into (t,n)  (see header comment)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) aM[j] = (fMn[j] + (bnext[j] + en[j])) - Z;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) aE[j] = (fEn[j] + bcur[j]) - Z;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) aT[j] = (op2[j] + bcur[j]) - Z;
+      dynmath::exp_vec<CPL>(aM, gM);
+      dynmath::exp_vec<CPL>(aE, gE);
+      dynmath::exp_vec<CPL>(aT, gT);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        const int nn = n[j];
-        const bool valid = (nn >= lo_n) && (nn <= hi_n);
-        const double ee = e[j];
-        double fMn = (fEl[j] + ee) + m1;
-        const double op2 = (fE[j] + ee) + e2;
-        double fEn = log_plus(fM[j] + ee, op2);
-        fMn = valid ? fMn : NEG_INF;
-        fEn = valid ? fEn : NEG_INF;
-        const double en = log_normal_pdf(xn, p[j]);
-        const double bMt = bnext[j] + en;
-        const double gM = valid ? exp((fMn + bMt) - Z) : 0.0;
-        const double gE = valid ? exp((fEn + bcur[j]) - Z) : 0.0;
-        const double gT = valid ? exp((op2 + bcur[j]) - Z) : 0.0;
-        const double g = gM + gE;
+        const double g = gM[j] + gE[j];
         aw[j] += g;
         a1[j] += g * xcur;
         a2[j] += g * xcur * xcur;
-        sumM += gM;
-        sumE2 += gT;
-        fM[j] = fMn;
-        fE[j] = fEn;
-        e[j] = en;
+        sumM += gM[j];
+        sumE2 += gT[j];
+        fM[j] = fMn[j];
+        fE[j] = fEn[j];
+        e[j] = en[j];
         bcur[j] = bnext[j];
         bnext[j] = bnn[j];
       }
@@ -761,7 +773,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   }
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    if (n[j] >= 1 && n[j] < N && n[j] >= lo) {
+    if (n[j] >= 1 && n[j] < N) {
       cw[n[j] - 1] = aw[j];
       cs1[n[j] - 1] = a1[j];
       cs2[n[j] - 1] = a2[j];
