@@ -101,9 +101,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: dynamont_amd has no CPU compute path")
+    # Rehearsal hooks (CPU-side control-flow checks on a 1-GPU box; never set by the driver):
+    #   DYN_BENCH_BACKEND=gloo   use gloo instead of nccl/RCCL
+    #   DYN_BENCH_ONE_DEVICE=1   every rank uses cuda:0
+    backend = os.environ.get("DYN_BENCH_BACKEND", "nccl")
+    if os.environ.get("DYN_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if n_gpus > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from dynamont_amd import Aligner
 
@@ -138,7 +147,11 @@ def main():
                 rows_t = wrap_rows()
                 if rank == 0:
                     gather_buf = [torch.empty_like(rows_t) for _ in range(n_gpus)]
-            dist.gather(rows_t, gather_buf if rank == 0 else None, dst=0)
+            if backend == "nccl":
+                dist.gather(rows_t, gather_buf if rank == 0 else None, dst=0)   # RCCL over xGMI, device to device
+            else:  # gloo rehearsal: host hop
+                h = rows_t.cpu()
+                dist.gather(h, [torch.empty_like(h) for _ in range(n_gpus)] if rank == 0 else None, dst=0)
 
     def sync():
         if n_gpus > 1:
@@ -158,10 +171,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if n_gpus > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_samples, len(reads)], device=f"cuda:{local_rank}", dtype=torch.float64)
+        tot = torch.tensor([n_samples, len(reads)], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_samples, total_reads = float(tot[0].item()), float(tot[1].item())
     else:

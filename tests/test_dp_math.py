@@ -13,9 +13,39 @@ from oracle import pyoracle
 
 SRC = r'''
 #include "%s/dynamont_amd/csrc/dp_math.hpp"
+#include <vector>
 extern "C" {
 void eval_softplus(const double* d, double* out, long n) { for (long i = 0; i < n; ++i) out[i] = dynmath::softplus_nonpos(d[i]); }
 void eval_logplus(const double* x, const double* y, double* out, long n) { for (long i = 0; i < n; ++i) out[i] = dynmath::log_plus(x[i], y[i]); }
+static std::vector<dynmath::SoftplusNode> TAB;
+void init_table() { TAB.resize(dynmath::SP_NODES); dynmath::softplus_build_table(TAB.data()); }
+// the product path: table-driven logPlus in its two-phase, 7-cells-at-a-time form
+void eval_logplus_table(const double* x, const double* y, double* out, long n) {
+  for (long i = 0; i + 7 <= n; i += 7) {
+    double a[7], b[7], o[7];
+    for (int j = 0; j < 7; ++j) { a[j] = x[i + j]; b[j] = y[i + j]; }
+    dynmath::SoftplusLookup<7> L;
+    dynmath::log_plus_issue<7>(a, b, L, TAB.data());
+    dynmath::log_plus_finish<7>(L, o);
+    for (int j = 0; j < 7; ++j) out[i + j] = o[j];
+  }
+}
+void eval_softplus_table(const double* d, double* out, long n) {
+  for (long i = 0; i + 7 <= n; i += 7) {
+    double a[7], g[7];
+    for (int j = 0; j < 7; ++j) a[j] = d[i + j];
+    dynmath::softplus_table_vec<7>(a, g, TAB.data());
+    for (int j = 0; j < 7; ++j) out[i + j] = g[j];
+  }
+}
+void eval_exp_vec(const double* d, double* out, long n) {
+  for (long i = 0; i + 7 <= n; i += 7) {
+    double a[7], g[7];
+    for (int j = 0; j < 7; ++j) a[j] = d[i + j];
+    dynmath::exp_vec<7>(a, g);
+    for (int j = 0; j < 7; ++j) out[i + j] = g[j];
+  }
+}
 void eval_pdf(const double* x, const double* mean, const double* sd, double* out, long n) {
   for (long i = 0; i < n; ++i) { dynmath::Emis p{mean[i], sd[i], 1.0 / sd[i], std::log(sd[i])}; out[i] = dynmath::log_normal_pdf(x[i], p); } }
 }
@@ -31,7 +61,9 @@ def mathlib(tmp_path_factory):
     src.write_text(SRC)
     so = d / "libt.so"
     subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
-    return C.CDLL(str(so))
+    lib = C.CDLL(str(so))
+    lib.init_table()
+    return lib
 
 
 def test_softplus_accuracy(mathlib):
@@ -85,3 +117,56 @@ def test_log_normal_pdf_bit_identical(mathlib, oracle_built):
     mathlib.eval_pdf(x.ctypes.data_as(dp), mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(n))
     ref = np.array([L.nto_log_normal_pdf(a, b, c) for a, b, c in zip(x, mean, sd)])
     assert np.array_equal(out, ref)
+
+
+def _grid7(rng):
+    d = np.concatenate([-np.abs(rng.standard_normal(1400)) * 3, -rng.uniform(0, 45, 1400),
+                        -10.0 ** rng.uniform(-12, 2.9, 1393), [0.0, -1 / 256, -1 / 128, -39.999, -40.0, -40.01, -1e9]])
+    return d[: len(d) // 7 * 7].copy()
+
+
+def test_table_softplus_accuracy(mathlib):
+    """The form the kernels run: (g, sigma) nodes every 1/128 + degree-5 Taylor about the nearest node."""
+    d = _grid7(np.random.default_rng(3))
+    out = np.empty_like(d)
+    mathlib.eval_softplus_table(d.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(d)))
+    mp.mp.dps = 40
+    worst = max(abs(mp.mpf(float(y)) - mp.log1p(mp.exp(mp.mpf(float(x))))) for x, y in zip(d, out))
+    assert worst < 1.5e-16, worst
+    assert out[-1] == 0.0 and out[-2] == 0.0     # d <= -40 -> exactly 0
+
+
+def test_table_logplus_special_values_and_oracle(mathlib, oracle_built):
+    inf = np.inf
+    x = np.array([-inf, 3.0, -inf, -5.0, 1e4, -2000.0, 0.25])
+    y = np.array([-inf, -inf, -7.5, -5.0, 1e4 - 800.0, 2000.0, 0.25])
+    out = np.empty_like(x)
+    mathlib.eval_logplus_table(x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(7))
+    assert out[0] == -inf and out[1] == 3.0 and out[2] == -7.5 and out[4] == 1e4 and out[5] == 2000.0
+    assert abs(out[3] - (-5.0 + np.log(2.0))) < 1e-15
+    L = C.CDLL(pyoracle.ORACLE_SO)
+    L.nto_log_plus.restype = C.c_double
+    L.nto_log_plus.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(4)
+    a = rng.uniform(-5000, 100, 7000)
+    b = a + rng.uniform(-60, 60, 7000)
+    o = np.empty_like(a)
+    mathlib.eval_logplus_table(a.ctypes.data_as(dp), b.ctypes.data_as(dp), o.ctypes.data_as(dp), C.c_long(len(a)))
+    ref = np.array([L.nto_log_plus(p, q) for p, q in zip(a, b)])
+    assert np.abs(o - ref).max() <= 2 * np.spacing(np.abs(ref)).max()
+    assert np.mean(o == ref) > 0.95
+
+
+def test_exp_vec_accuracy(mathlib):
+    rng = np.random.default_rng(5)
+    d = np.concatenate([-rng.uniform(0, 60, 3500), rng.uniform(-1e-9, 1e-9, 700), rng.uniform(0, 5, 693), [0.0, -745.0, -999.0, -1e9, 1e-300, -1e-300, -0.5]])
+    d = d[: len(d) // 7 * 7].copy()
+    out = np.empty_like(d)
+    mathlib.eval_exp_vec(d.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(d)))
+    mp.mp.dps = 40
+    worst = 0.0
+    for x, y in zip(d, out):
+        t = mp.exp(mp.mpf(float(max(x, -1000.0))))
+        if t > mp.mpf(10) ** -300:
+            worst = max(worst, float(abs(mp.mpf(float(y)) - t) / t))
+    assert worst < 3e-16, worst
