@@ -546,9 +546,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   uint32_t* __restrict__ pathn = tb.pathn + rd.path_off;
   uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
 
+  // Segment-at-a-time walk. Lane i owns row base+i of the current 64-row block. While the path
+  // stays in column n every row's decision is bit(row, slot(n)), which all 64 lanes test at once;
+  // the highest row <= t whose bit is set is where the path turns (E with bit 1 -> M one row
+  // below -> E in column n-1 two rows below), found with one ballot + find-first-set. A block
+  // costs one step per segment that crosses it (~6) instead of one per row (64).
   int t = T - 1, n = N - 1;
   int slot = n % P;
-  int stM = 0;
+  int stM = 0;  // the cell at row t is an M cell (carried across blocks)
   while (t > 0 && n > 0) {
     const int base = t - 63;
     const int row = base + lane;
@@ -558,25 +563,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     __syncthreads();
     int my_n = 0, my_slot = 0, my_st = -1;
-    for (int i = 63; i >= 0; --i) {
-      if (t == 0 || n == 0) break;
-      if (lane == i) {
-        my_n = n;
-        my_slot = slot;
-        my_st = stM;
-      }
-      if (stM) {  // M(t,n) -> E(t-1,n-1)
+    const int block_lo = base < 1 ? 1 : base;  // lowest row of this block that exists
+    while (t >= block_lo && n > 0) {
+      if (stM) {  // M(t,n): segment start; continue with E(t-1, n-1)
+        if (row == t) {
+          my_n = n;
+          my_slot = slot;
+          my_st = 1;
+        }
         --n;
         slot = slot ? slot - 1 : P - 1;
         stM = 0;
-      } else {    // E(t,n) -> M or E at (t-1,n)
-        const uint64_t w = sb[i * CPL + (slot >> 6)];
-        const uint32_t wl = __builtin_amdgcn_readfirstlane((uint32_t)w);
-        const uint32_t wh = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
-        const int sh = slot & 63;
-        stM = (sh < 32 ? (wl >> sh) : (wh >> (sh - 32))) & 1;
+        --t;
+        continue;
       }
-      --t;
+      // state E in column n at row t: every lane tests its own row for this column
+      const uint64_t w = sb[lane * CPL + (slot >> 6)];
+      const bool bit = (row >= block_lo) && (row <= t) && ((w >> (slot & 63)) & 1);
+      const uint64_t m = __ballot(bit);
+      const int r = m ? base + (63 - __builtin_clzll(m)) : block_lo - 1;  // highest turning row, or none
+      const int e_lo = m ? r : block_lo;  // rows e_lo..t are E cells of column n
+      if (row >= e_lo && row <= t) {
+        my_n = n;
+        my_slot = slot;
+        my_st = 0;
+      }
+      if (m) {
+        t = r - 1;  // M cell of column n (may lie in the next block: stM carries over)
+        stM = 1;
+      } else {
+        t = block_lo - 1;
+      }
     }
     if (my_st >= 0) {
       const float2 v = lp[(size_t)row * P + my_slot];
