@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.environ.get("DYN_LIB") or os.path.join(HERE, "libdynamont_mi.so")  # DYN_LIB: diagnostic builds only
+LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
 SOURCES = ["dynamont_mi.cpp", "pore_model.cpp", "nt_kernels.hip"]
 HEADERS = ["nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
 

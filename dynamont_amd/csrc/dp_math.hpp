@@ -142,90 +142,7 @@ DYN_HD double log_normal_pdf(double x, const Emis& p) {
 // interleaved in program order. A single wave then issues back-to-back fp64 instructions
 // (measured: ~4.8 cycles/instr at 8 independent chains vs 8.6 cycles for one dependent chain,
 // tools/ubench/issue_rate.hip) instead of M serial Horner chains.
-// The operations per cell are exactly those of the scalar functions above.
 // ---------------------------------------------------------------------------------------------
-template <int M>
-DYN_HD void softplus_nonpos_vec(double (&d)[M], double (&g)[M]) {
-  const double LOG2E = 0x1.71547652b82fep+0;
-  const double LN2_HI = 0x1.62e42fee00000p-1;
-  const double LN2_LO = 0x1.a39ef35793c76p-33;
-  const double SQRT2M1 = 0x1.a827999fcef32p-2;
-  const double LN2 = 0x1.62e42fefa39efp-1;
-  double kf[M], r[M], q[M], e[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -1000.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * LOG2E);
-#pragma unroll
-  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_HI, d[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_LO, r[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(0x1.af390ba7e6f47p-26, r[j], 0x1.2891d4ffbb0f9p-22);
-#define DYN_STEP(c)                \
-  _Pragma("unroll") for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], c);
-  DYN_STEP(0x1.71de0d85293b8p-19)
-  DYN_STEP(0x1.a019b8ca26fcfp-16)
-  DYN_STEP(0x1.a01a01a7cebcdp-13)
-  DYN_STEP(0x1.6c16c1789d1d7p-10)
-  DYN_STEP(0x1.11111111109a6p-7)
-  DYN_STEP(0x1.5555555553d37p-5)
-  DYN_STEP(0x1.5555555555556p-3)
-  DYN_STEP(0x1.0000000000001p-1)
-#undef DYN_STEP
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(r[j] * r[j], q[j], r[j]) + 1.0;
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    e[j] = __builtin_amdgcn_ldexp(q[j], (int)kf[j]);
-#else
-    e[j] = std::ldexp(q[j], (int)kf[j]);
-#endif
-  }
-  // log1p(e): c = 1 on the upper branch (e > sqrt2-1), 0 otherwise
-  double c[M], num[M], den[M], rc[M], t[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) c[j] = (e[j] > SQRT2M1) ? 1.0 : 0.0;
-#pragma unroll
-  for (int j = 0; j < M; ++j) num[j] = e[j] - c[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) den[j] = (e[j] + 2.0) + c[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) rc[j] = rcp_seed(den[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) t[j] = fma_(-den[j], rc[j], 1.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) rc[j] = fma_(rc[j], t[j], rc[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) t[j] = fma_(-den[j], rc[j], 1.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) rc[j] = fma_(rc[j], t[j], rc[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) t[j] = num[j] * rc[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) num[j] = fma_(-den[j], t[j], num[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) t[j] = fma_(num[j], rc[j], t[j]);  // t = num/den
-  double s[M], f[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) s[j] = t[j] * t[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) f[j] = fma_(0x1.2b6686d1072f3p-4, s[j], 0x1.39fd39474ad34p-4);
-#define DYN_STEP(cc)               \
-  _Pragma("unroll") for (int j = 0; j < M; ++j) f[j] = fma_(f[j], s[j], cc);
-  DYN_STEP(0x1.7462bd8e53c17p-4)
-  DYN_STEP(0x1.c71c62c63e016p-4)
-  DYN_STEP(0x1.2492492e09d1ap-3)
-  DYN_STEP(0x1.9999999995204p-3)
-  DYN_STEP(0x1.5555555555558p-2)
-#undef DYN_STEP
-#pragma unroll
-  for (int j = 0; j < M; ++j) f[j] = fma_(t[j] * s[j], f[j], t[j]);  // atanh(t)
-#pragma unroll
-  for (int j = 0; j < M; ++j) g[j] = fma_(c[j], LN2, f[j] + f[j]);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Table-driven softplus. g(d) = log1p(exp(d)) satisfies g1 = s (the logistic function) and every
 // higher derivative is a polynomial in s:  with u = s(1-s), w = 1-2s
@@ -296,20 +213,6 @@ DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNod
   for (int j = 0; j < M; ++j) g[j] = fma_(p[j], r[j], g0[j]);
 }
 
-// out[j] = logPlus(x[j], y[j]) with the table-driven softplus
-template <int M>
-DYN_HD void log_plus_table_vec(const double (&x)[M], const double (&y)[M], double (&out)[M],
-                               const SoftplusNode* __restrict__ tab) {
-  double hi[M], d[M], g[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) hi[j] = __builtin_fmax(x[j], y[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(x[j], y[j]) - hi[j];
-  softplus_table_vec<M>(d, g, tab);
-#pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = hi[j] + g[j];
-}
-
 // Two-phase form of the table-driven logPlus so that independent work (the next row's emission)
 // can be placed between issuing the LDS lookups and consuming them:
 //   SoftplusLookup<M> L;  log_plus_issue(x, y, L, tab);   ...independent code...   log_plus_finish(L, out);
@@ -369,19 +272,6 @@ DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
   for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.s[j]);
 #pragma unroll
   for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
-}
-
-// out[j] = logPlus(x[j], y[j])
-template <int M>
-DYN_HD void log_plus_vec(const double (&x)[M], const double (&y)[M], double (&out)[M]) {
-  double hi[M], d[M], g[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) hi[j] = __builtin_fmax(x[j], y[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(x[j], y[j]) - hi[j];
-  softplus_nonpos_vec<M>(d, g);
-#pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = hi[j] + g[j];
 }
 
 // exp(d) for M independent arguments, d clamped to [-1000, 700] (posterior exponents are <= ~0).

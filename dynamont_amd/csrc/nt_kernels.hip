@@ -45,12 +45,8 @@
 namespace dynk {
 
 using dynmath::NEG_INF;
-using dynmath::log_normal_pdf;
-using dynmath::log_plus;
 using dynmath::EmisV;
 using dynmath::log_normal_pdf_vec;
-using dynmath::log_plus_vec;
-using dynmath::log_plus_table_vec;
 using dynmath::SoftplusNode;
 using dynmath::SoftplusLookup;
 using dynmath::log_plus_issue;

@@ -227,3 +227,37 @@ def test_train_batch_against_oracle_and_pooled_stats(models, al9):
         pooled[K:2 * K] += want["sum"]
         pooled[2 * K:] += want["sumsq"]
     assert np.allclose(res.pooled, pooled, rtol=1e-9, atol=1e-9)
+
+
+def test_traceback_segments_spanning_many_64_row_blocks(models):
+    """k_trace walks 64 rows at a time and jumps a segment per step: exercise dwell times from the
+    minimum (2 samples) to stalls of several hundred samples, turning points on block boundaries,
+    and M cells that fall into the next block."""
+    pore = "dna_r9"
+    path = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(path)
+    mean_c, sd_c = synth.code_order_table(mean, sd, 5, False)
+    rng = np.random.default_rng(2024)
+    sigs, seqs = [], []
+    for rep in range(10):
+        nb = int(rng.integers(20, 160))
+        digits = rng.integers(0, 4, size=nb)
+        codes = synth._seq_codes(digits, 5)
+        dwell = rng.choice([2, 2, 3, 5, 9, 63, 64, 65, 127, 128, 129, 300, 700], size=len(codes))
+        if rep == 0:
+            dwell[:] = 64      # every turning point on a block boundary
+        if rep == 1:
+            dwell[:] = 2       # S == 2*Kc
+        idx = np.repeat(codes, dwell)
+        sigs.append(mean_c[idx] + 0.9 * sd_c[idx] * rng.standard_normal(len(idx)))
+        seqs.append("".join("ACGT"[d] for d in digits))
+    al = Aligner(path, pore, device=0)
+    orc = Oracle(path, synth.PORES[pore][0])
+    res = al.align_batch(sigs, seqs, True)
+    for i in range(len(sigs)):
+        want = orc.align(sigs[i], seqs[i], True)
+        got = res.read(i)
+        assert np.array_equal(got["signal_positions"], want["signal_positions"])
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
