@@ -140,6 +140,17 @@ def main():
         nonlocal gather_buf, rows_t
         if args.mode == "train":
             batch.train()
+            if n_gpus > 1:  # config 5: sum all-reduce of the pooled sufficient statistics (3 * 4^k doubles)
+                ptr, cnt = batch.device_pooled()
+
+                class _Pooled:
+                    __cuda_array_interface__ = {"shape": (cnt,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+                pooled_t = torch.as_tensor(_Pooled(), device=f"cuda:{local_rank}")
+                if backend == "nccl":
+                    dist.all_reduce(pooled_t, op=dist.ReduceOp.SUM)
+                else:
+                    h = pooled_t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
             return
         batch.align(True)
         if n_gpus > 1:

@@ -447,6 +447,8 @@ int run_job(dyn_batch* b, Job job) {
     HIP_TRY(a, b->d_cols1.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_cols2.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_trans.ensure(std::max<uint64_t>(16, b->n * 16)));
+    HIP_TRY(a, b->d_pooled.ensure(3 * m.num_kmers * 8));
+    HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->stream));
   }
 
   // HBM budget for lattice workspaces
@@ -549,6 +551,10 @@ int run_job(dyn_batch* b, Job job) {
                          b->d_rows.as<SegRow>(), m.k, z_fail, a->stream);
     } else {
       dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
+      if (job == Job::Train) {
+        dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
+        dynk::launch_pool_stats(dd, nr, max_N, dst, b->d_kmers.as<int32_t>(), tb, b->d_pooled.as<double>(), m.num_kmers, a->stream);
+      }
     }
     HIP_TRY(a, hipEventRecord(ev[3], a->stream));
     HIP_TRY(a, hipGetLastError());
@@ -765,24 +771,9 @@ int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
 
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
   if (!b || !b->trained) return DYN_ERR_INVALID_ARGUMENT;
-  dyn_aligner* a = b->a;
-  int rc = need_device(a);
-  if (rc != DYN_OK) return rc;
-  // pooled statistics are produced on the host path of dyn_batch_fetch_train; the device copy
-  // is materialised on demand so an RCCL all-reduce can run on it in place
-  const uint64_t K = a->model.num_kmers;
-  std::vector<double> pooled(3 * K, 0.0);
-  std::vector<int32_t> status(b->n);
-  std::vector<double> Z(b->n);
-  dyn_train_out tmp{};
-  tmp.Z = Z.data();
-  tmp.status = status.data();
-  rc = dyn_batch_fetch_train(b, &tmp, pooled.data());
-  if (rc != DYN_OK) return rc;
-  HIP_TRY(a, b->d_pooled.ensure(3 * K * 8));
-  HIP_TRY(a, hipMemcpy(b->d_pooled.p, pooled.data(), 3 * K * 8, hipMemcpyHostToDevice));
+  // filled on the device by k_pool_stats during dyn_batch_train (run_job)
   if (d_pooled3n) *d_pooled3n = b->d_pooled.p;
-  if (count) *count = 3 * K;
+  if (count) *count = 3 * b->a->model.num_kmers;
   return DYN_OK;
 }
 

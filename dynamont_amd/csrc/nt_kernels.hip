@@ -809,6 +809,30 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pooled sufficient statistics for the multi-GPU M-step (BASELINE.json config 5): every lattice
+// column of every successfully trained read adds its (w, s1, s2) to its k-mer's bins. One fp64
+// atomic per statistic per column; ~2 000 columns per read spread over 4^k bins, so contention
+// is negligible. (The per-read results of dyn_batch_fetch_train are summed on the host in column
+// order instead and are bitwise reproducible; this pooled form is for the all-reduce.)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pool_stats(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                             const int32_t* __restrict__ kmers, TrainBuffers tb,
+                             double* __restrict__ pooled, uint64_t num_kmers) {
+  const ReadDesc rd = descs[blockIdx.y];
+  if (st[rd.read].status != 0) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // column index - 1
+  if (c >= (int)rd.N - 1) return;
+  const uint64_t i = rd.par_off + c;
+  const int32_t code = kmers[i];
+  const double w = tb.col_w[i];
+  if (w > 0.0) {
+    atomicAdd(&pooled[code], w);
+    atomicAdd(&pooled[num_kmers + code], tb.col_s1[i]);
+    atomicAdd(&pooled[2 * num_kmers + code], tb.col_s2[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
@@ -848,6 +872,14 @@ void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig,
   if (n_reads <= 0) return;
   const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
   hipLaunchKernelGGL(k_forward_train, grid, block, 0, s, descs, sig, par, ws, st, tb, m1, e2, sp_tab, n_reads);
+}
+
+void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
+                       const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,
+                       hipStream_t s) {
+  if (n_reads <= 0) return;
+  hipLaunchKernelGGL(k_pool_stats, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, kmers, tb,
+                     pooled, num_kmers);
 }
 
 void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,

@@ -80,5 +80,9 @@ void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t m
                   SegRow* rows, int kmer_size, int z_fail_status, hipStream_t s);
 void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,
                    hipStream_t s);
+// pooled[3*num_kmers] += per-k-mer (w, s1, s2) of the reads in descs (fp64 atomics)
+void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
+                       const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,
+                       hipStream_t s);
 
 }  // namespace dynk

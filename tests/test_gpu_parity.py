@@ -227,6 +227,18 @@ def test_train_batch_against_oracle_and_pooled_stats(models, al9):
         pooled[K:2 * K] += want["sum"]
         pooled[2 * K:] += want["sumsq"]
     assert np.allclose(res.pooled, pooled, rtol=1e-9, atol=1e-9)
+    # the device-resident pooled statistics (what a multi-GPU job all-reduces) agree with the host sum.
+    # Read back with the HIP runtime this process already loaded (no torch here: a PyTorch wheel
+    # bundles its own libamdhip64 and must be imported BEFORE dynamont_amd if both are used).
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    with al9.batch([r.signal for r in reads], [r.sequence for r in reads]) as b:
+        b.train()
+        ptr, cnt = b.device_pooled()
+        dev = np.empty(cnt)
+        rc = hip.hipMemcpy(ctypes.c_void_p(dev.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(cnt * 8), 2)  # D2H
+        assert rc == 0
+    assert cnt == 3 * K and np.allclose(dev, pooled, rtol=1e-9, atol=1e-9)
 
 
 def test_traceback_segments_spanning_many_64_row_blocks(models):
