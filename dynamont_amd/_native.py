@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "pore_model.cpp", "nt_kernels.hip"]
+SOURCES = ["dynamont_mi.cpp", "pore_model.cpp", "csv_format.cpp", "nt_kernels.hip"]
 HEADERS = ["nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
@@ -68,6 +68,11 @@ SIGNATURES = {
                                   C.POINTER(DynAlignOut)]),
     "dyn_train_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                   C.POINTER(DynTrainOut), c_double_p]),
+    "dyn_format_csv_bound": (C.c_uint64, [C.c_void_p, C.c_uint64, C.POINTER(DynAlignOut), C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_char_p)]),
+    "dyn_format_csv": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(DynAlignOut), C.c_char_p, c_u64_p,
+                                 C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_uint64, c_u64_p, c_u64_p]),
     "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                    C.POINTER(C.c_void_p)]),
     "dyn_batch_destroy": (None, [C.c_void_p]),
@@ -101,7 +106,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wno-unused-result", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

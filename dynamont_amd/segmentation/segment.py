@@ -31,6 +31,7 @@ POLYA = "AAAAAAAAA"
 
 RAW_CACHE: OrderedDict | None = None
 RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
+ZSTD_WORKERS = 4    # libzstd worker threads of the writer (single frame, level 3 as the reference)
 
 
 def parse(argv=None) -> Namespace:
@@ -58,7 +59,7 @@ def listener(q, outfile: str) -> None:
     errfile = splitext(splitext(outfile)[0])[0] + ".errors"
     num_err = 0
     with open(outfile, "wb") as raw:
-        with ZstdWriter(raw, level=3) as output:
+        with ZstdWriter(raw, level=3, workers=ZSTD_WORKERS) as output:
             output.write(CSV_HEADER)
             while True:
                 result = q.get()
@@ -140,17 +141,24 @@ def prepare_job(job, is_rna: bool):
     return signal, read
 
 
-def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int) -> None:
-    """Align one batch and queue CSV bytes / error lines exactly as segment.py:160-176."""
+def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: int = 8) -> None:
+    """Align one batch and queue CSV bytes / error lines exactly as segment.py:160-176. The rows are
+    formatted by the native dyn_format_csv (same bytes as utils.segmentation_to_string; Python row
+    formatting would be ~50x slower than the GPU)."""
     if not pending:
         return
-    res = aligner.align_batch([p[0] for p in pending], [p[1] for p in pending], calc_probabilities=True)
+    from dynamont_amd._dynamont import format_csv
+    signals, reads = [p[0] for p in pending], [p[1] for p in pending]
+    res = aligner.align_batch(signals, reads, calc_probabilities=True)
+    starts = [p[2][3] for p in pending]
+    buf, begin, end = format_csv(aligner, res, reads, [p[2][6] for p in pending], [p[2][7] for p in pending], starts,
+                                 [len(sig) + st for sig, st in zip(signals, starts)], threads=threads)
     for i, (signal, read, job) in enumerate(pending):
-        _, _, _, start, _, _, readid, signalid = job
         if res.status[i] != 0:
+            _, _, _, _, _, _, readid, signalid = job
             q.put(f"error: native, {res.error(i)}\tT: {len(signal)}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
-            continue
-        q.put(segmentation_to_string(res.read(i), readid, signalid, start, len(signal) + start, read, kmer_size, is_rna))
+        else:
+            q.put(buf[int(begin[i]):int(end[i])].tobytes())
 
 
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,

@@ -21,6 +21,7 @@ class _OutBuf(C.Structure):
 
 
 _ZSTD_c_compressionLevel = 100
+_ZSTD_c_nbWorkers = 400
 _ZSTD_e_continue, _ZSTD_e_flush, _ZSTD_e_end = 0, 1, 2
 _lib = None
 
@@ -53,16 +54,20 @@ def _libzstd():
 class ZstdWriter:
     """File-like ``write(bytes)`` / ``close()`` producing one zstd frame at the given level."""
 
-    def __init__(self, raw, level: int = 3):
+    def __init__(self, raw, level: int = 3, workers: int = 0):
         self._raw = raw
         self._backend = None
         if _zstandard is not None:
-            self._backend = _zstandard.ZstdCompressor(level=level).stream_writer(raw, closefd=False)
+            self._backend = _zstandard.ZstdCompressor(level=level, threads=workers).stream_writer(raw, closefd=False)
             return
         L = self._L = _libzstd()
         self._ctx = L.ZSTD_createCCtx()
         rc = L.ZSTD_CCtx_setParameter(self._ctx, _ZSTD_c_compressionLevel, level)
         self._check(rc)
+        if workers > 0:  # one frame, compressed by `workers` threads (no-op if libzstd lacks MT support)
+            rc = L.ZSTD_CCtx_setParameter(self._ctx, _ZSTD_c_nbWorkers, int(workers))
+            if L.ZSTD_isError(rc):
+                workers = 0
         self._cap = int(L.ZSTD_CStreamOutSize())
         self._out = C.create_string_buffer(self._cap)
 

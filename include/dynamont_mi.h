@@ -188,6 +188,21 @@ int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
                     const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
                     dyn_train_out* out, double* pooled3n);
 
+/* segmentation_to_string (src/dynamont/segmentation/utils.py:193-232) for a whole batch, multi-
+ * threaded on the host. `res` is a filled dyn_align_out; seqs/seq_offsets are the aligner-orientation
+ * sequences the batch was aligned with; sig_offsets[i] = sigOffset, last_index[i] = lastIndex of the
+ * reference call. Read i's rows are written to out[row_begin[i] .. row_end[i]) (each read formats
+ * into its own worst-case slot, so the byte ranges are not contiguous; failed reads get an empty
+ * range and the caller writes their .errors line). out_cap must be >= dyn_format_csv_bound().
+ * Bytes are identical to the reference's Python formatting, including f"{p:.6f}". */
+uint64_t dyn_format_csv_bound(const dyn_aligner* a, uint64_t n_reads, const dyn_align_out* res,
+                              const char* const* readids, const char* const* signalids);
+int dyn_format_csv(const dyn_aligner* a, uint64_t n_reads, const dyn_align_out* res,
+                   const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
+                   const char* const* signalids, const int64_t* sig_offsets,
+                   const int64_t* last_index, int threads, char* out, uint64_t out_cap,
+                   uint64_t* row_begin, uint64_t* row_end);
+
 /* ---- staged form: inputs resident in HBM before the timed region (bench.py, pipelining) ---- */
 
 /* Validate (aligner.cpp:145-164), k-mer-code (aligner.cpp:166-205), and upload one batch. */

@@ -188,3 +188,73 @@ def test_job_generation_and_preprocessing(models, tmp_path, pore):
     kept = list(seg.generate_jobs(str(tmp_path), bam, 12.0))
     assert len(kept) == sum(q >= 12.0 for q in qs)
     seg.close_raw_cache()
+
+
+def _batch_result_from_dicts(results):
+    """Pack per-read result dicts (oracle output) into the columnar AlignBatchResult of the C ABI."""
+    from dynamont_amd._dynamont import AlignBatchResult
+    n = len(results)
+    cap = sum(len(r["sequence_positions"]) for r in results if r is not None)
+    out = AlignBatchResult(n, max(cap, 1))
+    off = 0
+    for i, r in enumerate(results):
+        out.seg_offsets[i] = off
+        if r is None:
+            out.status[i] = 4
+            continue
+        k = len(r["sequence_positions"])
+        out.n_segments[i] = k
+        out.sequence_positions[off:off + k] = r["sequence_positions"]
+        out.signal_positions[off:off + k] = r["signal_positions"]
+        out.probabilities[off:off + k] = r["probabilities"]
+        out.states[off:off + k] = ord("M")
+        out.Z[i] = r["Z"]
+        off += k
+    out.seg_offsets[n] = off
+    return out
+
+
+def test_native_csv_formatter_matches_reference_bytes(models, oracle_built, native_lib):
+    """dyn_format_csv (C++) == the reference's segmentation_to_string bytes (golden G6), incl. a failed read."""
+    from dynamont_amd import Aligner
+    from dynamont_amd._dynamont import format_csv
+    g = golden("g6_harness.npz")
+    for i in range(int(g["n_csv"])):
+        p = f"csv{i}_"
+        pore = str(g[p + "pore"])
+        pid, rna, k = synth.PORES[pore]
+        seq = str(g[p + "sequence"])
+        res = Oracle(model_for(models, pore), pid).align(g[p + "signal"], seq, True)
+        start = int(g[p + "start"])
+        al = Aligner(model_for(models, pore), pore, device="host")
+        batch = _batch_result_from_dicts([res, None, res])
+        buf, begin, end = format_csv(al, batch, [seq, "ACGT", seq], [f"read-{i}", "bad", f"read-{i}"],
+                                     [f"sig-{i}", "bad", f"sig-{i}"], [start, 0, start],
+                                     [len(g[p + "signal"]) + start, 0, len(g[p + "signal"]) + start], threads=3)
+        want = g[p + "bytes"].tobytes()
+        assert buf[int(begin[0]):int(end[0])].tobytes() == want and buf[int(begin[2]):int(end[2])].tobytes() == want
+        assert begin[1] == end[1]
+
+
+def test_native_probability_formatting_equals_python(models, native_lib):
+    """f"{p:.6f}" for awkward doubles: ties, values next to ties, tiny, exactly 1, slightly above 1."""
+    from dynamont_amd import Aligner
+    from dynamont_amd._dynamont import format_csv
+    rng = np.random.default_rng(12)
+    base = np.concatenate([rng.uniform(0, 1, 20000), 10.0 ** rng.uniform(-12, 0, 5000),
+                           (rng.integers(0, 10 ** 6, 5000) + 0.5) / 1e6,                      # decimal ties
+                           np.nextafter((rng.integers(0, 10 ** 6, 3000) + 0.5) / 1e6, 0),
+                           np.nextafter((rng.integers(0, 10 ** 6, 3000) + 0.5) / 1e6, 1),
+                           [0.0, 1.0, 1.0000000000004, 0.9999995, 0.99999949999, 5e-7, 4.999999e-7, 1e-300, 0.5, 0.125]])
+    n = len(base)
+    al = Aligner(models["syn5"], "dna_r9", device="host")
+    seq = "ACGTACGTAC" * ((n + 20) // 10)
+    res = dict(Z=0.0, sequence_positions=np.arange(n, dtype=np.uint64) + 2, signal_positions=np.arange(n, dtype=np.uint64) * 3,
+               probabilities=base)
+    buf, begin, end = format_csv(al, _batch_result_from_dicts([res]), [seq], ["r"], ["s"], [7], [3 * n + 7], threads=1)
+    data = buf[int(begin[0]):int(end[0])].tobytes()
+    got = [line.split(",")[8] for line in data.decode().splitlines()]
+    assert got == [f"{float(p):.6f}" for p in base]
+    res["states"] = ["M"] * n
+    res["polishes"] = [""] * n
+    assert data == U.segmentation_to_string(res, "r", "s", 7, 3 * n + 7, seq, 5, False)
