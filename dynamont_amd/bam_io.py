@@ -1,0 +1,157 @@
+"""Vendor-free readers for basecalls in SAM text and BAM (BGZF) form -- SURVEY.md §8f N1.
+
+The reference reads basecalls through pysam (segment.py:222-256, train.py:121-153) and only needs
+the read name, the sequence and eight optional tags: qs, pi, ns, ts, sp, fn|f5, sm, sd. pysam/htslib
+are absent from the ROCm image, so the two container formats are parsed directly from the SAM
+specification (BAM: BGZF = concatenated gzip members; records little-endian). Unaligned dorado output
+(uBAM) is the expected input; alignment fields are skipped. ``write_bam``/``write_sam`` exist for
+tests and for producing synthetic datasets; they emit only what the readers consume.
+"""
+from __future__ import annotations
+
+import gzip
+import struct
+import zlib
+
+from dynamont_amd.pod5_io import BasecallRecord
+
+_SEQ_DECODE = "=ACMGRSVTWYHKDBN"
+_TAG_FMT = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+
+
+def _parse_sam_tag(field: str):
+    tag, typ, val = field.split(":", 2)
+    if typ == "i":
+        return tag, int(val)
+    if typ == "f":
+        return tag, float(val)
+    return tag, val  # Z, A, H, B kept as text
+
+
+def iter_sam(path: str):
+    """Records of a SAM text file (header lines start with '@')."""
+    with open(path) as f:
+        for line in f:
+            if not line or line[0] == "@":
+                continue
+            p = line.rstrip("\n").split("\t")
+            if len(p) < 11:
+                continue
+            tags = dict(_parse_sam_tag(x) for x in p[11:] if x.count(":") >= 2)
+            yield BasecallRecord(p[0], p[9], tags)
+
+
+def _bgzf_bytes(path: str) -> bytes:
+    # BGZF is a series of gzip members; Python's gzip module reads multi-member files
+    with gzip.open(path, "rb") as f:
+        return f.read()
+
+
+def iter_bam(path: str):
+    """Records of a BAM file (SAM spec §4): name, sequence and tags of every alignment record."""
+    data = _bgzf_bytes(path)
+    if data[:4] != b"BAM\x01":
+        raise ValueError(f"{path}: not a BAM file")
+    l_text, = struct.unpack_from("<i", data, 4)
+    pos = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, pos)
+    pos += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, pos)
+        pos += 4 + l_name + 4
+    n = len(data)
+    while pos + 4 <= n:
+        block_size, = struct.unpack_from("<i", data, pos)
+        pos += 4
+        end = pos + block_size
+        (_ref, _p, l_read_name, _mapq, _bin, n_cigar, _flag, l_seq, _nref, _npos, _tlen) = struct.unpack_from("<iiBBHHHiiii", data, pos)
+        q = pos + 32
+        name = data[q:q + l_read_name - 1].decode()
+        q += l_read_name + 4 * n_cigar
+        nb = (l_seq + 1) // 2
+        packed = data[q:q + nb]
+        seq = "".join(_SEQ_DECODE[b >> 4] + _SEQ_DECODE[b & 15] for b in packed)[:l_seq]
+        q += nb + l_seq
+        tags = {}
+        while q < end:
+            tag = data[q:q + 2].decode()
+            typ = chr(data[q + 2])
+            q += 3
+            if typ in _TAG_FMT:
+                fmt = _TAG_FMT[typ]
+                tags[tag], = struct.unpack_from(fmt, data, q)
+                q += struct.calcsize(fmt)
+            elif typ == "A":
+                tags[tag] = chr(data[q])
+                q += 1
+            elif typ in "ZH":
+                e = data.index(b"\0", q)
+                tags[tag] = data[q:e].decode()
+                q = e + 1
+            elif typ == "B":
+                sub = chr(data[q])
+                cnt, = struct.unpack_from("<i", data, q + 1)
+                size = struct.calcsize(_TAG_FMT[sub])
+                tags[tag] = list(struct.unpack_from("<" + _TAG_FMT[sub][1] * cnt, data, q + 5))
+                q += 5 + size * cnt
+            else:
+                raise ValueError(f"{path}: unknown BAM tag type {typ!r}")
+        pos = end
+        yield BasecallRecord(name, seq, tags)
+
+
+def _sam_tag_text(tag, value):
+    if isinstance(value, bool):
+        value = int(value)
+    if isinstance(value, int):
+        return f"{tag}:i:{value}"
+    if isinstance(value, float):
+        return f"{tag}:f:{value!r}"
+    return f"{tag}:Z:{value}"
+
+
+def write_sam(path: str, records) -> None:
+    """records: iterable of (name, sequence, tags dict). Unaligned records (flag 4)."""
+    with open(path, "w") as w:
+        w.write("@HD\tVN:1.6\tSO:unknown\n")
+        for name, seq, tags in records:
+            fields = [name, "4", "*", "0", "0", "*", "*", "0", "0", seq, "*"] + [_sam_tag_text(k, v) for k, v in tags.items()]
+            w.write("\t".join(fields) + "\n")
+
+
+def _bgzf_block(payload: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = comp.compress(payload) + comp.flush()
+    bsize = len(body) + 25
+    header = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return header + body + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload))
+
+
+def write_bam(path: str, records) -> None:
+    """Minimal uBAM writer (tests / synthetic datasets): floats as 'f' (single precision, as dorado
+    writes sm/sd/qs), ints as 'i', strings as 'Z'."""
+    enc = {c: i for i, c in enumerate(_SEQ_DECODE)}
+    out = bytearray(b"BAM\x01")
+    text = b"@HD\tVN:1.6\tSO:unknown\n"
+    out += struct.pack("<i", len(text)) + text + struct.pack("<i", 0)
+    for name, seq, tags in records:
+        nm = name.encode() + b"\0"
+        codes = [enc.get(c.upper(), 15) for c in seq]
+        if len(codes) % 2:
+            codes.append(0)
+        packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+        tagb = bytearray()
+        for k, v in tags.items():
+            if isinstance(v, int):
+                tagb += k.encode() + b"i" + struct.pack("<i", v)
+            elif isinstance(v, float):
+                tagb += k.encode() + b"f" + struct.pack("<f", v)
+            else:
+                tagb += k.encode() + b"Z" + str(v).encode() + b"\0"
+        body = struct.pack("<iiBBHHHiiii", -1, -1, len(nm), 0, 4680, 0, 4, len(seq), -1, -1, 0) + nm + packed + b"\xff" * len(seq) + bytes(tagb)
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as w:
+        data = bytes(out)
+        for i in range(0, len(data), 0xFF00):
+            w.write(_bgzf_block(data[i:i + 0xFF00]))
+        w.write(_bgzf_block(b""))  # EOF marker block

@@ -7,8 +7,9 @@ container that ``dynamont_amd.synth.write_dataset`` produces:
 
   raw:        ``<name>.dynraw.npz``  read_ids, offsets, adc (int16), cal_scale, cal_offset
               (pod5 convention: picoampere = (adc + offset) * scale)
-  basecalls:  ``<name>.dynbam.tsv``  one line per read with the BAM fields the reference reads:
-              query_name, sequence, qs, pi, ns, ts, sp, fn, sm, sd   ('*' = tag absent)
+  basecalls:  ``.bam`` / ``.sam`` through pysam, else through the vendor-free parsers of
+              ``dynamont_amd.bam_io``; or ``<name>.dynbam.tsv``, one line per read with the BAM fields
+              the reference reads: query_name, sequence, qs, pi, ns, ts, sp, fn, sm, sd ('*' = absent)
 """
 from __future__ import annotations
 
@@ -82,11 +83,13 @@ class BasecallRecord:
 def iter_basecalls(path: str):
     """Yield records in file order: pysam for .bam/.sam, the TSV container otherwise."""
     if path.endswith((".bam", ".sam")):
-        if _pysam is None:
-            raise ImportError(f"cannot read {path}: 'pysam' is not installed; use the .dynbam.tsv container")
-        with _pysam.AlignmentFile(path, "r" if path.endswith(".sam") else "rb", check_sq=False) as f:
-            for rec in f.fetch(until_eof=True):
-                yield rec
+        if _pysam is not None:
+            with _pysam.AlignmentFile(path, "r" if path.endswith(".sam") else "rb", check_sq=False) as f:
+                for rec in f.fetch(until_eof=True):
+                    yield rec
+            return
+        from dynamont_amd import bam_io  # vendor-free parsers (pysam/htslib are not in the ROCm image)
+        yield from (bam_io.iter_sam(path) if path.endswith(".sam") else bam_io.iter_bam(path))
         return
     with open(path) as f:
         cols = f.readline().rstrip("\n").split("\t")

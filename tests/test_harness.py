@@ -258,3 +258,39 @@ def test_native_probability_formatting_equals_python(models, native_lib):
     res["states"] = ["M"] * n
     res["polishes"] = [""] * n
     assert data == U.segmentation_to_string(res, "r", "s", 7, 3 * n + 7, seq, 5, False)
+
+
+def test_sam_and_bam_readers_round_trip(tmp_path):
+    """The vendor-free SAM/BAM parsers deliver name, sequence and the eight tags segment.py reads."""
+    from dynamont_amd import bam_io
+    from dynamont_amd.pod5_io import iter_basecalls
+    rng = np.random.default_rng(1)
+    recs = []
+    for i in range(300):   # > one 64 KB BGZF block
+        seq = "".join(rng.choice(list("ACGTN"), size=int(rng.integers(1, 700))))
+        tags = {"qs": float(np.float32(rng.uniform(5, 30))), "ns": int(rng.integers(1000, 10 ** 6)), "ts": int(rng.integers(0, 500)),
+                "fn": f"file_{i % 3}.pod5", "sm": float(np.float32(rng.uniform(50, 120))), "sd": float(np.float32(rng.uniform(5, 30)))}
+        if i % 4 == 0:
+            tags["pi"] = f"parent-{i}"
+            tags["sp"] = int(rng.integers(0, 10 ** 5))
+        recs.append((f"read-{i:04d}", seq, tags))
+    bam, sam = str(tmp_path / "x.bam"), str(tmp_path / "x.sam")
+    bam_io.write_bam(bam, recs)
+    bam_io.write_sam(sam, recs)
+    import gzip
+    assert gzip.open(bam).read(4) == b"BAM\x01"
+    for path in (bam, sam):
+        got = list(iter_basecalls(path))
+        assert len(got) == len(recs)
+        for r, (name, seq, tags) in zip(got, recs):
+            assert r.query_name == name and r.query_sequence == seq
+            assert r.has_tag("pi") == ("pi" in tags) and r.has_tag("f5") is False
+            for k, v in tags.items():
+                assert r.get_tag(k) == v, (path, k)
+    # and the job generator consumes them exactly like the TSV container
+    jobs = list(seg.generate_jobs("/data", bam, 10.0))
+    assert len(jobs) == sum(t["qs"] >= 10.0 for _, _, t in recs)
+    name, seq, tags = next(x for x in recs if x[2]["qs"] >= 10.0)
+    j = jobs[0]
+    assert j[0] == "/data/" + tags["fn"] and j[5] == seq and j[6] == name
+    assert j[7] == tags.get("pi", name) and j[3] == tags.get("sp", 0) + tags["ts"] and j[4] == tags.get("sp", 0) + tags["ns"]
