@@ -247,6 +247,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   double* __restrict__ out = ws + rd.ws_off + lane;
   const int m63 = opaque_lane_mask(lane, 63);
 
+  bool bad_sample = false;
   int lo = band_mid(T - 1, ratio) - bw;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
   int n[CPL];
@@ -266,6 +267,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
     const int base = thi - 63;
     const int idx = base + lane;
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
+    bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
     log_normal_pdf_vec<CPL>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
 #pragma unroll 1
@@ -318,8 +320,14 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       }
     }
   }
+  // An infinite sample gives every cell of its row the score -inf in the reference (aligner.cpp:
+  // 287-292), hence Z = -inf and "alignment scores do not match" (NT_aligner_api.cpp:288-291). The
+  // residual-corrected quotient of log_normal_pdf_vec would turn it into NaN instead, so non-finite
+  // samples are flagged here and reported through the same Z check (NaN samples, for which the
+  // reference's behaviour is undefined, fail the same way).
+  const bool any_bad = __any(bad_sample);
   // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
-  if (lane == 0) st[rd.read].Zb = bE[0];
+  if (lane == 0) st[rd.read].Zb = any_bad ? NEG_INF : bE[0];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -273,3 +273,26 @@ def test_traceback_segments_spanning_many_64_row_blocks(models):
         assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
         assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
         assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+
+
+def test_empty_and_all_failed_batches(al5):
+    """Ragged/empty inputs: an empty batch and a batch in which every read is rejected on the host
+    never reach a kernel and still answer per read."""
+    res = al5.align_batch([], [], True)
+    assert res.n == 0 and len(res.Z) == 0
+    res = al5.align_batch([np.zeros(0), np.zeros(5), np.ones(40)], ["ACGTACGT", "ACG", "ACGTNACGTA"], True)
+    assert [res.error(i) for i in range(3)] == ["Signal is empty", "Sequence shorter than model kmer size",
+                                                 "Invalid nucleotide: N"]
+    assert res.n_segments.sum() == 0
+    tr = al5.train_batch([np.zeros(0)], ["ACGTACGT"])
+    assert tr.error(0) == "Signal is empty" and tr.em_count[0] == 0
+    # a Z mismatch is reported with the reference's text and does not disturb its neighbours
+    good = np.random.default_rng(0).standard_normal(60)
+    res = al5.align_batch([good, np.full(60, np.inf), good], ["ACGTACGTAC"] * 3, True)
+    assert res.status[0] == 0 and res.status[2] == 0
+    assert res.error(1) == "Alignment failed: alignment scores do not match"
+    assert np.array_equal(res.read(0)["signal_positions"], res.read(2)["signal_positions"])
+    one_inf = good.copy()
+    one_inf[17] = -np.inf
+    assert al5.align_batch([one_inf], ["ACGTACGTAC"], False).error(0) == "Alignment failed: alignment scores do not match"
+    assert al5.train_batch([one_inf], ["ACGTACGTAC"]).error(0) == "Training failed: alignment scores do not match"
