@@ -216,16 +216,6 @@ DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNod
 // Two-phase form of the table-driven logPlus so that independent work (the next row's emission)
 // can be placed between issuing the LDS lookups and consuming them:
 //   SoftplusLookup<M> L;  log_plus_issue(x, y, L, tab);   ...independent code...   log_plus_finish(L, out);
-DYN_HD int low_word(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __double2loint(x);
-#else
-  long long b;
-  __builtin_memcpy(&b, &x, 8);
-  return (int)(b & 0xffffffffll);
-#endif
-}
-
 template <int M>
 struct SoftplusLookup {
   double hi[M], r[M], g0[M], s[M];
@@ -234,11 +224,7 @@ struct SoftplusLookup {
 template <int M>
 DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusLookup<M>& L,
                            const SoftplusNode* __restrict__ tab) {
-  // node index k = rint(-128 d) via the 1.5*2^52 trick: after t = fma(d, -128, MAGIC) the integer
-  // sits in the low 32 bits of t and t - MAGIC is k as a double (same round-to-nearest-even as
-  // v_rndne_f64, one instruction fewer than mul + rndne + cvt).
-  const double MAGIC = 0x1.8p52;
-  double d[M], t[M], kf[M];
+  double d[M], kf[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) L.hi[j] = __builtin_fmax(x[j], y[j]);
 #pragma unroll
@@ -246,14 +232,12 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
 #pragma unroll
   for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -(double)SP_RANGE);  // also NaN -> -40
 #pragma unroll
-  for (int j = 0; j < M; ++j) t[j] = fma_(d[j], -(double)SP_STEPS, MAGIC);
-#pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = t[j] - MAGIC;
+  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * -(double)SP_STEPS);
 #pragma unroll
   for (int j = 0; j < M; ++j) L.r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);  // exact
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    const SoftplusNode nd = tab[low_word(t[j])];
+    const SoftplusNode nd = tab[(int)kf[j]];
     L.g0[j] = nd.g;
     L.s[j] = nd.s;
   }
