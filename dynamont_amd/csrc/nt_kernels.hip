@@ -19,14 +19,17 @@
 //          (vE == vM_prev + LPE, NT_aligner_api.cpp:448); forward / Viterbi rows never leave
 //          registers; it overwrites each bE row in place with (float LPM, float LPE) for the
 //          path-probability lookup and writes 1 decision bit per cell;
-//   K_trace walks the decision bits back (one wave per read, 64 rows per LDS block) and
-//          K_median/K_final produce the per-segment median posterior.
+//   K_trace walks the decision bits back one SEGMENT per step (ballot + find-first-set inside
+//          64-row LDS blocks) and K_median/K_final produce the per-segment median posterior.
 // HBM traffic is 24.1 B per in-band cell instead of the 64.1 B of the three-pass formulation
 // (SURVEY.md §8d), and the per-read footprint is 8 B per slot instead of 64 B per cell.
 //
-// One 64-lane wave owns one read; lane l owns slots l, l+64, ... (CPL of them), so every row
-// load/store is CPL fully coalesced 512-byte accesses. Cross-lane neighbours (n-1 for forward,
-// n+1 for backward) come from DPP wave rotates -- no LDS, no barriers in the DP loops.
+// Mapping: one 64-lane wave owns one read, four reads share a 256-thread workgroup (one wave per
+// SIMD). Lane l owns band slots l, l+64, ... (CPL of them), so every row access is CPL fully
+// coalesced 512-byte operations. Cross-lane neighbours (n-1 forward, n+1 backward) come from DPP
+// wave rotates + v_bfi -- no barrier anywhere in the DP loops. The CU's LDS holds the softplus
+// table shared by the four waves (dp_math.hpp) and, in K_fwd, a 4-row-deep ring per wave that is
+// filled straight from HBM by global_load_lds_dwordx4 (see ring_dma_row).
 #include "nt_kernels.hpp"
 
 // Placement: the SPI packs single-wave workgroups onto one SIMD for as long as its registers
