@@ -212,17 +212,33 @@ class Batch:
     """Staged form (dyn_batch_*): inputs are validated, k-mer coded and resident in HBM after
     construction; align()/train() only launch kernels; fetch() copies results back."""
 
-    def __init__(self, aligner: "Aligner", signals, sig_offsets, seqs: bytes, seq_offsets):
+    def __init__(self, aligner: "Aligner", signals, sig_offsets, seqs: bytes, seq_offsets, raw=None):
+        """raw = None: ``signals`` are normalised float64 samples. raw = dict(shift, scale, window,
+        n_sigmas, f32): ``signals`` are RAW float32 / int16 / float64 samples and the preprocessing of
+        segment.py:146-153 runs on the device (dyn_batch_create_raw)."""
         self._al = aligner
         self._L = N.lib()
         self.n = len(sig_offsets) - 1
         self._sig_off = np.ascontiguousarray(sig_offsets, dtype=np.uint64)
         self._seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
-        sig = np.ascontiguousarray(signals, dtype=np.float64)
         self.capacity = int(self._L.dyn_segment_capacity(aligner._h, self.n, _ptr(self._seq_off, N.c_u64_p)))
         h = C.c_void_p()
-        rc = self._L.dyn_batch_create(aligner._h, self.n, _ptr(sig, N.c_double_p), _ptr(self._sig_off, N.c_u64_p),
-                                      seqs, _ptr(self._seq_off, N.c_u64_p), C.byref(h))
+        if raw is None:
+            sig = np.ascontiguousarray(signals, dtype=np.float64)
+            rc = self._L.dyn_batch_create(aligner._h, self.n, _ptr(sig, N.c_double_p), _ptr(self._sig_off, N.c_u64_p),
+                                          seqs, _ptr(self._seq_off, N.c_u64_p), C.byref(h))
+        else:
+            sig = np.ascontiguousarray(signals)
+            code = {np.dtype(np.float32): 0, np.dtype(np.int16): 1, np.dtype(np.float64): 2}.get(sig.dtype)
+            if code is None:
+                raise ValueError(f"raw signal dtype {sig.dtype} is not float32, int16 or float64")
+            shift = np.ascontiguousarray(raw["shift"], dtype=np.float64)
+            scale = np.ascontiguousarray(raw["scale"], dtype=np.float64)
+            rc = self._L.dyn_batch_create_raw(aligner._h, self.n, sig.ctypes.data, code, _ptr(self._sig_off, N.c_u64_p),
+                                              _ptr(shift, N.c_double_p), _ptr(scale, N.c_double_p),
+                                              int(raw.get("window", 3)), float(raw.get("n_sigmas", 3.0)),
+                                              int(bool(raw.get("f32", False))), seqs, _ptr(self._seq_off, N.c_u64_p),
+                                              C.byref(h))
         if rc != N.DYN_OK:
             _raise(rc, aligner.last_error())
         self._h = h
@@ -261,6 +277,14 @@ class Batch:
         out = TrainBatchResult(self.n, self.capacity, self._al.num_kmers, pooled)
         rc = self._L.dyn_batch_fetch_train(self._h, C.byref(out._c),
                                            _ptr(out.pooled, N.c_double_p) if pooled else None)
+        if rc != N.DYN_OK:
+            _raise(rc, self._al.last_error())
+        return out
+
+    def signals(self) -> np.ndarray:
+        """The device-resident (normalised, Hampel-filtered) samples, concatenated."""
+        out = np.empty(int(self._sig_off[-1] - self._sig_off[0]))
+        rc = self._L.dyn_batch_signals(self._h, _ptr(out, N.c_double_p), out.size)
         if rc != N.DYN_OK:
             _raise(rc, self._al.last_error())
         return out
@@ -379,6 +403,21 @@ class Aligner:
 
     def batch_packed(self, signals, sig_offsets, seqs: bytes, seq_offsets) -> Batch:
         return Batch(self, signals, sig_offsets, seqs, seq_offsets)
+
+    def batch_raw(self, raw_slices: Sequence, sequences: Sequence[str], shift, scale, window: int = 3,
+                  n_sigmas: float = 3.0, f32: bool = False) -> Batch:
+        """Batch from RAW sample slices (all float32, all int16 or all float64): normalisation and the
+        Hampel filter of the reference's workers run on the device, bit-identically."""
+        n = len(raw_slices)
+        sig_off = np.zeros(n + 1, dtype=np.uint64)
+        seq_off = np.zeros(n + 1, dtype=np.uint64)
+        for i, s in enumerate(raw_slices):
+            sig_off[i + 1] = sig_off[i] + len(s)
+            seq_off[i + 1] = seq_off[i] + len(sequences[i])
+        raw = np.concatenate(raw_slices) if n else np.zeros(0, dtype=np.float32)
+        seqs = "".join(sequences).encode("latin-1")
+        return Batch(self, raw, sig_off, seqs, seq_off,
+                     raw=dict(shift=shift, scale=scale, window=window, n_sigmas=n_sigmas, f32=f32))
 
     def align_batch(self, signals: Sequence, sequences: Sequence[str], calc_probabilities: bool = True) -> AlignBatchResult:
         with self.batch(signals, sequences) as b:

@@ -75,6 +75,9 @@ SIGNATURES = {
                                  C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_uint64, c_u64_p, c_u64_p]),
     "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                    C.POINTER(C.c_void_p)]),
+    "dyn_batch_create_raw": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_double_p, c_double_p,
+                                       C.c_int, C.c_double, C.c_int, C.c_char_p, c_u64_p, C.POINTER(C.c_void_p)]),
+    "dyn_batch_signals": (C.c_int, [C.c_void_p, c_double_p, C.c_uint64]),
     "dyn_batch_destroy": (None, [C.c_void_p]),
     "dyn_batch_align": (C.c_int, [C.c_void_p, C.c_int]),
     "dyn_batch_train": (C.c_int, [C.c_void_p]),

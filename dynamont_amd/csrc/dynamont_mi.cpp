@@ -344,9 +344,22 @@ int dyn_validate_batch(const dyn_aligner* a, uint64_t n_reads, const uint64_t* s
   return DYN_OK;
 }
 
-int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
-                     const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
-                     dyn_batch** out) {
+}  // extern "C"
+
+namespace {
+struct RawSource {
+  const void* raw = nullptr;   // concatenated [start:end) slices
+  int dtype = 0;               // 0 float32, 1 int16, 2 float64
+  const double* shift = nullptr;
+  const double* scale = nullptr;
+  int window = 3;
+  double n_sigmas = 3.0;
+  int compute_f32 = 0;
+};
+
+int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const RawSource* rs,
+                const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                dyn_batch** out) {
   if (!a || !out) return DYN_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   int rc = need_device(a);
@@ -380,7 +393,34 @@ int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
   } while (0)
   const uint64_t total_sig = n_reads ? sig_offsets[n_reads] - sig_offsets[0] : 0;
   B_TRY(b->d_sig.ensure(std::max<uint64_t>(8, total_sig * 8)));
-  if (total_sig) B_TRY(hipMemcpyAsync(b->d_sig.p, signals + sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->stream));
+  DevBuf d_raw, d_norm, d_offs, d_shift, d_scale;  // preprocessing scratch, freed on return
+  struct Scratch {
+    DevBuf* v[5];
+    ~Scratch() { for (DevBuf* d : v) d->release(); }
+  } scratch{{&d_raw, &d_norm, &d_offs, &d_shift, &d_scale}};
+  if (!rs) {
+    if (total_sig) B_TRY(hipMemcpyAsync(b->d_sig.p, signals + sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->stream));
+  } else if (total_sig) {
+    // P1/P2 on the device (segment.py:146-153): upload the raw slices, normalise, Hampel-filter
+    const size_t esz = rs->dtype == 0 ? 4 : rs->dtype == 1 ? 2 : 8;
+    std::vector<uint64_t> offs(n_reads + 1);
+    uint64_t max_len = 0;
+    for (uint64_t i = 0; i <= n_reads; ++i) offs[i] = sig_offsets[i] - sig_offsets[0];
+    for (uint64_t i = 0; i < n_reads; ++i) max_len = std::max(max_len, offs[i + 1] - offs[i]);
+    B_TRY(d_raw.ensure(total_sig * esz));
+    B_TRY(d_norm.ensure(total_sig * (rs->compute_f32 ? 4 : 8)));
+    B_TRY(d_offs.ensure((n_reads + 1) * 8));
+    B_TRY(d_shift.ensure(n_reads * 8));
+    B_TRY(d_scale.ensure(n_reads * 8));
+    B_TRY(hipMemcpyAsync(d_raw.p, (const char*)rs->raw + sig_offsets[0] * esz, total_sig * esz, hipMemcpyHostToDevice, a->stream));
+    B_TRY(hipMemcpyAsync(d_offs.p, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, a->stream));
+    B_TRY(hipMemcpyAsync(d_shift.p, rs->shift, n_reads * 8, hipMemcpyHostToDevice, a->stream));
+    B_TRY(hipMemcpyAsync(d_scale.p, rs->scale, n_reads * 8, hipMemcpyHostToDevice, a->stream));
+    B_TRY(hipStreamSynchronize(a->stream));  // offs is a local vector
+    dynk::launch_preprocess(d_raw.p, rs->dtype, rs->compute_f32, d_offs.as<uint64_t>(), d_shift.as<double>(),
+                            d_scale.as<double>(), d_norm.p, b->d_sig.as<double>(), (int)n_reads, max_len, rs->window,
+                            rs->n_sigmas, a->stream);
+  }
   for (HostRead& r : b->reads) r.sig_off -= n_reads ? sig_offsets[0] : 0;
   B_TRY(b->d_kmers.ensure(std::max<uint64_t>(4, b->total_cols * 4)));
   B_TRY(b->d_par.ensure(std::max<uint64_t>(sizeof(Emis), b->total_cols * sizeof(Emis))));
@@ -393,6 +433,46 @@ int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
   B_TRY(hipStreamSynchronize(a->stream));
 #undef B_TRY
   *out = b;
+  return DYN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                     const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                     dyn_batch** out) {
+  return create_impl(a, n_reads, signals, nullptr, sig_offsets, seqs, seq_offsets, out);
+}
+
+int dyn_batch_create_raw(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                         const uint64_t* raw_offsets, const double* shift, const double* scale,
+                         int hampel_window, double hampel_n_sigmas, int compute_f32, const char* seqs,
+                         const uint64_t* seq_offsets, dyn_batch** out) {
+  if (!a) return DYN_ERR_INVALID_ARGUMENT;
+  if (raw_dtype < 0 || raw_dtype > 2 || hampel_window < 1 || hampel_window > 16 || !raw || !shift || !scale) {
+    a->last_error = "dyn_batch_create_raw: raw_dtype must be 0 (f32), 1 (i16) or 2 (f64) and 1 <= window <= 16";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  RawSource rs;
+  rs.raw = raw;
+  rs.dtype = raw_dtype;
+  rs.shift = shift;
+  rs.scale = scale;
+  rs.window = hampel_window;
+  rs.n_sigmas = hampel_n_sigmas;
+  rs.compute_f32 = compute_f32;
+  return create_impl(a, n_reads, nullptr, &rs, raw_offsets, seqs, seq_offsets, out);
+}
+
+// Normalised + filtered signals of a batch created with dyn_batch_create_raw (tests, debugging).
+int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count) {
+  if (!b || !out) return DYN_ERR_INVALID_ARGUMENT;
+  dyn_aligner* a = b->a;
+  int rc = need_device(a);
+  if (rc != DYN_OK) return rc;
+  if (count * 8 > b->d_sig.bytes) return DYN_ERR_INVALID_ARGUMENT;
+  HIP_TRY(a, hipMemcpy(out, b->d_sig.p, count * 8, hipMemcpyDeviceToHost));
   return DYN_OK;
 }
 

@@ -32,6 +32,8 @@
 // filled straight from HBM by global_load_lds_dwordx4 (see ring_dma_row).
 #include "nt_kernels.hpp"
 
+#include <algorithm>
+
 // Placement: the SPI packs single-wave workgroups onto one SIMD for as long as its registers
 // allow (measured: a 184-VGPR build of K_bwd ran 1 024 reads as 2 waves on each of 512 SIMDs and
 // took 2x the time of 512 reads; tools/ubench + DESIGN.md). The DP waves are pure fp64 issue
@@ -816,6 +818,96 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   if (lane == 0) {
     tb.trans[2 * rd.read] = sumM;
     tb.trans[2 * rd.read + 1] = sumE2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P1/P2 on the device: the per-read preprocessing of segment.py:146-153 / train.py:163-170.
+//   x = REAL(raw[i]); x -= shift; x /= scale            (REAL = double for dynamont-resquiggle,
+//   hampel(x, W, n_sigmas)   (utils.py:16-43)             float for dynamont-train, whose signal
+// Windows are taken from the UNFILTERED normalised signal; centres W/2 .. W/2 + nwin - 1 with        stays float32)
+// nwin = S - W - (W even); a centre is replaced by the window median when
+// |x - med| > n_sigmas * (1.4826 * MAD). Every operation is a single IEEE op in the reference's
+// order, so the result is bit-identical to the NumPy code (tests/test_gpu_preprocess.py).
+// ---------------------------------------------------------------------------------------------
+template <class REAL, class RAW>
+__global__ void k_normalise(const RAW* __restrict__ raw, const uint64_t* __restrict__ offs,
+                            const double* __restrict__ shift, const double* __restrict__ scale,
+                            REAL* __restrict__ norm, int n_reads) {
+  const int r = blockIdx.y;
+  if (r >= n_reads) return;
+  const uint64_t a = offs[r], b = offs[r + 1];
+  const REAL sh = (REAL)shift[r], sc = (REAL)scale[r];
+  for (uint64_t i = a + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b; i += (uint64_t)gridDim.x * blockDim.x) {
+    REAL x = (REAL)raw[i];
+    x = x - sh;
+    norm[i] = x / sc;
+  }
+}
+
+template <class REAL, int MAXW>
+__device__ __forceinline__ REAL window_median(REAL (&w)[MAXW], int W) {
+  for (int i = 1; i < W; ++i) {  // insertion sort of <= MAXW values
+    const REAL v = w[i];
+    int j = i - 1;
+    while (j >= 0 && w[j] > v) {
+      w[j + 1] = w[j];
+      --j;
+    }
+    w[j + 1] = v;
+  }
+  return (W & 1) ? w[W / 2] : (w[W / 2 - 1] + w[W / 2]) / (REAL)2;
+}
+
+template <class REAL>
+__global__ void k_hampel(const REAL* __restrict__ norm, const uint64_t* __restrict__ offs,
+                         double* __restrict__ out, int n_reads, int W, double n_sigmas) {
+  constexpr int MAXW = 16;
+  const int r = blockIdx.y;
+  if (r >= n_reads) return;
+  const uint64_t a = offs[r], S = offs[r + 1] - offs[r];
+  const long nwin = (S <= (uint64_t)W) ? 0 : (long)S - W - ((W & 1) ? 0 : 1);
+  const int half = W / 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (uint64_t)gridDim.x * blockDim.x) {
+    REAL x = norm[a + i];
+    const long wi = (long)i - half;  // window index of this centre
+    if (wi >= 0 && wi < nwin) {
+      REAL w[MAXW], d[MAXW];
+      for (int q = 0; q < W; ++q) w[q] = norm[a + wi + q];
+      for (int q = 0; q < W; ++q) d[q] = w[q];
+      const REAL med = window_median<REAL, MAXW>(d, W);
+      for (int q = 0; q < W; ++q) d[q] = fabs(w[q] - med);
+      const REAL mad = window_median<REAL, MAXW>(d, W);
+      const REAL sigma = (REAL)1.4826 * mad;
+      if (fabs(x - med) > (REAL)n_sigmas * sigma) x = med;
+    }
+    out[a + i] = (double)x;
+  }
+}
+
+template <class REAL, class RAW>
+static void preprocess_t(const RAW* raw, const uint64_t* offs, const double* shift, const double* scale,
+                         void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double ns,
+                         hipStream_t s) {
+  const int bx = (int)std::min<uint64_t>(1024, (max_len + 255) / 256);
+  hipLaunchKernelGGL((k_normalise<REAL, RAW>), dim3(bx ? bx : 1, n_reads), dim3(256), 0, s, raw, offs, shift, scale,
+                     (REAL*)norm_tmp, n_reads);
+  hipLaunchKernelGGL((k_hampel<REAL>), dim3(bx ? bx : 1, n_reads), dim3(256), 0, s, (const REAL*)norm_tmp, offs, out,
+                     n_reads, W, ns);
+}
+
+void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
+                       const double* shift, const double* scale, void* norm_tmp, double* out,
+                       int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s) {
+  if (n_reads <= 0) return;
+  if (compute_f32) {
+    if (raw_dtype == 0) preprocess_t<float, float>((const float*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    else if (raw_dtype == 1) preprocess_t<float, int16_t>((const int16_t*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    else preprocess_t<float, double>((const double*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+  } else {
+    if (raw_dtype == 0) preprocess_t<double, float>((const float*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    else if (raw_dtype == 1) preprocess_t<double, int16_t>((const int16_t*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    else preprocess_t<double, double>((const double*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
   }
 }
 

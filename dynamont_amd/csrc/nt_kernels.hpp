@@ -63,6 +63,11 @@ struct TrainBuffers {
   double* trans;      // [2*reads] expected E->M and E->E transition counts (linear domain)
 };
 
+// P1/P2 on the device: out[i] = hampel((REAL(raw[i]) - shift) / scale); REAL = float when compute_f32.
+// raw_dtype: 0 float32, 1 int16, 2 float64. norm_tmp: scratch of total samples * sizeof(REAL).
+void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
+                       const double* shift, const double* scale, void* norm_tmp, double* out,
+                       int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s);
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
                         hipStream_t s);
 // sp_tab: device copy of dynmath::softplus_build_table (SP_NODES entries)

@@ -50,6 +50,7 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
+    p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same bytes)")
     return p.parse_args(argv)
 
 
@@ -141,7 +142,22 @@ def prepare_job(job, is_rna: bool):
     return signal, read
 
 
-def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: int = 8) -> None:
+def prepare_job_raw(job, is_rna: bool):
+    """P1 without the arithmetic: the raw [start:end) slice (float32 picoampere when ``shift <= 400``,
+    int16 ADC otherwise, segment.py:147) and the aligner-orientation read; normalisation and the
+    Hampel filter then run on the device (dyn_batch_create_raw), bit-identically."""
+    raw_file, shift, scale, start, end, read, readid, signalid = job
+    raw = np.ascontiguousarray(get_signal(get_raw(raw_file), signalid, calibrated=shift <= 400)[start:end])
+    if raw.dtype not in (np.float32, np.int16):
+        raw = raw.astype(np.float64)
+    if is_rna:
+        read = read[::-1]
+        if not read.startswith(POLYA):
+            read = POLYA + read
+    return raw, read
+
+
+def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: int = 8, raw: bool = False) -> None:
     """Align one batch and queue CSV bytes / error lines exactly as segment.py:160-176. The rows are
     formatted by the native dyn_format_csv (same bytes as utils.segmentation_to_string; Python row
     formatting would be ~50x slower than the GPU)."""
@@ -149,7 +165,18 @@ def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: 
         return
     from dynamont_amd._dynamont import format_csv
     signals, reads = [p[0] for p in pending], [p[1] for p in pending]
-    res = aligner.align_batch(signals, reads, calc_probabilities=True)
+    if raw:  # one launch group per raw dtype (float32 pA vs int16 ADC)
+        res = None
+        kinds = sorted({s.dtype.str for s in signals})
+        if len(kinds) > 1:
+            for kd in kinds:
+                _flush(aligner, [p for p in pending if p[0].dtype.str == kd], q, is_rna, kmer_size, threads, raw=True)
+            return
+        with aligner.batch_raw(signals, reads, [p[2][1] for p in pending], [p[2][2] for p in pending]) as b:
+            b.align(True)
+            res = b.fetch()
+    else:
+        res = aligner.align_batch(signals, reads, calc_probabilities=True)
     starts = [p[2][3] for p in pending]
     buf, begin, end = format_csv(aligner, res, reads, [p[2][6] for p in pending], [p[2][7] for p in pending], starts,
                                  [len(sig) + st for sig, st in zip(signals, starts)], threads=threads)
@@ -162,7 +189,8 @@ def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: 
 
 
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
-            minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0) -> None:
+            minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
+            host_preprocess: bool = False) -> None:
     """Counterpart of segment.py:261-371."""
     q = queue_mod.Queue()
     writer = threading.Thread(target=listener, args=(q, outfile), daemon=True)
@@ -176,16 +204,16 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
         pending = []
         for job in generate_jobs(data_path, basecalls, minq):
             try:
-                signal, read = prepare_job(job, is_rna)
+                signal, read = prepare_job(job, is_rna) if host_preprocess else prepare_job_raw(job, is_rna)
             except Exception as error:  # noqa: BLE001  (segment.py:178-187)
                 _, _, _, _, _, read, readid, signalid = job
                 q.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
                 continue
             pending.append((signal, read, job))
             if len(pending) >= batch_reads:
-                _flush(aligner, pending, q, is_rna, kmer_size)
+                _flush(aligner, pending, q, is_rna, kmer_size, raw=not host_preprocess)
                 pending = []
-        _flush(aligner, pending, q, is_rna, kmer_size)
+        _flush(aligner, pending, q, is_rna, kmer_size, raw=not host_preprocess)
         print("Done with segmentation.", file=sys.stderr, flush=True)
     finally:
         q.put("kill")
@@ -211,7 +239,8 @@ def main(argv=None) -> None:
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
     segment(args.raw, args.basecalls, args.processes, outfile, model_path, args.pore, args.mode, args.qscore,
-            device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget)
+            device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget,
+            host_preprocess=args.host_preprocess)
 
 
 if __name__ == "__main__":

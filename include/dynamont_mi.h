@@ -209,6 +209,19 @@ int dyn_format_csv(const dyn_aligner* a, uint64_t n_reads, const dyn_align_out* 
 int dyn_batch_create(dyn_aligner* a, uint64_t n_reads, const double* signals,
                      const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
                      dyn_batch** out);
+/* The same with P1/P2 done on the device (src/dynamont/segmentation/segment.py:146-153,
+ * train.py:163-170, utils.py:16-43): raw = the concatenated raw[start:end) slices of every read
+ * (raw_dtype 0 = float32 picoampere `signal_pa`, 1 = int16 ADC `signal`, 2 = float64), read i =
+ * [raw_offsets[i], raw_offsets[i+1]); per read x = REAL(raw); x -= shift[i]; x /= scale[i]; then the
+ * Hampel filter (window, n_sigmas) -- (3, 3.0) for dynamont-resquiggle, (7, 5.0) for dynamont-train.
+ * compute_f32 = 1 performs the arithmetic in float32, as NumPy does in train.py where the signal stays
+ * float32; 0 = float64 as in segment.py. Results are bit-identical to the NumPy code. */
+int dyn_batch_create_raw(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                         const uint64_t* raw_offsets, const double* shift, const double* scale,
+                         int hampel_window, double hampel_n_sigmas, int compute_f32, const char* seqs,
+                         const uint64_t* seq_offsets, dyn_batch** out);
+/* Device-resident preprocessed signals of a batch copied back to the host (count doubles). */
+int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count);
 void dyn_batch_destroy(dyn_batch* b);
 /* Run the kernels (stream-ordered, returns after the stream is idle). */
 int dyn_batch_align(dyn_batch* b, int calc_probabilities);

@@ -32,6 +32,12 @@ def test_resquiggle_cli_end_to_end(models, tmp_path, pore):
     seg.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore,
               "--model_path", model, "--batch-reads", "4"])
     got = zstd_io.decompress(open(str(out) + ".zst", "rb").read())
+    # device preprocessing (default) and host preprocessing produce the same bytes
+    out2 = tmp_path / "out2" / "res.csv"
+    seg.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(out2), "--mode", "basic", "-p", pore,
+              "--model_path", model, "--batch-reads", "5", "--host-preprocess"])
+    assert zstd_io.decompress(open(str(out2) + ".zst", "rb").read()) == got
+    assert open(str(tmp_path / "out2" / "res.errors")).read() == open(str(tmp_path / "out" / "res.errors")).read()
     orc = Oracle(model, pid)
     want = [seg.CSV_HEADER]
     errors = []
