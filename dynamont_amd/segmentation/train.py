@@ -99,6 +99,7 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--aggregate", choices=["window-mean", "pooled"], default="window-mean",
                    help="parameter update: the reference's sliding-window mean of per-read estimates, or a pooled M-step")
     p.add_argument("--no-timestamp", action="store_true", help="write into OUTDIR itself (the reference appends a timestamp)")
+    p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same values)")
     return p.parse_args(argv)
 
 
@@ -110,8 +111,11 @@ def _code_order(model: dict, k: int, rna: bool):
     return names, mean, sd
 
 
-def read_items(data_path, basecalls, pore, minq):
-    """Read filters + preprocessing of train.py:125-176, one item per accepted read."""
+def read_items(data_path, basecalls, pore, minq, raw: bool = False):
+    """Read filters + preprocessing of train.py:125-176, one item per accepted read:
+    (signal, sequence, readid). With ``raw=True`` the arithmetic is left to the device and the item
+    is ((raw float32 slice, shift, scale), sequence, readid) for ``Aligner.batch_raw(..., window=7,
+    n_sigmas=5.0, f32=True)``."""
     old_file, r5 = None, None
     for rec in iter_basecalls(basecalls):
         if minq and rec.get_tag("qs") < minq:
@@ -134,18 +138,42 @@ def read_items(data_path, basecalls, pore, minq):
             yield "mismatch"
             continue
         signal = np.array(signal, dtype=np.float32 if signal.dtype.kind != "f" else signal.dtype, copy=True)
-        signal -= shift   # float32 arithmetic when the reader returns float32, as in train.py:168-169
-        signal /= scale
-        hampel(signal, 7, 5.0)
         if "rna" in pore:
             seq = seq[::-1]
             if not seq.startswith("AAAAAAAAA"):
                 seq = "AAAAAAAAA" + seq
+        if raw:
+            yield ((signal, float(shift), float(scale)), seq, readid)
+            continue
+        signal -= shift   # float32 arithmetic when the reader returns float32, as in train.py:168-169
+        signal /= scale
+        hampel(signal, 7, 5.0)
         yield (signal, seq, readid)
 
 
+def _train_items(al: Aligner, items, pooled: bool, raw: bool):
+    if not raw:
+        return al.train_batch([x[0] for x in items], [x[1] for x in items], pooled=pooled)
+    f32 = items[0][0][0].dtype == np.float32
+    with al.batch_raw([x[0][0] for x in items], [x[1] for x in items], [x[0][1] for x in items],
+                      [x[0][2] for x in items], window=7, n_sigmas=5.0, f32=f32) as b:
+        b.train()
+        return b.fetch_train(pooled)
+
+
+def _z_items(al: Aligner, items, raw: bool):
+    if not raw:
+        return al.align_batch([x[0] for x in items], [x[1] for x in items], calc_probabilities=False)
+    f32 = items[0][0][0].dtype == np.float32
+    with al.batch_raw([x[0][0] for x in items], [x[1] for x in items], [x[0][1] for x in items],
+                      [x[0][2] for x in items], window=7, n_sigmas=5.0, f32=f32) as b:
+        b.align(False)
+        return b.fetch()
+
+
 def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_file: str, mode: str, model_path: str,
-          max_batches, pore: str, minq=None, device: int = 0, aggregate: str = "window-mean", comm=None) -> None:
+          max_batches, pore: str, minq=None, device: int = 0, aggregate: str = "window-mean", comm=None,
+          host_preprocess: bool = False) -> None:
     """Counterpart of train.py:68-253. ``comm`` (optional, dynamont_amd.parallel.Comm) makes the
     pooled update a multi-GPU all-reduce of sufficient statistics."""
     if mode != "basic":
@@ -168,7 +196,7 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
         pw.write("epoch,batch,read," + "".join(p + "," for p in transition_params) + "Zchange\n")
         for e in range(epochs):
             items, cbatch = [], 0
-            for it in read_items(data_path, basecalls, pore, minq):
+            for it in read_items(data_path, basecalls, pore, minq, raw=not host_preprocess):
                 if it == "qskip":
                     qskips += 1
                     continue
@@ -183,11 +211,11 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 cbatch += 1
                 al = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
                 cur_mean, cur_sd = al.model_table()
-                res = al.train_batch([x[0] for x in items], [x[1] for x in items], pooled=(aggregate == "pooled"))
+                res = _train_items(al, items, aggregate == "pooled", raw=not host_preprocess)
                 preZ = {}
                 for j, (_, _, readid) in enumerate(items):
                     if res.status[j] != 0:
-                        print(f"error: native, {res.error(j)} T: {len(items[j][0])} N: {len(items[j][1])} Sid: {readid}", file=sys.stderr)
+                        print(f"error: native, {res.error(j)} T: {len(items[j][0][0] if not host_preprocess else items[j][0])} N: {len(items[j][1])} Sid: {readid}", file=sys.stderr)
                         print(f"No segmentation calculated for {readid} in {e}: {trained_model}.", file=sys.stderr)
                         continue
                     i += 1
@@ -231,7 +259,7 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 pw.flush()
                 # rerun with the new model to compare Zs (train.py:226-242)
                 al2 = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
-                post = al2.align_batch([x[0] for x in items], [x[1] for x in items], calc_probabilities=False)
+                post = _z_items(al2, items, raw=not host_preprocess)
                 dZ = np.array([float(post.Z[j]) - z for j, z in preZ.items() if post.status[j] == 0])
                 print(f"Z changes: {dZ}", file=sys.stderr)
                 deltaZ = np.mean(dZ) if len(dZ) else 0.0
@@ -258,7 +286,7 @@ def main(argv=None) -> None:
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
     train(args.raw, args.basecalls, args.batch_size, args.epochs, param_file, "basic", model_path, args.max_batches,
-          args.pore, args.qscore, device=args.device, aggregate=args.aggregate)
+          args.pore, args.qscore, device=args.device, aggregate=args.aggregate, host_preprocess=args.host_preprocess)
 
 
 if __name__ == "__main__":

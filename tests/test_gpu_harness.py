@@ -90,6 +90,12 @@ def test_train_cli(models, tmp_path, aggregate):
     assert rows[1].startswith("0,1,4,") and rows[2].startswith("0,2,8,")
     assert all(len(r.split(",")) == 7 for r in rows[1:])
     assert float(rows[1].split(",")[-1]) > 0       # an EM step on its own batch raises the likelihood
+    # host preprocessing (NumPy float32 arithmetic) gives the very same model files
+    outdir2 = tmp_path / f"train_{aggregate}_host"
+    trn.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(outdir2), "-p", pore, "--model_path", model,
+              "--batch_size", "4", "--max_batches", "2", "--aggregate", aggregate, "--no-timestamp", "--host-preprocess"])
+    for f in ("trained_0_1.model", "trained_0_2.model"):
+        assert open(outdir / f).read() == open(outdir2 / f).read()
     m0, m1 = U.read_kmer_model(str(outdir / "trained_0_0.model")), U.read_kmer_model(str(outdir / "trained_0_1.model"))
     assert list(m0) == list(m1) and m0 != m1
     if aggregate == "pooled":
