@@ -101,14 +101,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: dynamont_amd has no CPU compute path")
-    # Rehearsal hooks (CPU-side control-flow checks on a 1-GPU box; never set by the driver):
+    # Rehearsal hooks (control-flow checks on a 1-GPU box; never set by the driver):
     #   DYN_BENCH_BACKEND=gloo   use gloo instead of nccl/RCCL
     #   DYN_BENCH_ONE_DEVICE=1   every rank uses cuda:0
+    #   DYN_BENCH_FORCE_DIST=1   run the collectives even with a single rank (exercises RCCL on one GPU)
     backend = os.environ.get("DYN_BENCH_BACKEND", "nccl")
     if os.environ.get("DYN_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if n_gpus > 1:
+    use_dist = n_gpus > 1 or bool(os.environ.get("DYN_BENCH_FORCE_DIST"))
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -140,7 +142,7 @@ def main():
         nonlocal gather_buf, rows_t
         if args.mode == "train":
             batch.train()
-            if n_gpus > 1:  # config 5: sum all-reduce of the pooled sufficient statistics (3 * 4^k doubles)
+            if use_dist:  # config 5: sum all-reduce of the pooled sufficient statistics (3 * 4^k doubles)
                 ptr, cnt = batch.device_pooled()
 
                 class _Pooled:
@@ -153,7 +155,7 @@ def main():
                     dist.all_reduce(h, op=dist.ReduceOp.SUM)
             return
         batch.align(True)
-        if n_gpus > 1:
+        if use_dist:
             if rows_t is None:
                 rows_t = wrap_rows()
                 if rank == 0:
@@ -165,7 +167,7 @@ def main():
                 dist.gather(h, [torch.empty_like(h) for _ in range(n_gpus)] if rank == 0 else None, dst=0)
 
     def sync():
-        if n_gpus > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +183,7 @@ def main():
             kern[key] += tm[key]
     sync()
     elapsed = time.perf_counter() - t0
-    if n_gpus > 1:
+    if use_dist:
         red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -251,7 +253,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line))
     batch.close()
-    if n_gpus > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
