@@ -83,3 +83,42 @@ def rows_from_bytes(buf: np.ndarray) -> np.ndarray:
     """View gathered bytes as the C ABI's dyn_segment_row records."""
     dt = np.dtype([("signal_pos", "<u4"), ("sequence_pos", "<u4"), ("probability", "<f8")])
     return np.frombuffer(np.ascontiguousarray(buf).tobytes(), dtype=dt)
+
+
+def init_from_env():
+    """When launched by ``torch.distributed.run`` (WORLD_SIZE > 1) join the process group and return
+    (Comm, local_rank); otherwise (None, 0). Backend: ``DYN_DIST_BACKEND`` (default "nccl" = RCCL;
+    "gloo" for CPU rehearsals). ``DYN_DIST_ONE_DEVICE=1`` maps every rank to device 0 (rehearsal)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("DYN_DIST_BACKEND", "nccl")
+    local_rank = 0 if os.environ.get("DYN_DIST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return Comm(device=f"cuda:{local_rank}" if backend == "nccl" else "cpu"), local_rank
+
+
+def gather_bytes(comm: "Comm", payload: bytes, dst: int = 0):
+    """Variable-length gather of one bytes object per rank (CSV rows, error lines) to ``dst``."""
+    import torch
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else torch.zeros(0, dtype=torch.uint8)
+    parts = comm.gather_rows(t.to(comm.device), dst=dst)
+    if parts is None:
+        return None
+    return [bytes(p.cpu().numpy().tobytes()) for p in parts]
+
+
+def any_rank(comm: "Comm", flag: bool) -> bool:
+    """Logical OR of a flag over ranks."""
+    import torch
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=comm.device)
+    comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
+    return bool(t.item())

@@ -188,37 +188,93 @@ def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: 
             q.put(buf[int(begin[i]):int(end[i])].tobytes())
 
 
+class _Collector:
+    """Queue-like sink used by the non-root ranks of a multi-GPU run: rows and error lines of one
+    round are collected and shipped to rank 0 (BASELINE.json config 4: gather of per-read CSV rows)."""
+
+    def __init__(self):
+        self.rows, self.errors = [], []
+
+    def put(self, item):
+        (self.errors if isinstance(item, str) else self.rows).append(item)
+
+    def drain(self):
+        r, e = b"".join(self.rows), "\n".join(self.errors).encode()
+        self.rows, self.errors = [], []
+        return r, e
+
+
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
             host_preprocess: bool = False) -> None:
-    """Counterpart of segment.py:261-371."""
-    q = queue_mod.Queue()
-    writer = threading.Thread(target=listener, args=(q, outfile), daemon=True)
-    writer.start()
+    """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
+    on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
+    the writer (reads are independent; the gather is the only exchange)."""
+    from dynamont_amd import parallel
+    comm, local_rank = parallel.init_from_env()
+    rank, world = (comm.rank, comm.world) if comm else (0, 1)
+    if comm:
+        device = local_rank
+    q = queue_mod.Queue() if rank == 0 else None
+    writer = None
+    if rank == 0:
+        writer = threading.Thread(target=listener, args=(q, outfile), daemon=True)
+        writer.start()
+    sink = q if comm is None else _Collector()
     is_rna = "rna" in pore
     kmer_size = 5 if pore in ("dna_r9", "rna002") else 9
+
+    def ship():  # one collective round: everything collected since the last round goes to rank 0
+        rows, errs = sink.drain()
+        all_rows = parallel.gather_bytes(comm, rows)
+        all_errs = parallel.gather_bytes(comm, errs)
+        if rank == 0:
+            for blob in all_rows:
+                if blob:
+                    q.put(blob)
+            for blob in all_errs:
+                for line in blob.decode().split("\n") if blob else []:
+                    q.put(line)
+
     try:
         aligner = Aligner(model_path, pore, mode=mode, threads=1, band=400, device=device)
         if mem_budget_gib:
             aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
-        pending = []
-        for job in generate_jobs(data_path, basecalls, minq):
-            try:
-                signal, read = prepare_job(job, is_rna) if host_preprocess else prepare_job_raw(job, is_rna)
-            except Exception as error:  # noqa: BLE001  (segment.py:178-187)
-                _, _, _, _, _, read, readid, signalid = job
-                q.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
+        job_iter = enumerate(generate_jobs(data_path, basecalls, minq))
+        exhausted = False
+        while True:
+            pending = []
+            while len(pending) < batch_reads:
+                nxt = next(job_iter, None)
+                if nxt is None:
+                    exhausted = True
+                    break
+                idx, job = nxt
+                if idx % world != rank:  # every rank walks the basecalls and keeps its share
+                    continue
+                try:
+                    signal, read = prepare_job(job, is_rna) if host_preprocess else prepare_job_raw(job, is_rna)
+                except Exception as error:  # noqa: BLE001  (segment.py:178-187)
+                    _, _, _, _, _, read, readid, signalid = job
+                    sink.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
+                    continue
+                pending.append((signal, read, job))
+            _flush(aligner, pending, sink, is_rna, kmer_size, raw=not host_preprocess)
+            if comm is None:
+                if exhausted:
+                    break
                 continue
-            pending.append((signal, read, job))
-            if len(pending) >= batch_reads:
-                _flush(aligner, pending, q, is_rna, kmer_size, raw=not host_preprocess)
-                pending = []
-        _flush(aligner, pending, q, is_rna, kmer_size, raw=not host_preprocess)
+            ship()  # collective: every rank takes part in every round, with empty payloads once it is done
+            if not parallel.any_rank(comm, not exhausted):
+                break
         print("Done with segmentation.", file=sys.stderr, flush=True)
     finally:
-        q.put("kill")
-        writer.join()
+        if rank == 0:
+            q.put("kill")
+            writer.join()
         close_raw_cache()
+        if comm is not None and comm.dist.is_initialized():
+            comm.dist.barrier()
 
 
 def main(argv=None) -> None:

@@ -174,13 +174,23 @@ def _z_items(al: Aligner, items, raw: bool):
 def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_file: str, mode: str, model_path: str,
           max_batches, pore: str, minq=None, device: int = 0, aggregate: str = "window-mean", comm=None,
           host_preprocess: bool = False) -> None:
-    """Counterpart of train.py:68-253. ``comm`` (optional, dynamont_amd.parallel.Comm) makes the
-    pooled update a multi-GPU all-reduce of sufficient statistics."""
+    """Counterpart of train.py:68-253. ``comm`` (optional, dynamont_amd.parallel.Comm): multi-GPU
+    run -- accepted reads are dealt round-robin to the ranks (each rank fills ``batch_size`` reads of
+    its own per batch, so all ranks reach a batch boundary on the same read), the pooled sufficient
+    statistics, transition counts and Z changes are summed over ranks, every rank computes the same
+    model, and rank 0 owns params.csv and the model files in ``outdir``."""
     if mode != "basic":
         print(f"Mode {mode} not implemented", file=sys.stderr)
         sys.exit(1)
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    if world > 1 and aggregate != "pooled":
+        raise ValueError("multi-GPU training needs --aggregate pooled (per-read windows are rank-local)")
     model = read_kmer_model(model_path)
     outdir = dirname(param_file)
+    if rank != 0:  # private copies of the per-batch model files; params.csv is rank 0's
+        outdir = join(outdir, f".rank{rank}")
+        makedirs(outdir, exist_ok=True)
+        param_file = join(outdir, "params.csv")
     trained_model = join(outdir, "trained_0_0.model")
     write_kmer_model(trained_model, model)
     transition_params = {"e1": 1.0, "m1": 0.03, "e2": 0.97}  # train.py:76-82 (logged only)
@@ -189,13 +199,12 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
     names, mean0, sd0 = _code_order(model, k, rna)
     table = ManagedTable(mean0, sd0)
     trans = {p: ManagedList([v]) for p, v in transition_params.items()}
-    polya = (0 if True else None)  # code of the all-A k-mer is 0 in either orientation
     any_seen = False
     i = qskips = mismatches = 0
     with open(param_file, "w") as pw:
         pw.write("epoch,batch,read," + "".join(p + "," for p in transition_params) + "Zchange\n")
         for e in range(epochs):
-            items, cbatch = [], 0
+            items, cbatch, accepted = [], 0, 0
             for it in read_items(data_path, basecalls, pore, minq, raw=not host_preprocess):
                 if it == "qskip":
                     qskips += 1
@@ -203,8 +212,10 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 if it == "mismatch":
                     mismatches += 1
                     continue
-                items.append(it)
-                if len(items) < batch_size:
+                accepted += 1
+                if (accepted - 1) % world == rank:
+                    items.append(it)
+                if accepted % (batch_size * world):  # a batch = batch_size reads on EVERY rank
                     continue
                 print("============================", file=sys.stderr)
                 print(f"{datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}: Training epoch: {e}, reads: {i}, batch: {cbatch}\n{transition_params}", file=sys.stderr)
@@ -234,9 +245,16 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                     if aggregate == "window-mean":
                         table.add(dm, ds)
                 print(f"Zs: {list(preZ.values())}", file=sys.stderr)
-                pw.write(f"{e},{cbatch},{i},")
+                if comm is not None:  # reads trained so far and pooled transition estimate over all ranks
+                    ok = [j for j in preZ]
+                    tot = comm.allreduce_sum(np.array([len(ok), res.trans_counts[0::2][ok].sum(), res.trans_counts[1::2][ok].sum()]))
+                    i_global = getattr(train, "_i_global", 0) + int(tot[0])
+                    train._i_global = i_global
+                    m1 = tot[1] / (tot[1] + tot[2]) if tot[1] + tot[2] > 0 else 0.0
+                    pooled_trans = {"e1": 1.0, "m1": m1, "e2": 1.0 - m1 if tot[1] + tot[2] > 0 else 0.0}
+                pw.write(f"{e},{cbatch},{i if comm is None else i_global},")
                 for p in transition_params:
-                    transition_params[p] = trans[p].mean()
+                    transition_params[p] = trans[p].mean() if comm is None else pooled_trans[p]
                     pw.write(f"{transition_params[p]},")
                 if aggregate == "pooled":
                     pooled = res.pooled
@@ -262,12 +280,17 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 post = _z_items(al2, items, raw=not host_preprocess)
                 dZ = np.array([float(post.Z[j]) - z for j, z in preZ.items() if post.status[j] == 0])
                 print(f"Z changes: {dZ}", file=sys.stderr)
-                deltaZ = np.mean(dZ) if len(dZ) else 0.0
+                if comm is not None:
+                    sz = comm.allreduce_sum(np.array([dZ.sum(), float(len(dZ))]))
+                    deltaZ = sz[0] / sz[1] if sz[1] else 0.0
+                else:
+                    deltaZ = np.mean(dZ) if len(dZ) else 0.0
                 pw.write(f"{deltaZ}\n")
                 pw.flush()
                 items = []
                 if max_batches is not None and cbatch >= max_batches:
                     break
+    train._i_global = 0
     print("Done training", file=sys.stderr)
     print(f"Skipped reads due to low quality: {qskips}", file=sys.stderr)
 
@@ -285,8 +308,13 @@ def main(argv=None) -> None:
         model_path = get_model(args.pore)
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
+    # under torch.distributed.run: every rank trains its own shard of each batch on its own GPU and the
+    # pooled sufficient statistics are summed over ranks (BASELINE.json config 5)
+    from dynamont_amd import parallel
+    comm, local_rank = parallel.init_from_env()
     train(args.raw, args.basecalls, args.batch_size, args.epochs, param_file, "basic", model_path, args.max_batches,
-          args.pore, args.qscore, device=args.device, aggregate=args.aggregate, host_preprocess=args.host_preprocess)
+          args.pore, args.qscore, device=local_rank if comm else args.device, aggregate=args.aggregate, comm=comm,
+          host_preprocess=args.host_preprocess)
 
 
 if __name__ == "__main__":

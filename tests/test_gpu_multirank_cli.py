@@ -1,0 +1,69 @@
+"""GPU (-m gpu): the CLIs under torch.distributed.run with two ranks (both on cuda:0, gloo for the
+collectives -- a 1-GPU box cannot host two RCCL ranks): reads are sharded, rank 0 gathers the CSV rows
+(BASELINE config 4) / pooled statistics are all-reduced (config 5). Results must equal the
+single-process run up to row order."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, model_for
+from dynamont_amd import synth, zstd_io
+from dynamont_amd.segmentation import segment as seg
+from dynamont_amd.segmentation import train as trn
+from dynamont_amd.segmentation import utils as U
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib")]
+
+
+def _torchrun(module, args, port):
+    env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", module] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_resquiggle_two_ranks_gather_rows(models, tmp_path):
+    pore = "rna004"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(91, 11, pore, mean, sd, (60, 200))
+    raw, bam, _ = synth.write_dataset(str(tmp_path / "in"), "ds", reads, pore, seed=2)
+    lines = open(bam).read().splitlines()
+    f = lines[5].split("\t"); f[1] = f[1][:30] + "N" + f[1][31:]; lines[5] = "\t".join(f)
+    open(bam, "w").write("\n".join(lines) + "\n")
+    base = ["-r", str(tmp_path / "in"), "-b", bam, "--mode", "basic", "-p", pore, "--model_path", model, "--batch-reads", "3"]
+    seg.main(base + ["-o", str(tmp_path / "single.csv")])
+    _torchrun("dynamont_amd.segmentation.segment", base + ["-o", str(tmp_path / "multi.csv")], 29621)
+    one = zstd_io.decompress(open(tmp_path / "single.csv.zst", "rb").read()).decode().splitlines()
+    two = zstd_io.decompress(open(tmp_path / "multi.csv.zst", "rb").read()).decode().splitlines()
+    assert one[0] == two[0] and sorted(one[1:]) == sorted(two[1:]) and len(one) > 500
+    assert sorted(open(tmp_path / "single.errors").read().splitlines()) == sorted(open(tmp_path / "multi.errors").read().splitlines())
+
+
+def test_train_two_ranks_allreduce(models, tmp_path):
+    pore = "rna002"
+    kmers, mean, sd = synth.read_model_file(model_for(models, pore))
+    mean[kmers.index("AAAAA")] = 1.2
+    model = str(tmp_path / "polyA_ok.model")
+    U.write_kmer_model(model, {k_: (float(m), float(s)) for k_, m, s in zip(kmers, mean, sd)})
+    reads = synth.make_reads(92, 8, pore, mean, sd, (80, 200))
+    raw, bam, _ = synth.write_dataset(str(tmp_path / "in"), "tr", reads, pore, seed=5)
+    lines = open(bam).read().splitlines()
+    for i in range(1, len(lines)):
+        f = lines[i].split("\t"); f[2] = "15.0"; lines[i] = "\t".join(f)
+    open(bam, "w").write("\n".join(lines) + "\n")
+    common = ["-r", str(tmp_path / "in"), "-b", bam, "-p", pore, "--model_path", model, "--aggregate", "pooled", "--no-timestamp"]
+    # one process, batches of 8  ==  two ranks, batches of 4 reads per rank
+    trn.main(common + ["-o", str(tmp_path / "single"), "--batch_size", "8", "--max_batches", "1"])
+    _torchrun("dynamont_amd.segmentation.train", common + ["-o", str(tmp_path / "multi"), "--batch_size", "4", "--max_batches", "1"], 29622)
+    a, b = U.read_kmer_model(str(tmp_path / "single" / "trained_0_1.model")), U.read_kmer_model(str(tmp_path / "multi" / "trained_0_1.model"))
+    assert list(a) == list(b)
+    am, bm = np.array([v for v in a.values()]), np.array([v for v in b.values()])
+    assert np.abs(am - bm).max() <= 1e-9   # same statistics, different summation order
+    ra, rb = open(tmp_path / "single" / "params.csv").read().splitlines(), open(tmp_path / "multi" / "params.csv").read().splitlines()
+    assert ra[0] == rb[0] and rb[1].startswith("0,1,8,")
+    assert abs(float(ra[1].split(",")[-1]) - float(rb[1].split(",")[-1])) <= 1e-6
