@@ -25,11 +25,15 @@
 // (SURVEY.md §8d), and the per-read footprint is 8 B per slot instead of 64 B per cell.
 //
 // Mapping: one 64-lane wave owns one read, four reads share a 256-thread workgroup (one wave per
-// SIMD). Lane l owns band slots l, l+64, ... (CPL of them), so every row access is CPL fully
-// coalesced 512-byte operations. Cross-lane neighbours (n-1 forward, n+1 backward) come from DPP
-// wave rotates + v_bfi -- no barrier anywhere in the DP loops. The CU's LDS holds the softplus
-// table shared by the four waves (dp_math.hpp) and, in K_fwd, a 4-row-deep ring per wave that is
-// filled straight from HBM by global_load_lds_dwordx4 (see ring_dma_row).
+// SIMD). Band slot s = n mod P lives in lane s / CPL, register s % CPL: a lane owns CPL CONSECUTIVE
+// slots, so the cross-lane neighbour (n-1 forward, n+1 backward) of all but one of its cells is its
+// own next register and one DPP wave rotate per exchange serves the remaining cell -- no barrier
+// anywhere in the DP loops. In HBM a row stores slot s at position row_pos(s) = (s % CPL)*64 + s / CPL,
+// i.e. register j of all lanes is one contiguous 512-byte run: every row access is CPL fully
+// coalesced operations (a 56-byte lane stride, the "natural" placement of this slot numbering, cost
+// K_bwd 20 % in partial-line writes). The CU's LDS holds the softplus table shared by the four waves
+// (dp_math.hpp) and, in K_fwd, a 4-row-deep ring per wave that is filled straight from HBM by
+// global_load_lds_dwordx4 (see ring_dma_row).
 #include "nt_kernels.hpp"
 
 #include <algorithm>
@@ -65,6 +69,9 @@ __device__ __forceinline__ int pmod(int a) {
   return r < 0 ? r + P : r;
 }
 
+// position of band slot s inside a stored row (see "Mapping" above)
+__device__ __forceinline__ int row_pos(int s) { return (s % CPL) * 64 + s / CPL; }
+
 // size_t(t * RATIO): one IEEE fp64 multiply, then truncation (NT_aligner_api.cpp:100).
 __device__ __forceinline__ int band_mid(int t, double ratio) {
   return (int)__dmul_rn((double)t, ratio);
@@ -92,39 +99,22 @@ __device__ __forceinline__ double wave_rol1(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// Lane mask that the optimiser cannot see through: all ones in `which` lane, zero elsewhere.
-// (With a visible `lane == 63 ? a : b` hipcc merges the 7 per-register selects into a 7-way
-// indexed lookup: 12 v_cndmask + 6 v_cmp per cell instead of 2 v_bfi.)
-__device__ __forceinline__ int opaque_lane_mask(int lane, int which) {
-  int m = (lane == which) ? -1 : 0;
-  asm volatile("" : "+v"(m));
-  return m;
+// Blocked slot layout: lane l owns the CPL consecutive slots l*CPL .. l*CPL+CPL-1, so the left
+// neighbour of its cells 1..CPL-1 is its own previous register and only cell 0 needs the last cell
+// of lane l-1: ONE wave rotate per exchange (the cyclic layout slot = j*64+lane needed CPL rotates
+// plus CPL lane-0 fix-ups). The rotate wraps lane 63 -> lane 0, which is exactly the slot P-1 -> 0
+// wrap of the band ring.
+__device__ __forceinline__ void from_left(const double (&x)[CPL], double (&out)[CPL]) {
+  out[0] = wave_ror1(x[CPL - 1]);
+#pragma unroll
+  for (int j = 1; j < CPL; ++j) out[j] = x[j - 1];
 }
 
-// bitwise (m ? a : b) on both halves of a double: two v_bfi_b32
-__device__ __forceinline__ double bit_select(int m, double a, double b) {
-  int lo, hi;  // v_bfi_b32 D = (S0 & S1) | (~S0 & S2); hipcc does not form it from either C idiom
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"(__double2loint(a)), "v"(__double2loint(b)));
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"(__double2hiint(a)), "v"(__double2hiint(b)));
-  return __hiloint2double(hi, lo);
-}
-
-// out[slot] = x[slot-1] over the P slots of a row (slot = j*64 + lane, cyclic). m0 = mask of lane 0.
-__device__ __forceinline__ void from_left(const double (&x)[CPL], double (&out)[CPL], int m0) {
-  double rot[CPL];
+// out[slot] = x[slot+1]
+__device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)[CPL]) {
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) rot[j] = wave_ror1(x[j]);
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) out[j] = bit_select(m0, rot[(j + CPL - 1) % CPL], rot[j]);
-}
-
-// out[slot] = x[slot+1]. m63 = mask of lane 63.
-__device__ __forceinline__ void from_right(const double (&x)[CPL], double (&out)[CPL], int m63) {
-  double rot[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) rot[j] = wave_rol1(x[j]);
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) out[j] = bit_select(m63, rot[(j + 1) % CPL], rot[j]);
+  for (int j = 0; j < CPL - 1; ++j) out[j] = x[j + 1];
+  out[CPL - 1] = wave_rol1(x[0]);
 }
 
 // n is wave-uniform at the re-assignment sites: the load then becomes an s_load (lgkmcnt), which
@@ -177,7 +167,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// the wave's copy of one row: cell (j, lane) sits at slot*8 = (j*64 + lane)*8
+// the wave's copy of one row: cell (lane, j) sits at row_pos*8 = (j*64 + lane)*8
 __device__ __forceinline__ void ring_read_row(unsigned lds_lane_addr, double (&b)[CPL]) {
   static_assert(CPL == 7, "ring_read_row is written for 7 cells per lane");
   asm volatile(
@@ -247,7 +237,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
   double* __restrict__ out = ws + rd.ws_off + lane;
-  const int m63 = opaque_lane_mask(lane, 63);
 
   bool bad_sample = false;
   int lo = band_mid(T - 1, ratio) - bw;
@@ -257,7 +246,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   EmisV<CPL> p;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int slot = j * 64 + lane;
+    const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
     p.set(j, load_emis(pr, n[j], N));
     bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
@@ -281,7 +270,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       for (int j = 0; j < CPL; ++j) Y[j] = bM[j] + e[j];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) A[j] = bE[j] + e[j];
-      from_right(Y, Yr, m63);
+      from_right(Y, Yr);
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved down by one column
         const int leaving = lo + P - 1;
@@ -372,7 +361,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   float2* __restrict__ lat_lp = ws_wr + rd.ws_off + lane;
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
-  const int m0 = opaque_lane_mask(lane, 0);
 
   int lo = band_mid(0, ratio) - bw;  // = -bw
   int n[CPL];
@@ -382,7 +370,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int slot = j * 64 + lane;
+    const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
     p.set(j, load_emis(pr, n[j], N));
     fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
@@ -425,23 +413,20 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
           for (int j = 0; j < CPL; ++j) bnext[j] = NEG_INF;
         }
       }
-      from_left(fE, fEl, m0);
-      if (POST) from_left(vE, vEl, m0);
+      from_left(fE, fEl);
+      if (POST) from_left(vE, vEl);
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved up by one column
         const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load (see k_backward)
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == lo) {  // column lo leaves the band; its slot becomes column lo+P
+            // e = -inf alone empties the slot: a1, a2 and with them fE', LPE, vE' become -inf this
+            // row, fM'/LPM/vM' through the band mask below. Leaving fE/vE untouched keeps the
+            // shifted copies fEl/vEl plain register renames.
             n[j] = lo + P;
             p.set(j, fresh);
-            fM[j] = NEG_INF;
-            fE[j] = NEG_INF;
             e[j] = NEG_INF;
-            if (POST) {
-              vM[j] = NEG_INF;
-              vE[j] = NEG_INF;
-            }
           }
         }
         lo = new_lo;
@@ -501,7 +486,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const int sf = pmod(nf);
 #pragma unroll
   for (int j = 0; j < CPL; ++j)
-    if (j == (sf >> 6) && lane == (sf & 63)) st[rd.read].Zf = fE[j];
+    if (j == sf % CPL && lane == sf / CPL) st[rd.read].Zf = fE[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -587,8 +572,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         continue;
       }
       // state E in column n at row t: every lane tests its own row for this column
-      const uint64_t w = sb[lane * CPL + (slot >> 6)];
-      const bool bit = (row >= block_lo) && (row <= t) && ((w >> (slot & 63)) & 1);
+      const uint64_t w = sb[lane * CPL + (slot % CPL)];  // ballot word of cell index j = slot % CPL
+      const bool bit = (row >= block_lo) && (row <= t) && ((w >> (slot / CPL)) & 1);  // lane = slot / CPL
       const uint64_t m = __ballot(bit);
       const int r = m ? base + (63 - __builtin_clzll(m)) : block_lo - 1;  // highest turning row, or none
       const int e_lo = m ? r : block_lo;  // rows e_lo..t are E cells of column n
@@ -605,7 +590,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     if (my_st >= 0) {
-      const float2 v = lp[(size_t)row * P + my_slot];
+      const float2 v = lp[(size_t)row * P + row_pos(my_slot)];
       pp[row] = exp((double)(my_st ? v.x : v.y));
       pathn[row] = (uint32_t)my_n | (my_st ? 0x80000000u : 0u);
       if (my_st) segrow[my_n - 1] = (uint32_t)row;
@@ -699,7 +684,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
   const double Z = st[rd.read].Zb;
-  const int m0 = opaque_lane_mask(lane, 0);
 
   int lo = band_mid(0, ratio) - bw;
   int n[CPL];
@@ -710,7 +694,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int slot = j * 64 + lane;
+    const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
     p.set(j, load_emis(pr, n[j], N));
     fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
@@ -731,7 +715,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
       const int t = tb0 + i;
       const double xn = readlane_f64(xs, i);
       double fEl[CPL], bnn[CPL];
-      from_left(fE, fEl, m0);
+      from_left(fE, fEl);
       const bool have = (t + 2 < T);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
@@ -749,9 +733,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
             aw[j] = a1[j] = a2[j] = 0.0;
             n[j] = lo + P;
             p.set(j, fresh);
-            fM[j] = NEG_INF;
-            fE[j] = NEG_INF;
-            e[j] = NEG_INF;
+            e[j] = NEG_INF;  // empties the slot (see k_forward)
           }
         }
         lo = new_lo;
@@ -814,7 +796,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   const int sf = pmod(nf);
 #pragma unroll
   for (int j = 0; j < CPL; ++j)
-    if (j == (sf >> 6) && lane == (sf & 63)) st[rd.read].Zf = fE[j];
+    if (j == sf % CPL && lane == sf / CPL) st[rd.read].Zf = fE[j];
   if (lane == 0) {
     tb.trans[2 * rd.read] = sumM;
     tb.trans[2 * rd.read + 1] = sumE2;

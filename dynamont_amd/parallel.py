@@ -122,3 +122,16 @@ def any_rank(comm: "Comm", flag: bool) -> bool:
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=comm.device)
     comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
     return bool(t.item())
+
+
+def broadcast_str(comm: "Comm", text: str, src: int = 0) -> str:
+    """Rank ``src``'s string on every rank (e.g. a time-stamped output directory name)."""
+    import torch
+    data = text.encode() if comm.rank == src else b""
+    n = torch.tensor([len(data)], dtype=torch.int64, device=comm.device)
+    comm.dist.broadcast(n, src=src)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=comm.device)
+    if comm.rank == src and data:
+        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    comm.dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().numpy().tobytes()).decode()

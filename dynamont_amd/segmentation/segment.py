@@ -286,7 +286,7 @@ def main(argv=None) -> None:
         outfile += ".zst"
     parent = dirname(outfile)
     if parent and not exists(parent):
-        makedirs(parent)
+        makedirs(parent, exist_ok=True)
     if args.model_path:
         model_path = args.model_path
         assert exists(model_path), "Model path does not exist"

@@ -297,9 +297,14 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
 
 def main(argv=None) -> None:
     args = parse(argv)
+    # under torch.distributed.run: every rank trains its own shard of each batch on its own GPU and the
+    # pooled sufficient statistics are summed over ranks (BASELINE.json config 5)
+    from dynamont_amd import parallel
+    comm, local_rank = parallel.init_from_env()
     outdir = args.outdir if args.no_timestamp else args.outdir + f'_{datetime.now().strftime("%Y-%m-%d_%H-%M-%S")}'
-    if not exists(outdir):
-        makedirs(outdir)
+    if comm is not None:
+        outdir = parallel.broadcast_str(comm, outdir)  # one time stamp for the whole job
+    makedirs(outdir, exist_ok=True)  # every rank gets here; the first one wins
     param_file = join(outdir, "params.csv")
     if args.model_path:
         model_path = args.model_path
@@ -308,10 +313,6 @@ def main(argv=None) -> None:
         model_path = get_model(args.pore)
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
-    # under torch.distributed.run: every rank trains its own shard of each batch on its own GPU and the
-    # pooled sufficient statistics are summed over ranks (BASELINE.json config 5)
-    from dynamont_amd import parallel
-    comm, local_rank = parallel.init_from_env()
     train(args.raw, args.basecalls, args.batch_size, args.epochs, param_file, "basic", model_path, args.max_batches,
           args.pore, args.qscore, device=local_rank if comm else args.device, aggregate=args.aggregate, comm=comm,
           host_preprocess=args.host_preprocess)

@@ -52,6 +52,12 @@ def _worker(rank, world, port, model, outdir):
         got = comm.gather_rows(torch.from_numpy(np.frombuffer(mine.tobytes(), dtype=np.uint8).copy()), dst=0)
         total = comm.allreduce_sum(pooled)
         np.save(os.path.join(outdir, f"pooled_{rank}.npy"), total)
+        # helpers of the multi-rank CLIs: rank 0's string everywhere, OR of a flag, ragged byte gather
+        assert parallel.broadcast_str(comm, f"out_{rank}_stamp") == "out_0_stamp"
+        assert parallel.broadcast_str(comm, "") == ""
+        assert parallel.any_rank(comm, rank == 1) and not parallel.any_rank(comm, False)
+        parts = parallel.gather_bytes(comm, b"x" * (3 * rank))
+        assert parts == [b"", b"xxx"] if rank == 0 else parts is None
         if rank == 0:
             allrows = np.concatenate([parallel.rows_from_bytes(g.numpy()) for g in got])
             np.save(os.path.join(outdir, "rows.npy"), allrows)
