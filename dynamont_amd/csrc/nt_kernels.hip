@@ -248,7 +248,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], N));
+    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
     bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
     bM[j] = NEG_INF;
     if (STORE) out[(size_t)(T - 1) * P + j * 64] = bE[j];
@@ -274,21 +274,30 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {  // wave-uniform: the window moved down by one column
         const int leaving = lo + P - 1;
+        const int top = lo + W - 1;  // last band column of row t+1: above the band of row t
         // uniform address, outside the per-lane branch: a scalar load (lgkmcnt). A vector load here
         // makes hipcc guard every later read of p with s_waitcnt vmcnt(0) in EVERY row.
         const Emis fresh = load_emis(pr, new_lo, N);
+        const Emis none = load_emis(pr, 0, 0);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
             p.set(j, fresh);
           }
+          // Upper band edge: bM(t, top) = A must not see the in-band cell (t+1, top); Y keeps it for
+          // the diagonal into (t, top-1). From row t on the slot carries the "no k-mer" parameters, so
+          // e = -inf and with it A = Y = -inf for every column above the band without a per-row
+          // select -- including the slot of column lo+P-1, whose bE picks up a finite x1 from its
+          // ring neighbour, band column lo, in every row (the slot ring wraps) and is emptied by
+          // e = -inf before anything reads it.
+          if (n[j] == top) {
+            A[j] = NEG_INF;
+            p.set(j, none);
+          }
         }
         lo = new_lo;
       }
-      const int hi_n = lo + W - 1;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) A[j] = (n[j] <= hi_n) ? A[j] : NEG_INF;  // bM(t,n)
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
 #pragma unroll
@@ -362,7 +371,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
 
-  int lo = band_mid(0, ratio) - bw;  // = -bw
+  // Band edges without per-row masks. Lower edge: the slot of a column that leaves the band is
+  // handed to column lo+P. Upper edge: a slot carries the k-mer parameters of its column only from
+  // the row in which the column ENTERS the band; before that it carries the "no k-mer" parameters
+  // (log_stdev = +inf), hence e = -inf, hence fM = fE = LPM = LPE = vM = vE = -inf in that slot with
+  // no select in the row loop. Both hand-overs happen in the rare block that looks one row ahead.
+  int lo = band_mid(1, ratio) - bw;  // band of row 1 (column 0 of row 0 is inside: band_mid(1) <= 1 <= bw)
   int n[CPL];
   double fM[CPL], fE[CPL], e[CPL];
   double vM[CPL], vE[CPL], bcur[CPL], bnext[CPL];
@@ -372,7 +386,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], N));
+    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
     fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     fM[j] = NEG_INF;
     if (POST) {
@@ -415,26 +429,24 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       }
       from_left(fE, fEl);
       if (POST) from_left(vE, vEl);
-      const int new_lo = band_mid(t, ratio) - bw;
-      if (new_lo != lo) {  // wave-uniform: the window moved up by one column
-        const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load (see k_backward)
+      const int next_lo = band_mid(t + 1, ratio) - bw;
+      if (next_lo != lo) {  // wave-uniform: the window moves up by one column between rows t and t+1
+        // uniform addresses -> scalar loads (see k_backward)
+        const Emis none = load_emis(pr, 0, 0);
+        const Emis entering = load_emis(pr, lo + W, N);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          if (n[j] == lo) {  // column lo leaves the band; its slot becomes column lo+P
-            // e = -inf alone empties the slot: a1, a2 and with them fE', LPE, vE' become -inf this
-            // row, fM'/LPM/vM' through the band mask below. Leaving fE/vE untouched keeps the
-            // shifted copies fEl/vEl plain register renames.
-            n[j] = lo + P;
-            p.set(j, fresh);
-            e[j] = NEG_INF;
-          }
+          // Column lo is in the band for the last time in this row; its slot becomes column lo+P. n and
+          // p are only read by the emission of row t+1 below, which must already be -inf here; e(t, lo)
+          // and fE/vE(t-1, lo) stay where this row and the right neighbour (fEl/vEl) still read them.
+          const bool leaves = n[j] == lo;
+          n[j] = leaves ? lo + P : n[j];
+          if (leaves) p.set(j, none);
+          if (n[j] == lo + W) p.set(j, entering);  // first band row of this column is t+1
         }
-        lo = new_lo;
+        lo = next_lo;
       }
-      const int hi_n = lo + W - 1;
       double a1[CPL], a2[CPL], fMn[CPL], fEn[CPL], en[CPL];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) fEl[j] = (n[j] <= hi_n) ? fEl[j] : NEG_INF;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
 #pragma unroll
