@@ -109,7 +109,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-o", LIB_PATH + ".tmp"]
+    cmd += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -548,7 +548,7 @@ int run_job(dyn_batch* b, Job job) {
     Chunk cur;
     uint64_t used = 0;
     for (uint32_t i : order) {
-      const uint64_t need = lattice ? (b->reads[i].S + 1) * row_bytes : 0;
+      const uint64_t need = lattice ? (b->reads[i].S + 2) * row_bytes : 0;  // T rows + the -inf row T
       if (lattice && need > budget) {
         a->last_error = "a single read's lattice does not fit the HBM budget";
         return DYN_ERR_OUT_OF_MEMORY;
@@ -575,7 +575,7 @@ int run_job(dyn_batch* b, Job job) {
   std::vector<ReadDesc> descs;
   for (const Chunk& ch : chunks) {
     descs.clear();
-    uint64_t rows_total = 0;
+    uint64_t rows_total = 0, ws_rows = 0;  // the lattice workspace holds T+1 rows per read
     uint32_t max_T = 0, max_N = 0;
     for (uint32_t i : ch.idx) {
       const HostRead& r = b->reads[i];
@@ -588,10 +588,11 @@ int run_job(dyn_batch* b, Job job) {
       d.sig_off = r.sig_off;
       d.par_off = r.flat_off;
       d.seg_off = r.seg_off;
-      d.ws_off = rows_total * dynk::P;
+      d.ws_off = ws_rows * dynk::P;
       d.bits_off = rows_total * dynk::CPL;
       d.path_off = rows_total;
       rows_total += d.T;
+      ws_rows += d.T + 1;
       max_T = std::max(max_T, d.T);
       max_N = std::max(max_N, d.N);
       descs.push_back(d);
@@ -600,7 +601,7 @@ int run_job(dyn_batch* b, Job job) {
     }
     const int nr = (int)descs.size();
     HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
-    if (lattice) HIP_TRY(a, a->ws.ensure(rows_total * dynk::P * 8));
+    if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8));
     if (calc) {
       HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8));
       HIP_TRY(a, a->pp.ensure(rows_total * 8));

@@ -86,17 +86,24 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // lane i receives lane i-1 (lane 0 receives lane 63)
 __device__ __forceinline__ double wave_ror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  // mov_dpp: no "old" operand tied to the source, so a still-live source needs no copy first
+#ifdef DYN_EXP_UPDATE_DPP
+  const int rlo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
+  const int rhi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+#else
+  const int rlo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xf, 0xf, false);
+  const int rhi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xf, 0xf, false);
+#endif
+  return __hiloint2double(rhi, rlo);
 }
 
 // lane i receives lane i+1 (lane 63 receives lane 0)
 __device__ __forceinline__ double wave_rol1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  // mov_dpp: no "old" operand tied to the source, so a still-live source needs no copy first
+  const int rlo = __builtin_amdgcn_mov_dpp(lo, 0x134, 0xf, 0xf, false);
+  const int rhi = __builtin_amdgcn_mov_dpp(hi, 0x134, 0xf, 0xf, false);
+  return __hiloint2double(rhi, rlo);
 }
 
 // Blocked slot layout: lane l owns the CPL consecutive slots l*CPL .. l*CPL+CPL-1, so the left
@@ -251,7 +258,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
     p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
     bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
     bM[j] = NEG_INF;
-    if (STORE) out[(size_t)(T - 1) * P + j * 64] = bE[j];
+    if (STORE) {
+      out[(size_t)(T - 1) * P + j * 64] = bE[j];
+      // one row past the lattice, all -inf: bM(T-1, .) = bE(T, .) + e has no successor. It lets
+      // k_forward stream row t+1 for every t without a last-row special case in its row loop.
+      out[(size_t)T * P + j * 64] = NEG_INF;
+    }
   }
 
   for (int thi = T - 2; thi >= 0; thi -= 64) {
@@ -402,8 +414,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][0];
   const unsigned ring_lane = ring_base + lane * 8;
   const double* __restrict__ dma_src = ws_rd + rd.ws_off + lane * 2;
-  if (POST) {
-    for (int r = 2; r <= RING_D + 1 && r < T; ++r) ring_dma_row(dma_src + (size_t)r * P, ring_base + (r % RING_D) * ROW_BYTES);
+  if (POST) {  // rows past T repeat the all -inf row T (k_backward): RING_D rows are always in flight
+    for (int r = 2; r <= RING_D + 1; ++r) ring_dma_row(dma_src + (size_t)min(r, T) * P, ring_base + (r % RING_D) * ROW_BYTES);
   }
 
   for (int tb = 1; tb < T; tb += 64) {
@@ -416,16 +428,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       const double xn = readlane_f64(xs, i);
       double fEl[CPL], vEl[CPL];
       if (POST) {
-        // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D
-        if (t + 1 < T) {
-          if (t + RING_D < T) wait_vmcnt<RING_WAIT>(); else wait_vmcnt<0>();
-          ring_read_row(ring_lane + ((t + 1) % RING_D) * ROW_BYTES, bnext);
-          if (t + 1 + RING_D < T)
-            ring_dma_row(dma_src + (size_t)(t + 1 + RING_D) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
-        } else {
-#pragma unroll
-          for (int j = 0; j < CPL; ++j) bnext[j] = NEG_INF;
-        }
+        // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D (clamped to the
+        // -inf row T, so that the same number of memory operations is in flight in every row and
+        // one hand-counted s_waitcnt serves the whole loop, tail included)
+        wait_vmcnt<RING_WAIT>();
+        ring_read_row(ring_lane + ((t + 1) % RING_D) * ROW_BYTES, bnext);
+        ring_dma_row(dma_src + (size_t)min(t + 1 + RING_D, T) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
       }
       from_left(fE, fEl);
       if (POST) from_left(vE, vEl);
@@ -472,9 +480,24 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
-        uint64_t mybits = bj[0];  // lane j keeps ballot j
+#ifdef DYN_EXP_BITS_SELECT
+        uint64_t mybits = bj[0];
 #pragma unroll
         for (int j = 1; j < CPL; ++j) mybits = (lane == j) ? bj[j] : mybits;
+#else
+        // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much)
+        unsigned wlo, whi;
+        asm("" : "=v"(wlo), "=v"(whi));  // lanes >= CPL are never stored
+#define DYN_PUT_BALLOT(J)                                                                              \
+  asm("v_writelane_b32 %0, %2, " #J "\n\tv_writelane_b32 %1, %3, " #J                          \
+               : "+v"(wlo), "+v"(whi)                                                                  \
+               : "s"((unsigned)bj[J]), "s"((unsigned)(bj[J] >> 32)))
+        static_assert(CPL == 7, "one DYN_PUT_BALLOT per cell register");
+        DYN_PUT_BALLOT(0); DYN_PUT_BALLOT(1); DYN_PUT_BALLOT(2); DYN_PUT_BALLOT(3);
+        DYN_PUT_BALLOT(4); DYN_PUT_BALLOT(5); DYN_PUT_BALLOT(6);
+#undef DYN_PUT_BALLOT
+        const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
+#endif
 #pragma unroll
         for (int j = 0; j < CPL; ++j) lat_lp[(size_t)t * P + j * 64] = make_float2((float)LPM[j], (float)LPE[j]);
         if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
@@ -493,6 +516,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
       }
     }
   }
+  if (POST) wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
   // Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285)
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);

@@ -24,7 +24,7 @@ constexpr int MAX_HALF_BAND = (P - 2) / 2;   // 2*bw+1 <= P-1  ->  bw <= 223 (ba
 struct ReadDesc {
   uint64_t sig_off;   // first sample in the signal pool (doubles)
   uint64_t par_off;   // first entry in the per-column emission table; entry n-1 <-> column n
-  uint64_t ws_off;    // lattice workspace [T][P] (8 B per slot)
+  uint64_t ws_off;    // lattice workspace [T+1][P] (8 B per slot; row T = -inf)
   uint64_t bits_off;  // decision bits [T][CPL] (uint64)
   uint64_t path_off;  // per-row path arrays [T]
   uint64_t seg_off;   // first output row of this read
