@@ -43,13 +43,23 @@ void copy_msg(char* buf, uint64_t cap, const std::string& s) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
-  hipError_t ensure(size_t want) {
+  // grow-only. `headroom` > 1 over-allocates when the buffer has to grow: releasing and re-allocating
+  // a 70 GB lattice pool costs 4-5 s on an MI355X (measured, tools/batch_latency.py), which a stream
+  // of batches of slightly different size would otherwise pay every time a new maximum shows up.
+  hipError_t ensure(size_t want, double headroom = 1.0) {
     if (want <= bytes) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) bytes = want;
+    size_t ask = (size_t)((double)want * headroom);
+    if (ask < want) ask = want;
+    hipError_t e = hipMalloc(&p, ask);
+    if (e != hipSuccess && ask > want) {  // no room for the headroom: take exactly what is needed
+      (void)hipGetLastError();
+      ask = want;
+      e = hipMalloc(&p, ask);
+    }
+    if (e == hipSuccess) bytes = ask;
     return e;
   }
   void release() {
@@ -544,6 +554,7 @@ int run_job(dyn_batch* b, Job job) {
 
   // greedy chunks in LPT order
   std::vector<Chunk> chunks;
+  uint64_t used_max = 0;
   {
     Chunk cur;
     uint64_t used = 0;
@@ -560,9 +571,12 @@ int run_job(dyn_batch* b, Job job) {
       }
       cur.idx.push_back(i);
       used += need;
+      used_max = std::max(used_max, used);
     }
     if (!cur.idx.empty()) chunks.push_back(std::move(cur));
   }
+  // pool growth headroom (see DevBuf::ensure), never beyond the budget
+  const double headroom = used_max ? std::min(1.25, std::max(1.0, (double)budget / (double)used_max)) : 1.0;
 
   dyn_timing tm{};
   hipEvent_t ev[4];
@@ -601,11 +615,11 @@ int run_job(dyn_batch* b, Job job) {
     }
     const int nr = (int)descs.size();
     HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
-    if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8));
+    if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8, headroom));
     if (calc) {
-      HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8));
-      HIP_TRY(a, a->pp.ensure(rows_total * 8));
-      HIP_TRY(a, a->pathn.ensure(rows_total * 4));
+      HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8, headroom));
+      HIP_TRY(a, a->pp.ensure(rows_total * 8, headroom));
+      HIP_TRY(a, a->pathn.ensure(rows_total * 4, headroom));
     }
     // the previous chunk still reads a->descs: stream order makes the copy safe
     HIP_TRY(a, hipMemcpyAsync(a->descs.p, descs.data(), descs.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));

@@ -24,14 +24,14 @@ import numpy as np
 from dynamont_amd import Aligner, __version__
 from dynamont_amd.pod5_io import get_signal, iter_basecalls, open_pod5
 from dynamont_amd.segmentation.utils import get_model, hampel, segmentation_to_string
-from dynamont_amd.zstd_io import ZstdWriter
+from dynamont_amd.zstd_io import open_writer
 
 CSV_HEADER = b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
 POLYA = "AAAAAAAAA"
 
 RAW_CACHE: OrderedDict | None = None
 RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
-ZSTD_WORKERS = 4    # libzstd worker threads of the writer (single frame, level 3 as the reference)
+ZSTD_WORKERS = 0    # compression threads of the writer (0: up to 8 host cores; level 3 as the reference)
 
 
 def parse(argv=None) -> Namespace:
@@ -60,7 +60,7 @@ def listener(q, outfile: str) -> None:
     errfile = splitext(splitext(outfile)[0])[0] + ".errors"
     num_err = 0
     with open(outfile, "wb") as raw:
-        with ZstdWriter(raw, level=3, workers=ZSTD_WORKERS) as output:
+        with open_writer(raw, level=3, threads=ZSTD_WORKERS) as output:
             output.write(CSV_HEADER)
             while True:
                 result = q.get()
@@ -242,6 +242,12 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
             aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
         job_iter = enumerate(generate_jobs(data_path, basecalls, minq))
         exhausted = False
+        # Two-stage pipeline: this thread reads and slices the next batch (pod5 / BAM, GIL-bound Python)
+        # while one worker thread runs the previous batch through the GPU and the native formatter
+        # (ctypes calls, GIL released). One batch in flight bounds the memory.
+        from concurrent.futures import ThreadPoolExecutor
+        gpu_worker = ThreadPoolExecutor(max_workers=1)
+        in_flight = None
         while True:
             pending = []
             while len(pending) < batch_reads:
@@ -259,16 +265,23 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                     sink.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
                     continue
                 pending.append((signal, read, job))
-            _flush(aligner, pending, sink, is_rna, kmer_size, raw=not host_preprocess)
+            if in_flight is not None:
+                in_flight.result()  # re-raises what the batch raised
+            in_flight = gpu_worker.submit(_flush, aligner, pending, sink, is_rna, kmer_size, 8, not host_preprocess)
             if comm is None:
                 if exhausted:
+                    in_flight.result()
                     break
                 continue
+            in_flight.result()  # multi-rank: the round's rows must be complete before they are shipped
+            in_flight = None
             ship()  # collective: every rank takes part in every round, with empty payloads once it is done
             if not parallel.any_rank(comm, not exhausted):
                 break
         print("Done with segmentation.", file=sys.stderr, flush=True)
     finally:
+        if "gpu_worker" in locals():
+            gpu_worker.shutdown(wait=True)
         if rank == 0:
             q.put("kill")
             writer.join()

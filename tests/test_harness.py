@@ -167,6 +167,24 @@ def test_zstd_roundtrip_large():
     assert zstd_io.decompress(buf.getvalue()) == payload and len(buf.getvalue()) < len(payload)
 
 
+@pytest.mark.parametrize("threads,chunk", [(1, 4 << 20), (3, 5000), (8, 1 << 16)])
+def test_zstd_parallel_frames_roundtrip(threads, chunk):
+    """The CLI writer: chunks compressed concurrently, written in order as independent frames."""
+    rng = np.random.default_rng(1)
+    payload = b"".join(b"r%d,%d,%f\n" % (i, i * 7, x) for i, x in enumerate(rng.standard_normal(30000)))
+    buf = io.BytesIO()
+    with zstd_io.ParallelZstdWriter(buf, level=3, threads=threads, chunk_bytes=chunk) as w:
+        w.write(b"")                                  # ignored
+        w.write(payload[:10])                         # small writes are coalesced
+        for i in range(10, len(payload), 123457):
+            w.write(memoryview(payload)[i:i + 123457])
+    out = buf.getvalue()
+    assert out[:4] == b"\x28\xb5\x2f\xfd" and zstd_io.decompress(out) == payload and len(out) < len(payload)
+    empty = io.BytesIO()
+    zstd_io.open_writer(empty).close()                # no rows at all: still one valid (empty) frame
+    assert empty.getvalue()[:4] == b"\x28\xb5\x2f\xfd" and zstd_io.decompress(empty.getvalue()) == b""
+
+
 @pytest.mark.parametrize("pore", ["rna004", "dna_r10_400bps"])
 def test_job_generation_and_preprocessing(models, tmp_path, pore):
     _, mean, sd = synth.read_model_file(model_for(models, pore))
