@@ -134,6 +134,36 @@ def test_random_reads_against_oracle(models, pore, nb):
         assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
 
 
+@pytest.mark.parametrize("pore,band,dwell", [("rna004", 400, 0.5), ("dna_r9", 400, 2.5), ("rna004", 100, 0.5),
+                                             ("dna_r10_260bps", 446, 3.0), ("rna002", 30, 1.0)])
+def test_dense_reads_moving_window(models, pore, band, dwell):
+    """Reads longer than the band with 2-3 samples per base: the band window moves in (almost)
+    every other row, so the slot hand-overs of the kernels' window-move blocks (leaving column ->
+    column lo+P, entering column gets its k-mer parameters one row ahead) run back to back."""
+    path = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(path)
+    reads = synth.make_reads(99, 6, pore, mean, sd, (band + 30, band + 500), dwell=dwell)
+    ratio = [(len(r.sequence) - synth.PORES[pore][2] + 2) / (len(r.signal) + 1) for r in reads]
+    assert max(ratio) > 0.3
+    al = Aligner(path, pore, band=band, device=0)
+    orc = Oracle(path, synth.PORES[pore][0], band)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    checked = 0
+    for i, r in enumerate(reads):
+        try:
+            want = orc.align(r.signal, r.sequence, True)
+        except RuntimeError as e:
+            assert res.error(i) == str(e)
+            continue
+        got = res.read(i)
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
+        assert np.array_equal(got["signal_positions"], want["signal_positions"])
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+        checked += 1
+    assert checked >= 3
+
+
 def test_order_and_chunking_invariance(models, al9):
     _, mean, sd = synth.read_model_file(models["syn9"])
     reads = synth.make_reads(77, 24, "rna004", mean, sd, (150, 900))

@@ -124,3 +124,20 @@ def test_oracle_against_compiled_reference_when_present(models):
         ta, tb = orc.train(rd.signal, rd.sequence), ref.train(rd.signal, rd.sequence, orc.num_kmers)
         assert ta["m1"] == tb["m1"] and ta["e2"] == tb["e2"]
         assert np.array_equal(ta["mean"], tb["mean"]) and np.array_equal(ta["stdev"], tb["stdev"])
+
+
+@pytest.mark.parametrize("band,dwell", [(400, 0.5), (100, 0.5), (446, 3.0)])
+def test_oracle_against_compiled_reference_dense_long_reads(models, band, dwell):
+    """The regime of tests/test_gpu_parity.py::test_dense_reads_moving_window: reads longer than the
+    band with 2-3 samples per base (the band window moves in almost every other row)."""
+    from oracle import pyoracle
+    if not pyoracle.reference_available():
+        pytest.skip("oracle/_ref not built here (needs /root/reference)")
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(99, 3, "rna004", mean, sd, (band + 30, band + 500), dwell=dwell)
+    orc, ref = Oracle(models["syn9"], 1, band), pyoracle.Reference(models["syn9"], 1, band)
+    for rd in reads:
+        a, b = orc.align(rd.signal, rd.sequence, True), ref.align(rd.signal, rd.sequence, True)
+        assert a["Z"] == b["Z"] and np.array_equal(a["probabilities"], b["probabilities"])
+        assert np.array_equal(a["signal_positions"], b["signal_positions"])
+        assert np.array_equal(a["sequence_positions"], b["sequence_positions"])
