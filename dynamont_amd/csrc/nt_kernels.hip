@@ -87,13 +87,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 __device__ __forceinline__ double wave_ror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   // mov_dpp: no "old" operand tied to the source, so a still-live source needs no copy first
-#ifdef DYN_EXP_UPDATE_DPP
-  const int rlo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
-  const int rhi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
-#else
   const int rlo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xf, 0xf, false);
   const int rhi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xf, 0xf, false);
-#endif
   return __hiloint2double(rhi, rlo);
 }
 
@@ -480,11 +475,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
-#ifdef DYN_EXP_BITS_SELECT
-        uint64_t mybits = bj[0];
-#pragma unroll
-        for (int j = 1; j < CPL; ++j) mybits = (lane == j) ? bj[j] : mybits;
-#else
         // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much)
         unsigned wlo, whi;
         asm("" : "=v"(wlo), "=v"(whi));  // lanes >= CPL are never stored
@@ -497,7 +487,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         DYN_PUT_BALLOT(4); DYN_PUT_BALLOT(5); DYN_PUT_BALLOT(6);
 #undef DYN_PUT_BALLOT
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
-#endif
 #pragma unroll
         for (int j = 0; j < CPL; ++j) lat_lp[(size_t)t * P + j * 64] = make_float2((float)LPM[j], (float)LPE[j]);
         if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
