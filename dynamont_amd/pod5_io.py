@@ -2,8 +2,9 @@
 loop in ``segment.py:189-258``).
 
 ``pod5`` / ``pysam`` are used when importable. They are not installed in the ROCm image and
-there is no network, so the same interface is also served from a vendor-free synthetic
-container that ``dynamont_amd.synth.write_dataset`` produces:
+there is no network, so ``.pod5`` files are otherwise read by the vendor-free
+``dynamont_amd.pod5_native.Pod5File`` (pyarrow + libzstd + NumPy), and the same interface is also
+served from a synthetic container that ``dynamont_amd.synth.write_dataset`` produces:
 
   raw:        ``<name>.dynraw.npz``  read_ids, offsets, adc (int16), cal_scale, cal_offset
               (pod5 convention: picoampere = (adc + offset) * scale)
@@ -52,14 +53,14 @@ def open_pod5(path: str):
     if path.endswith(".npz"):
         return SynthRawReader(path)
     if _pod5 is None:
-        raise ImportError(f"cannot open {path}: the 'pod5' package is not installed; "
-                          "only the synthetic .dynraw.npz container is readable here")
+        from dynamont_amd.pod5_native import Pod5File  # vendor-free reader (pyarrow + libzstd)
+        return Pod5File(path)
     return _pod5.Reader(path)
 
 
 def get_signal(reader, read_id: str, calibrated: bool = False):
     """pod5_io.py:6-16: ``signal_pa`` when calibrated, raw ADC ``signal`` otherwise."""
-    if isinstance(reader, SynthRawReader):
+    if not hasattr(reader, "reads"):  # SynthRawReader / pod5_native.Pod5File
         return reader.signal(read_id, calibrated)
     record = next(reader.reads(selection=[read_id], missing_ok=False, preload={"samples"}))
     return record.signal_pa if calibrated else record.signal

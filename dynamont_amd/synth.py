@@ -162,7 +162,8 @@ def pack_reads(reads: list[SynthRead]):
 
 
 def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, seed: int = 0,
-                  drop_polya_every: int = 3, lead: int = 37, sm: float = 90.0, sd: float = 15.0):
+                  drop_polya_every: int = 3, lead: int = 37, sm: float = 90.0, sd: float = 15.0,
+                  container: str = "npz"):
     """Write reads as the vendor-free containers of ``dynamont_amd.pod5_io``: ``<name>.dynraw.npz``
     (int16 ADC + calibration) and ``<name>.dynbam.tsv`` (the BAM fields segment.py:222-256 reads).
 
@@ -170,9 +171,13 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
     and every ``drop_polya_every``-th read loses its polyA pad, which the harness must re-add
     (segment.py:155-158). ``lead`` untrimmed samples precede each signal (tag ts).
     Returns (raw_path, basecalls_path, expected) where expected[i] = (normalised float64 signal the
-    harness must reconstruct, aligner-orientation sequence)."""
+    harness must reconstruct, aligner-orientation sequence).
+    ``container="pod5"`` writes ``<name>.pod5`` (``dynamont_amd.pod5_native.write_pod5``, UUID read ids)
+    instead of the .npz container."""
     import os
+    import uuid
     _, rna, _k = PORES[pore]
+    raw_name = f"{name}.pod5" if container == "pod5" else f"{name}.dynraw.npz"
     rng = np.random.default_rng(seed)
     scale, offset = 0.1755, -240.0
     adcs, offs, ids, rows, expected = [], [0], [], [], []
@@ -181,7 +186,7 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
         adc = np.rint(pa / scale - offset).astype(np.int16)
         pre = rng.integers(300, 900, size=lead).astype(np.int16)
         full = np.concatenate([pre, adc])
-        rid = f"read-{seed}-{i:05d}"
+        rid = str(uuid.UUID(int=(seed << 64) | i)) if container == "pod5" else f"read-{seed}-{i:05d}"
         ids.append(rid)
         adcs.append(full)
         offs.append(offs[-1] + len(full))
@@ -193,7 +198,7 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
         else:
             bam_seq = seq
         qs = float(np.round(rng.uniform(8.0, 20.0), 3))
-        rows.append(f"{rid}\t{bam_seq}\t{qs}\t*\t{len(full)}\t{lead}\t*\t{name}.dynraw.npz\t{sm}\t{sd}\n")
+        rows.append(f"{rid}\t{bam_seq}\t{qs}\t*\t{len(full)}\t{lead}\t*\t{raw_name}\t{sm}\t{sd}\n")
         # what the harness reconstructs: float64((adc+offset)*scale in float32), -sm, /sd
         pa32 = (adc.astype(np.float32) + np.float32(offset)) * np.float32(scale)
         x = pa32.astype(np.float64)
@@ -201,9 +206,13 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
         x /= sd
         expected.append((x, seq if not rna else ("A" * 9 + bam_seq[::-1] if not bam_seq[::-1].startswith("A" * 9) else bam_seq[::-1])))
     os.makedirs(outdir, exist_ok=True)
-    raw = os.path.join(outdir, f"{name}.dynraw.npz")
-    np.savez(raw, read_ids=np.array(ids), offsets=np.array(offs, dtype=np.int64), adc=np.concatenate(adcs),
-             cal_scale=np.full(len(reads), scale), cal_offset=np.full(len(reads), offset))
+    raw = os.path.join(outdir, raw_name)
+    if container == "pod5":
+        from dynamont_amd.pod5_native import write_pod5
+        write_pod5(raw, ids, adcs, np.full(len(reads), offset), np.full(len(reads), scale))
+    else:
+        np.savez(raw, read_ids=np.array(ids), offsets=np.array(offs, dtype=np.int64), adc=np.concatenate(adcs),
+                 cal_scale=np.full(len(reads), scale), cal_offset=np.full(len(reads), offset))
     bam = os.path.join(outdir, f"{name}.dynbam.tsv")
     with open(bam, "w") as w:
         w.write("query_name\tsequence\tqs\tpi\tns\tts\tsp\tfn\tsm\tsd\n")
