@@ -318,11 +318,17 @@ DYN_HD void exp_vec(double (&d)[M], double (&out)[M]) {
 template <int M>
 struct EmisV {
   double mean[M], stdev[M], inv_stdev[M], log_stdev[M];
+#ifdef DYN_FAST_EMISSION
+  double cst[M];
+#endif
   DYN_HD void set(int j, const Emis& e) {
     mean[j] = e.mean;
     stdev[j] = e.stdev;
     inv_stdev[j] = e.inv_stdev;
     log_stdev[j] = e.log_stdev;
+#ifdef DYN_FAST_EMISSION
+    cst[j] = -e.log_stdev - 0x1.d67f1c864beb4p-1;
+#endif
   }
 };
 
@@ -330,6 +336,17 @@ template <int M>
 DYN_HD void log_normal_pdf_vec(double x, const EmisV<M>& p, double (&out)[M]) {
   const double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;
   double diff[M], z[M], rem[M];
+#ifdef DYN_FAST_EMISSION
+#pragma unroll
+  for (int j = 0; j < M; ++j) diff[j] = x - p.mean[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) z[j] = diff[j] * p.inv_stdev[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) rem[j] = -0.5 * z[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = fma_(rem[j], z[j], p.cst[j]);
+  return;
+#endif
 #pragma unroll
   for (int j = 0; j < M; ++j) diff[j] = x - p.mean[j];
 #pragma unroll

@@ -150,15 +150,17 @@ constexpr int ROW_BYTES = P * 8;
 constexpr int RING_WAIT = 4 * (RING_D - 1);
 
 // row_lane_ptr = &row[lane*2]; `offset:` advances both the global and the LDS address.
+// Each row is consumed exactly once: the DMA carries the non-temporal hint (-1 % on the kernel).
+#define DYN_DMA_MOD " nt"
 __device__ __forceinline__ void ring_dma_row(const double* row_lane_ptr, unsigned lds_slot_addr) {
   asm volatile(
       "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, off\n\t"
-      "global_load_lds_dwordx4 %0, off offset:1024\n\t"
-      "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %0, off" DYN_DMA_MOD "\n\t"
+      "global_load_lds_dwordx4 %0, off offset:1024" DYN_DMA_MOD "\n\t"
+      "global_load_lds_dwordx4 %0, off offset:2048" DYN_DMA_MOD "\n\t"
       "s_mov_b32 exec_hi, 0\n\t"
-      "global_load_lds_dwordx4 %0, off offset:3072\n\t"
+      "global_load_lds_dwordx4 %0, off offset:3072" DYN_DMA_MOD "\n\t"
       "s_mov_b32 exec_hi, -1\n\t"
       ::"v"(row_lane_ptr), "s"(__builtin_amdgcn_readfirstlane(lds_slot_addr))
       : "memory");
@@ -323,7 +325,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
       for (int j = 0; j < CPL; ++j) {
         bE[j] = ne[j];
         bM[j] = A[j];
-        if (STORE) out[(size_t)t * P + j * 64] = ne[j];
+        // streamed once, read back by k_forward ~70 GB later: non-temporal (-2 % on the kernel)
+        if (STORE) __builtin_nontemporal_store(ne[j], &out[(size_t)t * P + j * 64]);
       }
     }
   }
@@ -475,20 +478,31 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
-        // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much)
+        // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much). All 14
+        // sit in ONE asm block behind an s_nop: the ballots are SGPR pairs written by v_cmp (VALU), and
+        // a v_writelane that reads such an SGPR too soon after the v_cmp picks up stale data -- the
+        // compiler's hazard recogniser does not look inside inline asm (observed: a build that happened
+        // to schedule v_cmp two instructions ahead of the v_writelane produced garbage decision bits).
         unsigned wlo, whi;
-        asm("" : "=v"(wlo), "=v"(whi));  // lanes >= CPL are never stored
-#define DYN_PUT_BALLOT(J)                                                                              \
-  asm("v_writelane_b32 %0, %2, " #J "\n\tv_writelane_b32 %1, %3, " #J                          \
-               : "+v"(wlo), "+v"(whi)                                                                  \
-               : "s"((unsigned)bj[J]), "s"((unsigned)(bj[J] >> 32)))
-        static_assert(CPL == 7, "one DYN_PUT_BALLOT per cell register");
-        DYN_PUT_BALLOT(0); DYN_PUT_BALLOT(1); DYN_PUT_BALLOT(2); DYN_PUT_BALLOT(3);
-        DYN_PUT_BALLOT(4); DYN_PUT_BALLOT(5); DYN_PUT_BALLOT(6);
-#undef DYN_PUT_BALLOT
+        static_assert(CPL == 7, "one v_writelane pair per cell register");
+#define DYN_WL(J, LO, HI) "v_writelane_b32 %0, %" #LO ", " #J "\n\tv_writelane_b32 %1, %" #HI ", " #J "\n\t"
+        asm("s_nop 4\n\t"
+            DYN_WL(0, 2, 3) DYN_WL(1, 4, 5) DYN_WL(2, 6, 7) DYN_WL(3, 8, 9) DYN_WL(4, 10, 11) DYN_WL(5, 12, 13) DYN_WL(6, 14, 15)
+            : "=&v"(wlo), "=&v"(whi)
+            : "s"((unsigned)bj[0]), "s"((unsigned)(bj[0] >> 32)), "s"((unsigned)bj[1]), "s"((unsigned)(bj[1] >> 32)),
+              "s"((unsigned)bj[2]), "s"((unsigned)(bj[2] >> 32)), "s"((unsigned)bj[3]), "s"((unsigned)(bj[3] >> 32)),
+              "s"((unsigned)bj[4]), "s"((unsigned)(bj[4] >> 32)), "s"((unsigned)bj[5]), "s"((unsigned)(bj[5] >> 32)),
+              "s"((unsigned)bj[6]), "s"((unsigned)(bj[6] >> 32)));
+#undef DYN_WL
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) lat_lp[(size_t)t * P + j * 64] = make_float2((float)LPM[j], (float)LPE[j]);
+        for (int j = 0; j < CPL; ++j) {  // read again only by k_trace, one cell per row: non-temporal
+          typedef float dyn_f2 __attribute__((ext_vector_type(2)));
+          dyn_f2 v2;
+          v2.x = (float)LPM[j];
+          v2.y = (float)LPE[j];
+          __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[(size_t)t * P + j * 64]));
+        }
         if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
