@@ -114,27 +114,46 @@ DYN_HD double log_plus(double x, double y) {
 // Per-k-mer emission constants kept with each band slot.
 struct Emis {
   double mean;
-  double stdev;
   double inv_stdev;  // 1/stdev rounded to nearest
-  double log_stdev;  // std::log(stdev) evaluated on the host by the same libm the reference uses
+  double log_norm;   // -log(stdev) - 0.5*log(2*pi); std::log evaluated on the host by the libm the reference calls
+  double stdev;      // only for log_normal_pdf_exact (host tests)
 };
 
-// aligner.cpp:287-292 with the same evaluation order. z = diff/stdev is formed as
-// diff*inv + one FMA residual correction, which reproduces the correctly rounded quotient
-// (Markstein) so the score is bit-identical to the CPU expression in all but vanishingly rare
-// cases, at 3 instructions instead of a ~12-instruction fp64 divide.
-DYN_HD double log_normal_pdf(double x, const Emis& p) {
-  const double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;  // 0.5*log(2*pi) = 0.91893853320467274178
-  const double diff = x - p.mean;
-  double z = diff * p.inv_stdev;
-  const double rem = fma_(-z, p.stdev, diff);
-  z = fma_(rem, p.inv_stdev, z);
+constexpr double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;  // 0.5*log(2*pi) = 0.91893853320467274178
+
+// aligner.cpp:287-292 with the reference's evaluation order: z = diff/stdev formed as diff*inv + one
+// FMA residual correction (= the correctly rounded quotient, Markstein), then
+// (-0.5*z*z - log(stdev)) - 0.5*log(2*pi). Bit-identical to the CPU expression (tests/test_dp_math.py);
+// 8 fp64 operations. Kept as the yardstick for the 4-operation form the kernels run.
+DYN_HD double log_normal_pdf_exact(double x, double mean, double stdev, double log_stdev) {
+  const double inv = 1.0 / stdev;
+  const double diff = x - mean;
+  double z = diff * inv;
+  const double rem = fma_(-z, stdev, diff);
+  z = fma_(rem, inv, z);
   double t = -0.5 * z;
   t = t * z;
-  t = t - p.log_stdev;
+  t = t - log_stdev;
   return t - HALF_LOG_2PI;
 }
 
+// The kernels' emission: z = diff * (1/stdev), e = fma(-0.5*z, z, log_norm): 4 fp64 operations per
+// cell instead of 8. Differs from the expression above by a few ulp of |z^2/2| + |log_norm| (the
+// quotient is not corrected and the two constants are pre-added); the chip is power-limited on fp64
+// operations, and the differences are 1e-16-level, like those of the softplus.
+DYN_HD double log_normal_pdf(double x, const Emis& p) {
+  const double z = (x - p.mean) * p.inv_stdev;
+  return fma_(-0.5 * z, z, p.log_norm);
+}
+
+DYN_HD Emis make_emis(double mean, double stdev, double log_stdev) {
+  Emis e;
+  e.mean = mean;
+  e.inv_stdev = 1.0 / stdev;
+  e.log_norm = -log_stdev - HALF_LOG_2PI;
+  e.stdev = stdev;
+  return e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // "Vector across cells" forms. A wave owns M independent lattice cells per lane; each stage of
@@ -317,52 +336,25 @@ DYN_HD void exp_vec(double (&d)[M], double (&out)[M]) {
 // Structure-of-arrays emission constants of the M cells of a lane.
 template <int M>
 struct EmisV {
-  double mean[M], stdev[M], inv_stdev[M], log_stdev[M];
-#ifdef DYN_FAST_EMISSION
-  double cst[M];
-#endif
+  double mean[M], inv_stdev[M], log_norm[M];
   DYN_HD void set(int j, const Emis& e) {
     mean[j] = e.mean;
-    stdev[j] = e.stdev;
     inv_stdev[j] = e.inv_stdev;
-    log_stdev[j] = e.log_stdev;
-#ifdef DYN_FAST_EMISSION
-    cst[j] = -e.log_stdev - 0x1.d67f1c864beb4p-1;
-#endif
+    log_norm[j] = e.log_norm;
   }
 };
 
 template <int M>
 DYN_HD void log_normal_pdf_vec(double x, const EmisV<M>& p, double (&out)[M]) {
-  const double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;
-  double diff[M], z[M], rem[M];
-#ifdef DYN_FAST_EMISSION
+  double diff[M], z[M], h[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) diff[j] = x - p.mean[j];
 #pragma unroll
   for (int j = 0; j < M; ++j) z[j] = diff[j] * p.inv_stdev[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) rem[j] = -0.5 * z[j];
+  for (int j = 0; j < M; ++j) h[j] = -0.5 * z[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = fma_(rem[j], z[j], p.cst[j]);
-  return;
-#endif
-#pragma unroll
-  for (int j = 0; j < M; ++j) diff[j] = x - p.mean[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) z[j] = diff[j] * p.inv_stdev[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) rem[j] = fma_(-z[j], p.stdev[j], diff[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) z[j] = fma_(rem[j], p.inv_stdev[j], z[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) diff[j] = -0.5 * z[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) diff[j] = diff[j] * z[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) diff[j] = diff[j] - p.log_stdev[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = diff[j] - HALF_LOG_2PI;
+  for (int j = 0; j < M; ++j) out[j] = fma_(h[j], z[j], p.log_norm[j]);
 }
 
 }  // namespace dynmath

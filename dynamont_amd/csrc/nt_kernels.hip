@@ -125,11 +125,11 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   Emis e;
   if (n >= 1 && n < N) {
     e = pr[n - 1];
-  } else {  // column without a k-mer (n <= 0 or n >= N): log-density -inf (log_stdev = +inf)
+  } else {  // column without a k-mer (n <= 0 or n >= N): log-density -inf (log_norm = -inf)
     e.mean = 0.0;
-    e.stdev = 1.0;
     e.inv_stdev = 1.0;
-    e.log_stdev = -NEG_INF;
+    e.log_norm = NEG_INF;
+    e.stdev = 1.0;
   }
   return e;
 }
@@ -384,7 +384,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   // Band edges without per-row masks. Lower edge: the slot of a column that leaves the band is
   // handed to column lo+P. Upper edge: a slot carries the k-mer parameters of its column only from
   // the row in which the column ENTERS the band; before that it carries the "no k-mer" parameters
-  // (log_stdev = +inf), hence e = -inf, hence fM = fE = LPM = LPE = vM = vE = -inf in that slot with
+  // (log_norm = -inf), hence e = -inf, hence fM = fE = LPM = LPE = vM = vE = -inf in that slot with
   // no select in the row loop. Both hand-overs happen in the rare block that looks one row ahead.
   int lo = band_mid(1, ratio) - bw;  // band of row 1 (column 0 of row 0 is inside: band_mid(1) <= 1 <= bw)
   int n[CPL];

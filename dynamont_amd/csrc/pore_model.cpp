@@ -111,12 +111,8 @@ void PoreModel::load(const std::string& path, int pore_id, uint64_t band) {
 
   table.resize(num_kmers);
   for (uint64_t i = 0; i < num_kmers; ++i) {
-    dynmath::Emis e;
-    e.mean = mean[i];
-    e.stdev = stdev[i];
-    e.inv_stdev = 1.0 / stdev[i];
-    e.log_stdev = std::log(stdev[i]);  // same libm call the reference makes per cell (aligner.cpp:291)
-    table[i] = e;
+    // std::log: the same libm call the reference makes per cell (aligner.cpp:291)
+    table[i] = dynmath::make_emis(mean[i], stdev[i], std::log(stdev[i]));
   }
 }
 
