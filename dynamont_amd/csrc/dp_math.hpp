@@ -213,13 +213,13 @@ DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNod
 #pragma unroll
   for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0, 1.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = (uw[j] * q[j]) * (1.0 / 120.0);
+  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0, 1.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = (u[j] * q[j]) * (1.0 / 24.0);
+  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
 #pragma unroll
   for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], q[j]);
 #pragma unroll
@@ -274,13 +274,13 @@ DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
 #pragma unroll
   for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0, 1.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = (uw[j] * q[j]) * (1.0 / 120.0);
+  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0, 1.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = (u[j] * q[j]) * (1.0 / 24.0);
+  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
 #pragma unroll
   for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], q[j]);
 #pragma unroll
