@@ -141,7 +141,7 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
 // AGPRs mid-row). The rows now go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, 3 full +
 // 1 half-wave instruction per 3584-byte row), RING_D rows ahead, and are picked up with ds_read_b64
 // behind a hand-counted s_waitcnt. Validated in isolation by tools/ubench/lds_dma_test.hip.
-constexpr int RING_D = 4;
+constexpr int RING_D = 4;  // 2..5 rows deep measure the same: the kernel is bandwidth-, not latency-bound
 constexpr int ROW_BYTES = P * 8;
 // vmcnt(N) lets the N youngest vector-memory operations stay in flight. Only the DMA instructions
 // themselves are counted (4 per row, RING_D-1 younger rows => 12): loads retire in issue order, so
