@@ -111,6 +111,9 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = n_gpus > 1 or bool(os.environ.get("DYN_BENCH_FORCE_DIST"))
     if use_dist:
+        if n_gpus == 1:  # DYN_BENCH_FORCE_DIST without a launcher: a one-rank group on the loopback
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29561")):
+                os.environ.setdefault(key, val)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
