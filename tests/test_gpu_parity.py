@@ -164,6 +164,41 @@ def test_dense_reads_moving_window(models, pore, band, dwell):
     assert checked >= 3
 
 
+@pytest.mark.parametrize("pore,band", [("dna_r9", 4), ("dna_r9", 7), ("rna002", 10), ("dna_r9", 31), ("rna004", 60),
+                                       ("dna_r10_260bps", 199), ("rna002", 446)])
+def test_small_bands_and_tiny_reads_fuzz(models, pore, band):
+    """Property check of the band logic: many short reads of every length class (sequence barely
+    longer than k, band wider than / equal to / much narrower than the read, 2-4 samples per base up
+    to the default dwell) against the oracle, one batch per band."""
+    path = model_for(models, pore)
+    k = synth.PORES[pore][2]
+    _, mean, sd = synth.read_model_file(path)
+    rng = np.random.default_rng(band)
+    reads = []
+    for i in range(48):
+        nb = int(rng.choice([k, k + 1, k + 2, k + 5, band // 2 + k, band + k - 1, band + k, band + k + 1, 2 * band + k + 3, 3 * band + 40]))
+        dwell = float(rng.choice([0.5, 2.0, 3.5, 10.0]))
+        reads += synth.make_reads(1000 * band + i, 1, pore, mean, sd, max(nb, k), dwell=dwell)
+    al = Aligner(path, pore, band=band, device=0)
+    orc = Oracle(path, synth.PORES[pore][0], band)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    ok = 0
+    for i, r in enumerate(reads):
+        try:
+            want = orc.align(r.signal, r.sequence, True)
+        except RuntimeError as e:
+            assert res.error(i) == str(e), (i, len(r.sequence), len(r.signal))
+            continue
+        assert res.status[i] == 0, (i, len(r.sequence), len(r.signal), res.error(i))
+        got = res.read(i)
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), (i, len(r.sequence), len(r.signal))
+        assert np.array_equal(got["signal_positions"], want["signal_positions"]), (i, len(r.sequence), len(r.signal))
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+        ok += 1
+    assert ok >= 24
+
+
 def test_order_and_chunking_invariance(models, al9):
     _, mean, sd = synth.read_model_file(models["syn9"])
     reads = synth.make_reads(77, 24, "rna004", mean, sd, (150, 900))
