@@ -11,6 +11,7 @@
 #include "../../include/dynamont_mi.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -377,8 +378,13 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
   dyn_batch* b = new dyn_batch();
   b->a = a;
   b->n = n_reads;
+  // DYN_TRACE_HOST=1: wall time of the host stages of batch creation on stderr (tools/batch_latency.py)
+  static const bool trace_host = std::getenv("DYN_TRACE_HOST") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now_ms();
   prepare_reads(a->model, n_reads, sig_offsets, seqs, seq_offsets, b->reads, b->kmers, &b->capacity,
                 &b->total_cols);
+  const double t_prepared = now_ms();
   for (const HostRead& r : b->reads) {
     if (r.status != DYN_READ_OK) continue;
     if (r.S + 1 > 0x7fffffffull || r.kc + 1 > 0x7fffffffull) {
@@ -440,8 +446,12 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
   }
   B_TRY(b->d_state.ensure(std::max<uint64_t>(sizeof(ReadState), n_reads * sizeof(ReadState))));
   B_TRY(b->d_rows.ensure(std::max<uint64_t>(sizeof(SegRow), b->capacity * sizeof(SegRow))));
+  const double t_enqueued = now_ms();
   B_TRY(hipStreamSynchronize(a->stream));
 #undef B_TRY
+  if (trace_host)
+    std::fprintf(stderr, "[dyn] batch create: validate+encode %.2f ms, alloc+enqueue (H2D of pageable memory is synchronous) %.2f ms, drain %.2f ms\n",
+                 t_prepared - t_start, t_enqueued - t_prepared, now_ms() - t_enqueued);
   *out = b;
   return DYN_OK;
 }
