@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 SURVEY_BYTES_PER_CELL = 64.125   # three-pass fp64 formulation, whole align()
-KFWD_BYTES_PER_CELL = 16.125     # this design, dominant kernel: read bE 8 B + write (LPM,LPE) 8 B + 1 bit
+KFWD_BYTES_PER_CELL = 12.125     # this design, dominant kernel: read bE 8 B + write float LPE 4 B + 1 bit
 KBWD_BYTES_PER_CELL = 8.0        # this design: write bE
 
 
@@ -230,7 +230,7 @@ def main():
             "k_backward": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "avg_launch_ms": round(ms_bwd, 3),
                            "achieved": round(cells * KBWD_BYTES_PER_CELL / (ms_bwd * 1e-3) / 1e9, 1)},
             # SURVEY.md §8(d) prices the whole align() of the three-pass formulation at 64.125 B/cell;
-            # this design moves 24.125 B/cell, so the survey-normalised figure exceeds real traffic.
+            # this design moves 20.125 B/cell, so the survey-normalised figure exceeds real traffic.
             "survey_8d_whole_path": {"bytes_per_cell": SURVEY_BYTES_PER_CELL, "ms_all_kernels": round(ms_all, 3),
                                      "achieved": round(cells * SURVEY_BYTES_PER_CELL / (ms_all * 1e-3) / 1e9, 1),
                                      "frac": round(cells * SURVEY_BYTES_PER_CELL / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

@@ -84,7 +84,7 @@ struct dyn_aligner {
   uint64_t mem_budget = 0;
   std::string last_error;
   // grow-only lattice workspace pool, reused across batches
-  DevBuf ws, bits, pp, pathn, descs;
+  DevBuf ws, lpe, bits, pp, pathn, descs;
 };
 
 struct HostRead {
@@ -171,8 +171,8 @@ void prepare_reads(const PoreModel& m, uint64_t n, const uint64_t* sig_offsets, 
 struct Chunk { std::vector<uint32_t> idx; };
 
 uint64_t lattice_bytes_per_row(bool calc) {
-  // [T][P] slots (8 B) + decision bits + per-row path arrays
-  return calc ? (uint64_t)dynk::P * 8 + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
+  // [T][P] bE slots (8 B) + float LPE per slot + decision bits + per-row path arrays
+  return calc ? (uint64_t)dynk::P * 12 + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
 }
 
 }  // namespace
@@ -266,6 +266,7 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->d_model.release();
     a->d_sptab.release();
     a->ws.release();
+    a->lpe.release();
     a->bits.release();
     a->pp.release();
     a->pathn.release();
@@ -556,7 +557,7 @@ int run_job(dyn_batch* b, Job job) {
   if (lattice) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t pool = a->ws.bytes + a->bits.bytes + a->pp.bytes + a->pathn.bytes;
+    const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + a->pp.bytes + a->pathn.bytes;
     const uint64_t avail = (uint64_t)((double)(free_b + pool) * 0.90);
     if (budget == 0 || budget > avail) budget = avail;
   }
@@ -627,6 +628,7 @@ int run_job(dyn_batch* b, Job job) {
     HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
     if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8, headroom));
     if (calc) {
+      HIP_TRY(a, a->lpe.ensure(ws_rows * dynk::P * 4, headroom));
       HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8, headroom));
       HIP_TRY(a, a->pp.ensure(rows_total * 8, headroom));
       HIP_TRY(a, a->pathn.ensure(rows_total * 4, headroom));
@@ -646,14 +648,14 @@ int run_job(dyn_batch* b, Job job) {
       dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
       dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     } else {
-      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
+      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->lpe.as<float>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     }
     HIP_TRY(a, hipEventRecord(ev[2], a->stream));
     if (calc) {
       dynk::TraceBuffers tb{a->pp.as<double>(), a->pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
                             b->d_medhi.as<double>(), b->d_medlo.as<double>()};
-      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), a->bits.as<uint64_t>(), dst, tb,
-                         b->d_rows.as<SegRow>(), m.k, z_fail, a->stream);
+      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), a->lpe.as<float>(), a->bits.as<uint64_t>(), sig, par, dst, tb,
+                         b->d_rows.as<SegRow>(), m.k, m.log_m1, z_fail, a->stream);
     } else {
       dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
       if (job == Job::Train) {

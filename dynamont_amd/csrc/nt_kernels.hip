@@ -357,7 +357,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par,
                                                  const double* __restrict__ ws_rd,
-                                                 float2* __restrict__ ws_wr,
+                                                 float* __restrict__ lp_out,
                                                  uint64_t* __restrict__ bits,
                                                  ReadState* __restrict__ st, double m1,
                                                  double e2, const SoftplusNode* __restrict__ sp_tab,
@@ -371,13 +371,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  // ws_rd / ws_wr are the SAME workspace: row t+2 (bE) is read while row t is overwritten in
-  // place with (float LPM, float LPE). They are separate __restrict__ parameters on purpose: with a
-  // pointer derived from the load pointer hipcc orders every prefetch behind the previous row's
-  // stores (s_waitcnt vmcnt(0) at the top of each row = 43 % of the wave's lifetime spent waiting).
-  // No address is ever read after it has been written within one launch.
+  // The bE rows stay intact; the kernel writes ONE float per slot, LPE, into its own array (same
+  // [row][row_pos] indexing). k_trace needs the posterior of one cell per row: LPE for the E cells
+  // of the path, and for the ~10 % M cells (segment starts) it rebuilds LPM from LPE of the diagonal
+  // predecessor and the bE rows (see k_trace). Storing (LPM, LPE) for every slot, as an earlier
+  // build did in place, made this kernel HBM-bound: 16 B per slot per row instead of 12.
   const double* __restrict__ lat = ws_rd + rd.ws_off + lane;
-  float2* __restrict__ lat_lp = ws_wr + rd.ws_off + lane;
+  float* __restrict__ lat_lp = lp_out + rd.ws_off + lane;
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
 
@@ -496,13 +496,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
 #undef DYN_WL
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {  // read again only by k_trace, one cell per row: non-temporal
-          typedef float dyn_f2 __attribute__((ext_vector_type(2)));
-          dyn_f2 v2;
-          v2.x = (float)LPM[j];
-          v2.y = (float)LPE[j];
-          __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[(size_t)t * P + j * 64]));
-        }
+        for (int j = 0; j < CPL; ++j)  // read again only by k_trace, one cell per row: non-temporal
+          __builtin_nontemporal_store((float)LPE[j], &lat_lp[(size_t)t * P + j * 64]);
         if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -556,7 +551,7 @@ __global__ void k_zcheck(const ReadDesc* __restrict__ descs, int n_reads,
 // 64 rows of bits are staged in LDS per step so the serial walk pays LDS, not HBM, latency.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_trace(const ReadDesc* __restrict__ descs,
-                                               const double* __restrict__ ws,
+                                               const float* __restrict__ lpe,
                                                const uint64_t* __restrict__ bits,
                                                ReadState* __restrict__ st, TraceBuffers tb,
                                                int fail_status) {
@@ -573,7 +568,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     return;
   }
   const int T = (int)rd.T, N = (int)rd.N;
-  const float2* __restrict__ lp = reinterpret_cast<const float2*>(ws + rd.ws_off);
+  const float* __restrict__ lp = lpe + rd.ws_off;     // LPE rows [T][P], indexed like the bE rows
   const uint64_t* __restrict__ bt = bits + rd.bits_off;
   double* __restrict__ pp = tb.pp + rd.path_off;
   uint32_t* __restrict__ pathn = tb.pathn + rd.path_off;
@@ -629,8 +624,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     if (my_st >= 0) {
-      const float2 v = lp[(size_t)row * P + row_pos(my_slot)];
-      pp[row] = exp((double)(my_st ? v.x : v.y));
+      // E cell of the path: k_forward stored its log-posterior. M cells (segment starts, ~1 row in 10)
+      // get theirs from k_mpost, one thread per segment, instead of ~6 dependent loads in this walk.
+      if (my_st == 0) pp[row] = exp((double)lp[(size_t)row * P + row_pos(my_slot)]);
       pathn[row] = (uint32_t)my_n | (my_st ? 0x80000000u : 0u);
       if (my_st) segrow[my_n - 1] = (uint32_t)row;
     }
@@ -641,6 +637,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     st[rd.read].status = complete ? 0 : 7;
     st[rd.read].n_segments = complete ? (uint32_t)(N - 1) : 0;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_mpost: posterior of the M cell (segment start) of every segment. k_forward stores only LPE; the
+// M cell (row, n) is preceded on the path by the E cell (row-1, n-1), so
+//   fE(row-1, n-1) = LPE(row-1, n-1) - bE(row-1, n-1) + Zb      (NT_aligner_api.cpp:222 solved for fE)
+//   fM(row, n)     = (fE(row-1, n-1) + e(row, n)) + m1            (:146)
+//   bM(row, n)     = bE(row+1, n) + e(row+1, n)                   (:200; row T of the workspace is -inf)
+//   LPM(row, n)    = (fM + bM) - Zb                               (:222)
+// The float LPE costs <= 6e-8 * |LPE| here; every other term is fp64. One thread per segment.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mpost(const ReadDesc* __restrict__ descs, const double* __restrict__ ws,
+                        const float* __restrict__ lpe, const double* __restrict__ sig,
+                        const Emis* __restrict__ par, const ReadState* __restrict__ st, TraceBuffers tb,
+                        double m1) {
+  const ReadDesc rd = descs[blockIdx.y];
+  const ReadState s = st[rd.read];
+  if (s.status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x + 1;  // lattice column of the segment, 1 .. N-1
+  if (n >= N) return;
+  const double* __restrict__ bE = ws + rd.ws_off;
+  const float* __restrict__ lp = lpe + rd.ws_off;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const int row = (int)tb.segrow[rd.seg_off + n - 1];
+  const int slot = n % P, pslot = (n - 1) % P;
+  const size_t pcell = (size_t)(row - 1) * P + row_pos(pslot);
+  const double fE_prev = row == 1 ? (n == 1 ? 0.0 : NEG_INF)  // fE(0, 0) = 0, nothing else in row 0 (:120)
+                                  : ((double)lp[pcell] - bE[pcell]) + s.Zb;
+  const Emis em = par[rd.par_off + n - 1];
+  const double e_here = dynmath::log_normal_pdf(sg[row - 1], em);
+  const double e_next = row + 1 < T ? dynmath::log_normal_pdf(sg[row], em) : NEG_INF;
+  const double fM = (fE_prev + e_here) + m1;
+  const double bM = bE[(size_t)(row + 1) * P + row_pos(slot)] + e_next;
+  tb.pp[rd.path_off + row] = exp((fM + bM) - s.Zb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -980,14 +1011,14 @@ void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, cons
 }
 
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    double* ws, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
+                    const double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
                     const SoftplusNode* sp_tab, hipStream_t s) {
   if (n_reads <= 0) return;
   const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
   if (post)
-    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, (const double*)ws, reinterpret_cast<float2*>(ws), bits, st, m1, e2, sp_tab, n_reads);
+    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, (const double*)ws, lpe, bits, st, m1, e2, sp_tab, n_reads);
   else
-    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, (const double*)ws, reinterpret_cast<float2*>(ws), bits, st, m1, e2, sp_tab, n_reads);
+    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, (const double*)ws, lpe, bits, st, m1, e2, sp_tab, n_reads);
 }
 
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
@@ -1014,10 +1045,12 @@ void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail
 }
 
 void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
-                  const double* ws, const uint64_t* bits, ReadState* st, TraceBuffers tb,
-                  SegRow* rows, int kmer_size, int z_fail_status, hipStream_t s) {
+                  const double* ws, const float* lpe, const uint64_t* bits, const double* sig, const Emis* par,
+                  ReadState* st, TraceBuffers tb, SegRow* rows, int kmer_size, double m1, int z_fail_status,
+                  hipStream_t s) {
   if (n_reads <= 0) return;
-  hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, ws, bits, st, tb, z_fail_status);
+  hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, lpe, bits, st, tb, z_fail_status);
+  hipLaunchKernelGGL(k_mpost, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, ws, lpe, sig, par, st, tb, m1);
   hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb);
   hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb, rows,
                      kmer_size);

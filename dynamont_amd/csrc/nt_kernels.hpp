@@ -74,15 +74,17 @@ void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint
 void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                      double* ws, ReadState* st, double m1, double e2, bool store,
                      const dynmath::SoftplusNode* sp_tab, hipStream_t s);
+// lpe: float [rows][P] log-posterior of state E per slot (written when post), indexed like ws
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    double* ws, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
+                    const double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
                     const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                           const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
                           const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
-                  const double* ws, const uint64_t* bits, ReadState* st, TraceBuffers tb,
-                  SegRow* rows, int kmer_size, int z_fail_status, hipStream_t s);
+                  const double* ws, const float* lpe, const uint64_t* bits, const double* sig, const Emis* par,
+                  ReadState* st, TraceBuffers tb, SegRow* rows, int kmer_size, double m1, int z_fail_status,
+                  hipStream_t s);
 void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,
                    hipStream_t s);
 // pooled[3*num_kmers] += per-k-mer (w, s1, s2) of the reads in descs (fp64 atomics)
