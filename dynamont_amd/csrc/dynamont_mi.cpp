@@ -170,9 +170,9 @@ void prepare_reads(const PoreModel& m, uint64_t n, const uint64_t* sig_offsets, 
 
 struct Chunk { std::vector<uint32_t> idx; };
 
-uint64_t lattice_bytes_per_row(bool calc) {
-  // [T][P] bE slots (8 B) + float LPE per slot + decision bits + per-row path arrays
-  return calc ? (uint64_t)dynk::P * 12 + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
+uint64_t lattice_bytes_per_row(bool calc, bool lpe_separate) {
+  // [T][P] bE slots (8 B) [+ float LPE per slot] + decision bits + per-row path arrays
+  return calc ? (uint64_t)dynk::P * (lpe_separate ? 12 : 8) + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
 }
 
 }  // namespace
@@ -561,7 +561,16 @@ int run_job(dyn_batch* b, Job job) {
     const uint64_t avail = (uint64_t)((double)(free_b + pool) * 0.90);
     if (budget == 0 || budget > avail) budget = avail;
   }
-  const uint64_t row_bytes = lattice_bytes_per_row(calc);
+  // Posterior layout (nt_kernels.hip, k_forward): the separate float LPE array makes k_forward 17 %
+  // faster but costs 12 instead of 8 bytes of HBM per band slot. When the batch does not fit one
+  // launch that way, more reads per launch are worth more than the faster kernel: in place then.
+  bool lpe_separate = calc;
+  if (calc) {
+    uint64_t need_sep = 0;
+    for (uint32_t i : order) need_sep += (b->reads[i].S + 2) * lattice_bytes_per_row(true, true);
+    if (need_sep > budget) lpe_separate = false;
+  }
+  const uint64_t row_bytes = lattice_bytes_per_row(calc, lpe_separate);
 
   // greedy chunks in LPT order
   std::vector<Chunk> chunks;
@@ -628,7 +637,7 @@ int run_job(dyn_batch* b, Job job) {
     HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
     if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8, headroom));
     if (calc) {
-      HIP_TRY(a, a->lpe.ensure(ws_rows * dynk::P * 4, headroom));
+      if (lpe_separate) HIP_TRY(a, a->lpe.ensure(ws_rows * dynk::P * 4, headroom));
       HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8, headroom));
       HIP_TRY(a, a->pp.ensure(rows_total * 8, headroom));
       HIP_TRY(a, a->pathn.ensure(rows_total * 4, headroom));
@@ -648,13 +657,13 @@ int run_job(dyn_batch* b, Job job) {
       dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
       dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     } else {
-      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), a->lpe.as<float>(), a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
+      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
     }
     HIP_TRY(a, hipEventRecord(ev[2], a->stream));
     if (calc) {
       dynk::TraceBuffers tb{a->pp.as<double>(), a->pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
                             b->d_medhi.as<double>(), b->d_medlo.as<double>()};
-      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), a->lpe.as<float>(), a->bits.as<uint64_t>(), sig, par, dst, tb,
+      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), sig, par, dst, tb,
                          b->d_rows.as<SegRow>(), m.k, m.log_m1, z_fail, a->stream);
     } else {
       dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
@@ -676,6 +685,7 @@ int run_job(dyn_batch* b, Job job) {
     tm.ms_total += ms01 + ms12 + ms23;
     tm.launches_backward += 1;
     tm.launches_forward += 1;
+    tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
   }
   tm.reads_ok = order.size();
   b->timing = tm;

@@ -352,7 +352,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
 // Masks: emission -inf for k-mer-less columns covers n < 1 and n >= N; a column's state is reset
 // to -inf when it leaves the band; the upper band edge masks the value taken from column n-1.
 // ---------------------------------------------------------------------------------------------
-template <bool POST>
+// INPLACE (only with POST): see the comment at lat_lp below
+template <bool POST, bool INPLACE>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ descs,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par,
@@ -371,13 +372,19 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  // The bE rows stay intact; the kernel writes ONE float per slot, LPE, into its own array (same
-  // [row][row_pos] indexing). k_trace needs the posterior of one cell per row: LPE for the E cells
-  // of the path, and for the ~10 % M cells (segment starts) it rebuilds LPM from LPE of the diagonal
-  // predecessor and the bE rows (see k_trace). Storing (LPM, LPE) for every slot, as an earlier
-  // build did in place, made this kernel HBM-bound: 16 B per slot per row instead of 12.
+  // Two layouts for the log-posteriors k_trace needs (one cell per row):
+  //  * separate (default): the bE rows stay intact and ONE float per slot, LPE, goes to its own array
+  //    (same [row][row_pos] indexing); the ~10 % M cells of the path (segment starts) get LPM rebuilt
+  //    from LPE of the diagonal predecessor and two bE cells (k_mpost). 12 B per slot per row here.
+  //  * INPLACE: (float LPM, float LPE) overwrite the bE slot of row t while rows t+1.. are still
+  //    being read (lp_out then aliases ws_rd; no address is read after it has been written within one
+  //    launch). 16 B per slot per row make this kernel HBM-bound, but the footprint is 8 instead of
+  //    12 B per slot: the host picks it when the separate layout would not fit the batch in one launch.
+  // ws_rd and lp_out are separate __restrict__ parameters on purpose: with a pointer derived from
+  // the load pointer hipcc orders every prefetch behind the previous row's stores (s_waitcnt vmcnt(0)
+  // at the top of each row = 43 % of the wave's lifetime spent waiting).
   const double* __restrict__ lat = ws_rd + rd.ws_off + lane;
-  float* __restrict__ lat_lp = lp_out + rd.ws_off + lane;
+  float* __restrict__ lat_lp = lp_out + (INPLACE ? 2 : 1) * (rd.ws_off + lane);
   uint64_t* __restrict__ bt = bits + rd.bits_off;
   const double Z = POST ? st[rd.read].Zb : 0.0;
 
@@ -496,8 +503,17 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
 #undef DYN_WL
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)  // read again only by k_trace, one cell per row: non-temporal
-          __builtin_nontemporal_store((float)LPE[j], &lat_lp[(size_t)t * P + j * 64]);
+        for (int j = 0; j < CPL; ++j) {  // read again only by k_trace, one cell per row: non-temporal
+          if (INPLACE) {
+            typedef float dyn_f2 __attribute__((ext_vector_type(2)));
+            dyn_f2 v2;
+            v2.x = (float)LPM[j];
+            v2.y = (float)LPE[j];
+            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * ((size_t)t * P + j * 64)]));
+          } else {
+            __builtin_nontemporal_store((float)LPE[j], &lat_lp[(size_t)t * P + j * 64]);
+          }
+        }
         if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                                const float* __restrict__ lpe,
                                                const uint64_t* __restrict__ bits,
                                                ReadState* __restrict__ st, TraceBuffers tb,
-                                               int fail_status) {
+                                               int fail_status, int inplace) {
   __shared__ uint64_t sb[64 * CPL];
   const ReadDesc rd = descs[blockIdx.x];
   const int lane = threadIdx.x;
@@ -568,7 +584,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     return;
   }
   const int T = (int)rd.T, N = (int)rd.N;
-  const float* __restrict__ lp = lpe + rd.ws_off;     // LPE rows [T][P], indexed like the bE rows
+  // separate layout: float LPE rows [T][P]; in-place layout: (float LPM, float LPE) in the 8-byte bE slots
+  const float* __restrict__ lp = lpe + (inplace ? 2 : 1) * rd.ws_off;
   const uint64_t* __restrict__ bt = bits + rd.bits_off;
   double* __restrict__ pp = tb.pp + rd.path_off;
   uint32_t* __restrict__ pathn = tb.pathn + rd.path_off;
@@ -626,7 +643,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (my_st >= 0) {
       // E cell of the path: k_forward stored its log-posterior. M cells (segment starts, ~1 row in 10)
       // get theirs from k_mpost, one thread per segment, instead of ~6 dependent loads in this walk.
-      if (my_st == 0) pp[row] = exp((double)lp[(size_t)row * P + row_pos(my_slot)]);
+      const size_t cell = (size_t)row * P + row_pos(my_slot);
+      if (inplace) pp[row] = exp((double)lp[2 * cell + (my_st ? 0 : 1)]);
+      else if (my_st == 0) pp[row] = exp((double)lp[cell]);
       pathn[row] = (uint32_t)my_n | (my_st ? 0x80000000u : 0u);
       if (my_st) segrow[my_n - 1] = (uint32_t)row;
     }
@@ -1011,14 +1030,17 @@ void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, cons
 }
 
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    const double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
+                    double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
                     const SoftplusNode* sp_tab, hipStream_t s) {
   if (n_reads <= 0) return;
   const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
-  if (post)
-    hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, descs, sig, par, (const double*)ws, lpe, bits, st, m1, e2, sp_tab, n_reads);
-  else
-    hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, descs, sig, par, (const double*)ws, lpe, bits, st, m1, e2, sp_tab, n_reads);
+  const double* rd = ws;
+  if (!post)
+    hipLaunchKernelGGL((k_forward<false, false>), grid, block, 0, s, descs, sig, par, rd, (float*)nullptr, bits, st, m1, e2, sp_tab, n_reads);
+  else if (lpe)
+    hipLaunchKernelGGL((k_forward<true, false>), grid, block, 0, s, descs, sig, par, rd, lpe, bits, st, m1, e2, sp_tab, n_reads);
+  else  // in place: the log-posteriors overwrite the bE rows
+    hipLaunchKernelGGL((k_forward<true, true>), grid, block, 0, s, descs, sig, par, rd, reinterpret_cast<float*>(ws), bits, st, m1, e2, sp_tab, n_reads);
 }
 
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
@@ -1049,8 +1071,12 @@ void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t m
                   ReadState* st, TraceBuffers tb, SegRow* rows, int kmer_size, double m1, int z_fail_status,
                   hipStream_t s) {
   if (n_reads <= 0) return;
-  hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, lpe, bits, st, tb, z_fail_status);
-  hipLaunchKernelGGL(k_mpost, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, ws, lpe, sig, par, st, tb, m1);
+  if (lpe) {
+    hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, lpe, bits, st, tb, z_fail_status, 0);
+    hipLaunchKernelGGL(k_mpost, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, ws, lpe, sig, par, st, tb, m1);
+  } else {
+    hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, reinterpret_cast<const float*>(ws), bits, st, tb, z_fail_status, 1);
+  }
   hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb);
   hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb, rows,
                      kmer_size);

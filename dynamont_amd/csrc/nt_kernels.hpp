@@ -74,9 +74,10 @@ void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint
 void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                      double* ws, ReadState* st, double m1, double e2, bool store,
                      const dynmath::SoftplusNode* sp_tab, hipStream_t s);
-// lpe: float [rows][P] log-posterior of state E per slot (written when post), indexed like ws
+// lpe != nullptr: float [rows][P] log-posterior of state E per slot, indexed like ws (ws stays intact);
+// lpe == nullptr (with post): (float LPM, float LPE) overwrite the 8-byte slots of ws in place
 void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    const double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
+                    double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
                     const dynmath::SoftplusNode* sp_tab, hipStream_t s);
 void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
                           const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,

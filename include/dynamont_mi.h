@@ -137,7 +137,8 @@ typedef struct dyn_timing {
   uint64_t samples;      /* sum of signal lengths over ok reads */
   uint64_t reads_ok;
   uint32_t launches_backward, launches_forward; /* >1 when the batch was split to fit HBM */
-  uint32_t reserved;
+  uint32_t lp_inplace;   /* 1: the batch did not fit one launch with the separate LPE array (12 B per band slot),
+                            the posteriors overwrote the backward rows in place (8 B per slot, slower kernel) */
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
