@@ -17,12 +17,13 @@
 //   K_fwd  walks t = 1..T-1 and fuses forward, posterior (needs Zb, known after K_bwd),
 //          the posterior-Viterbi fill and the traceback decision
 //          (vE == vM_prev + LPE, NT_aligner_api.cpp:448); forward / Viterbi rows never leave
-//          registers; it overwrites each bE row in place with (float LPM, float LPE) for the
-//          path-probability lookup and writes 1 decision bit per cell;
+//          registers; per cell it writes one float, LPE, for the path-probability lookup and
+//          1 decision bit (footprint-limited batches: (float LPM, float LPE) over the bE slot);
 //   K_trace walks the decision bits back one SEGMENT per step (ballot + find-first-set inside
-//          64-row LDS blocks) and K_median/K_final produce the per-segment median posterior.
-// HBM traffic is 24.1 B per in-band cell instead of the 64.1 B of the three-pass formulation
-// (SURVEY.md §8d), and the per-read footprint is 8 B per slot instead of 64 B per cell.
+//          64-row LDS blocks), K_mpost rebuilds LPM for the segment starts, K_median/K_final
+//          produce the per-segment median posterior.
+// HBM traffic is 20.1 B per in-band cell instead of the 64.1 B of the three-pass formulation
+// (SURVEY.md §8d), and the per-read footprint is 12 B per slot instead of 64 B per cell.
 //
 // Mapping: one 64-lane wave owns one read, four reads share a 256-thread workgroup (one wave per
 // SIMD). Band slot s = n mod P lives in lane s / CPL, register s % CPL: a lane owns CPL CONSECUTIVE
@@ -221,7 +222,7 @@ __global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __r
 //   bE(t,n)   = logPlus( (bM(t+1,n+1) + e(t+1,n+1)) + m1 ,    (n+1 < N)          :192-195
 //                        (bE(t+1,n)   + e(t+1,n))   + e2 )    (n > 0)            :201
 // Columns without a k-mer (n <= 0, n >= N) carry emission -inf, which realises the n > 0 and
-// n+1 < N guards arithmetically; the only mask left is the upper band edge.
+// n+1 < N guards arithmetically; the upper band edge is handled in the window-move block.
 // ---------------------------------------------------------------------------------------------
 template <bool STORE>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ descs,
@@ -349,8 +350,9 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
 //   LPM      = (fM + bM) - Zb,  LPE = (fE + bE) - Zb                              :222
 //   vM(t,n)  = vE(t-1,n-1) + LPM ;  vE(t,n) = max(vM(t-1,n), vE(t-1,n)) + LPE     :360-361
 //   bit(t,n) = ( vE(t,n) == vM(t-1,n) + LPE )                                     :448
-// Masks: emission -inf for k-mer-less columns covers n < 1 and n >= N; a column's state is reset
-// to -inf when it leaves the band; the upper band edge masks the value taken from column n-1.
+// Masks: none per row. Emission -inf for k-mer-less columns covers n < 1 and n >= N, and a slot
+// carries its column's k-mer parameters only while the column is inside the band (hand-over in the
+// window-move block that looks one row ahead), so e = -inf empties every out-of-band slot.
 // ---------------------------------------------------------------------------------------------
 // INPLACE (only with POST): see the comment at lat_lp below
 template <bool POST, bool INPLACE>
