@@ -89,6 +89,7 @@ class AlignBatchResult:
 
     def __init__(self, n, cap):
         self.n = n
+        self.cap = cap
         self.Z = np.zeros(n)
         self.status = np.zeros(n, dtype=np.int32)
         self.bad_char = np.zeros(n, dtype=np.uint8)
@@ -266,8 +267,12 @@ class Batch:
         if rc != N.DYN_OK:
             _raise(rc, self._al.last_error())
 
-    def fetch(self) -> AlignBatchResult:
-        out = AlignBatchResult(self.n, self.capacity)
+    def fetch(self, out: AlignBatchResult | None = None) -> AlignBatchResult:
+        """Results of the last align(). ``out``: a result object of an earlier batch to refill (same
+        number of reads, enough segment capacity) instead of allocating and page-faulting in ~50 MB of
+        fresh arrays per 1 024-read batch; whatever it held is overwritten."""
+        if out is None or out.n != self.n or out.cap < self.capacity:
+            out = AlignBatchResult(self.n, self.capacity + self.capacity // 8)
         rc = self._L.dyn_batch_fetch(self._h, C.byref(out._c))
         if rc != N.DYN_OK:
             _raise(rc, self._al.last_error())

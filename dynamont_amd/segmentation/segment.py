@@ -174,7 +174,8 @@ def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: 
             return
         with aligner.batch_raw(signals, reads, [p[2][1] for p in pending], [p[2][2] for p in pending]) as b:
             b.align(True)
-            res = b.fetch()
+            res = b.fetch(getattr(aligner, "_fetch_cache", None))  # batches run one at a time: refill the arrays
+            aligner._fetch_cache = res
     else:
         res = aligner.align_batch(signals, reads, calc_probabilities=True)
     starts = [p[2][3] for p in pending]

@@ -11,6 +11,7 @@ d = tempfile.mkdtemp(prefix="dyn_lat_")
 model = synth.write_model(os.path.join(d, "m9.model"), 9)
 _, mean, sd = synth.read_model_file(model)
 al = Aligner(model, "rna004", device=0)
+res = None
 for rep in range(6):
     reads = synth.make_reads(100 + rep, n, "rna004", mean, sd, 2000)
     sig, seq = [r.signal for r in reads], [r.sequence for r in reads]
@@ -19,7 +20,7 @@ for rep in range(6):
     t1 = time.time()
     b.align(True)
     t2 = time.time()
-    res = b.fetch()
+    res = b.fetch(res)  # refill the previous result object (what the CLI does)
     t3 = time.time()
     tm = b.timing()
     b.close() if hasattr(b, "close") else None
