@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""How close is the HIP path to the CPU oracle (itself bit-identical to the compiled reference)?
+"""Test infrastructure (run by hand on a GPU box: `python tests/parity_stats.py`; not collected by pytest).
+How close is the HIP path to the CPU oracle (itself bit-identical to the compiled reference)?
 Random reads of every pore type + dense reads: integer columns, max |d posterior|, max relative |d Z|."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
