@@ -219,15 +219,16 @@ def main():
         ms_all = kern["ms_total"] / steps if args.steps else tm["ms_total"]
         achieved = cells * KFWD_BYTES_PER_CELL / (ms_fwd * 1e-3) / 1e9
         traffic = load_traffic()
+        tbytes = (traffic or {}).get("k_forward_bytes_per_launch")
         roofline = {
             "bound": "hbm",
             "kernel": "k_forward<POST> (forward + posterior + posterior-Viterbi, fused)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": (traffic or {}).get("k_forward_bytes_per_launch"),
+            "traffic": tbytes,
             # HBM bytes actually moved per second (PMC traffic / live duration): the padded 448-slot rows
-            "traffic_GBps": round(traffic / (ms_fwd * 1e-3) / 1e9, 1) if traffic else None,
-            "traffic_frac": round(traffic / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+            "traffic_GBps": round(tbytes / (ms_fwd * 1e-3) / 1e9, 1) if tbytes else None,
+            "traffic_frac": round(tbytes / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tbytes else None,
             "bytes_per_cell": KFWD_BYTES_PER_CELL, "cells_per_launch": cells,
             "avg_launch_ms": round(ms_fwd, 3),
             "k_backward": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "avg_launch_ms": round(ms_bwd, 3),
