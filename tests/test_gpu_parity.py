@@ -388,3 +388,32 @@ def test_empty_and_all_failed_batches(al5):
     one_inf[17] = -np.inf
     assert al5.align_batch([one_inf], ["ACGTACGTAC"], False).error(0) == "Alignment failed: alignment scores do not match"
     assert al5.train_batch([one_inf], ["ACGTACGTAC"]).error(0) == "Training failed: alignment scores do not match"
+
+
+def test_many_small_reads_in_one_batch(models):
+    """More reads than the chip has SIMDs (4 096 reads -> 1 024 workgroups per DP kernel, one block per
+    read in k_trace): dispatch order, LPT sorting and the per-read offsets must not mix reads up."""
+    pore = "dna_r9"
+    path = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(path)
+    reads = synth.make_reads(4096, 4096, pore, mean, sd, (8, 70), dwell=4.0)
+    al = Aligner(path, pore, device=0)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    assert int((res.status == 0).sum()) >= 4000
+    orc = Oracle(path, synth.PORES[pore][0])
+    for i in list(range(0, 4096, 131)) + [4095]:
+        r = reads[i]
+        try:
+            want = orc.align(r.signal, r.sequence, True)
+        except RuntimeError as e:
+            assert res.error(i) == str(e)
+            continue
+        got = res.read(i)
+        assert np.array_equal(got["signal_positions"], want["signal_positions"])
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+    # empty batch and single read through the same entry point
+    none = al.align_batch([], [], True)
+    assert none.n == 0
+    one = al.align_batch([reads[7].signal], [reads[7].sequence], True)
+    assert np.array_equal(one.read(0)["signal_positions"], res.read(7)["signal_positions"])
