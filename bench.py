@@ -217,9 +217,12 @@ def main():
         ms_fwd = kern["ms_forward"] / steps if args.steps else tm["ms_forward"]
         ms_bwd = kern["ms_backward"] / steps if args.steps else tm["ms_backward"]
         ms_all = kern["ms_total"] / steps if args.steps else tm["ms_total"]
-        achieved = cells * KFWD_BYTES_PER_CELL / (ms_fwd * 1e-3) / 1e9
+        # footprint-limited batches (cfg3) keep (float LPM, float LPE) in place: 16.125 B per cell, and the
+        # committed PMC traffic (measured on cfg2) does not apply to them
+        kfwd_bytes = 16.125 if tm.get("lp_inplace") else KFWD_BYTES_PER_CELL
+        achieved = cells * kfwd_bytes / (ms_fwd * 1e-3) / 1e9
         traffic = load_traffic()
-        tbytes = (traffic or {}).get("k_forward_bytes_per_launch")
+        tbytes = (traffic or {}).get("k_forward_bytes_per_launch") if (args.workload == "cfg2" and not args.reads and not tm.get("lp_inplace")) else None
         roofline = {
             "bound": "hbm",
             "kernel": "k_forward<POST> (forward + posterior + posterior-Viterbi, fused)",
@@ -229,7 +232,7 @@ def main():
             # HBM bytes actually moved per second (PMC traffic / live duration): the padded 448-slot rows
             "traffic_GBps": round(tbytes / (ms_fwd * 1e-3) / 1e9, 1) if tbytes else None,
             "traffic_frac": round(tbytes / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if tbytes else None,
-            "bytes_per_cell": KFWD_BYTES_PER_CELL, "cells_per_launch": cells,
+            "bytes_per_cell": kfwd_bytes, "cells_per_launch": cells,
             "avg_launch_ms": round(ms_fwd, 3),
             "k_backward": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "avg_launch_ms": round(ms_bwd, 3),
                            "achieved": round(cells * KBWD_BYTES_PER_CELL / (ms_bwd * 1e-3) / 1e9, 1)},
