@@ -158,7 +158,12 @@ def format_csv(aligner: "Aligner", res: AlignBatchResult, sequences: Sequence[st
 
 
 class TrainBatchResult:
-    def __init__(self, n, cap, num_kmers, pooled: bool):
+    def __init__(self, n, cap, num_kmers, pooled: bool, emissions: bool = True):
+        """``emissions=False``: no per-read sparse emission updates (their arrays stay empty and the library
+        skips the per-column D2H and grouping) -- for jobs that only consume Z, transitions and the pooled
+        statistics."""
+        if not emissions:
+            cap = 0
         self.n = n
         self.num_kmers = num_kmers
         self.Z = np.zeros(n)
@@ -175,12 +180,13 @@ class TrainBatchResult:
         self.em_sumsq = np.zeros(cap)
         self.trans_counts = np.zeros(2 * n)
         self.pooled = np.zeros(3 * num_kmers) if pooled else None
+        opt = (lambda a, t: _ptr(a, t)) if emissions else (lambda a, t: None)
         self._c = N.DynTrainOut(_ptr(self.Z, N.c_double_p), _ptr(self.status, N.c_i32_p), self.bad_char.ctypes.data,
                                 _ptr(self.transitions, N.c_double_p), _ptr(self.em_offsets, N.c_u64_p),
-                                _ptr(self.em_count, N.c_u64_p), _ptr(self.em_code, N.c_i32_p),
-                                _ptr(self.em_mean, N.c_double_p), _ptr(self.em_stdev, N.c_double_p),
-                                _ptr(self.em_weight, N.c_double_p), _ptr(self.em_sum, N.c_double_p),
-                                _ptr(self.em_sumsq, N.c_double_p), _ptr(self.trans_counts, N.c_double_p), cap)
+                                _ptr(self.em_count, N.c_u64_p), opt(self.em_code, N.c_i32_p),
+                                opt(self.em_mean, N.c_double_p), opt(self.em_stdev, N.c_double_p),
+                                opt(self.em_weight, N.c_double_p), opt(self.em_sum, N.c_double_p),
+                                opt(self.em_sumsq, N.c_double_p), _ptr(self.trans_counts, N.c_double_p), cap)
 
     def error(self, i: int) -> str | None:
         if self.status[i] == 0:
@@ -318,6 +324,73 @@ class Batch:
         return p.value, cnt.value
 
 
+class AsyncBatch:
+    """Ticket of ``Aligner.align_async`` / ``train_async`` (dyn_batch_align_async): the batch runs on the
+    handle's pipeline; ``wait()`` returns the filled result object. The input arrays are kept alive here
+    (the library reads them until the batch is complete)."""
+
+    def __init__(self, aligner: "Aligner", handle, result, keep):
+        self._al = aligner
+        self._L = N.lib()
+        self._h = handle
+        self.result = result
+        self._keep = keep
+        self._waited = False
+
+    def wait(self):
+        if not self._waited:
+            rc = self._L.dyn_batch_wait(self._h)
+            self._waited = True
+            if rc != N.DYN_OK:
+                _raise(rc, self._al.last_error())
+        return self.result
+
+    def timing(self) -> dict:
+        self.wait()
+        t = N.DynTiming()
+        self._L.dyn_batch_timing(self._h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in N.DynTiming._fields_}
+
+    device_results = Batch.device_results
+    device_pooled = Batch.device_pooled
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dyn_batch_destroy(self._h)  # waits first if the batch is still in flight
+            self._h = None
+            self._keep = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def pinned_empty(n: int, dtype) -> np.ndarray:
+    """An uninitialised 1-D array in page-locked host memory (dyn_host_alloc): H2D/D2H of the asynchronous
+    calls then run as plain DMA. The memory is released when the array (and every view of it) is gone."""
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n) * dt.itemsize)
+    L = N.lib()
+    p = L.dyn_host_alloc(nbytes)
+    if not p:
+        raise MemoryError(f"dyn_host_alloc({nbytes}) failed")
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            L.dyn_host_free(self.ptr)
+
+    buf = (C.c_char * nbytes).from_address(p)
+    buf._owner = _Owner(p)  # ctypes array -> numpy keeps `buf` alive as its base
+    return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
 class Aligner:
     """Mirror of ``_dynamont.Aligner`` (aligner_bindings.cpp:191-216).
 
@@ -423,6 +496,48 @@ class Aligner:
         seqs = "".join(sequences).encode("latin-1")
         return Batch(self, raw, sig_off, seqs, seq_off,
                      raw=dict(shift=shift, scale=scale, window=window, n_sigmas=n_sigmas, f32=f32))
+
+    def align_async(self, signals, sig_offsets, seqs: bytes, seq_offsets, calc_probabilities: bool = True,
+                    out: AlignBatchResult | None = None) -> AsyncBatch:
+        """dyn_batch_align_async on packed inputs (``synth.pack_reads`` layout): returns at once; the batch's
+        validation, H2D, kernels, D2H and unpacking overlap with those of the batches submitted around it.
+        ``out``: result object of an EARLIER, completed batch to refill."""
+        sig = np.ascontiguousarray(signals, dtype=np.float64)
+        sig_off = np.ascontiguousarray(sig_offsets, dtype=np.uint64)
+        seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(sig_off) - 1
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        if out is None or out.n != n or out.cap < cap:
+            out = AlignBatchResult(n, cap + cap // 8)
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_align_async(self._h, n, _ptr(sig, N.c_double_p), _ptr(sig_off, N.c_u64_p), seqs,
+                                           _ptr(seq_off, N.c_u64_p), int(bool(calc_probabilities)), C.byref(out._c),
+                                           C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return AsyncBatch(self, h, out, (sig, sig_off, seqs, seq_off))
+
+    def segment_capacity(self, seq_offsets) -> int:
+        """dyn_segment_capacity: rows to allocate for a batch with these sequence offsets."""
+        so = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        return int(self._L.dyn_segment_capacity(self._h, len(so) - 1, _ptr(so, N.c_u64_p)))
+
+    def train_async(self, signals, sig_offsets, seqs: bytes, seq_offsets, pooled: bool = False,
+                    emissions: bool = True) -> AsyncBatch:
+        """dyn_batch_train_async on packed inputs."""
+        sig = np.ascontiguousarray(signals, dtype=np.float64)
+        sig_off = np.ascontiguousarray(sig_offsets, dtype=np.uint64)
+        seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(sig_off) - 1
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        out = TrainBatchResult(n, cap, self.num_kmers, pooled, emissions)
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_train_async(self._h, n, _ptr(sig, N.c_double_p), _ptr(sig_off, N.c_u64_p), seqs,
+                                           _ptr(seq_off, N.c_u64_p), C.byref(out._c),
+                                           _ptr(out.pooled, N.c_double_p) if pooled else None, C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return AsyncBatch(self, h, out, (sig, sig_off, seqs, seq_off))
 
     def align_batch(self, signals: Sequence, sequences: Sequence[str], calc_probabilities: bool = True) -> AlignBatchResult:
         with self.batch(signals, sequences) as b:

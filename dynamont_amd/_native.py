@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "pore_model.cpp", "csv_format.cpp", "nt_kernels.hip"]
-HEADERS = ["nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "nt_kernels.hip"]
+HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
 DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)
@@ -86,6 +86,13 @@ SIGNATURES = {
     "dyn_batch_device_results": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_u64_p, C.POINTER(C.c_void_p)]),
     "dyn_batch_device_pooled": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_u64_p]),
     "dyn_batch_timing": (C.c_int, [C.c_void_p, C.POINTER(DynTiming)]),
+    "dyn_batch_align_async": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p, C.c_int,
+                                        C.POINTER(DynAlignOut), C.POINTER(C.c_void_p)]),
+    "dyn_batch_train_async": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
+                                        C.POINTER(DynTrainOut), c_double_p, C.POINTER(C.c_void_p)]),
+    "dyn_batch_wait": (C.c_int, [C.c_void_p]),
+    "dyn_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "dyn_host_free": (None, [C.c_void_p]),
 }
 
 

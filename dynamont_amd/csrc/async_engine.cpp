@@ -1,0 +1,295 @@
+// async_engine.cpp -- the asynchronous batch pipeline behind dyn_batch_align_async /
+// dyn_batch_train_async / dyn_batch_wait (include/dynamont_mi.h).
+//
+// What it replaces: the reference overlaps reading, preprocessing, alignment and writing by running
+// `processes` worker processes behind a multiprocessing pool and a listener process
+// (src/dynamont/segmentation/segment.py:301-325). One GPU replaces the workers; to keep it fed, the
+// host stages of neighbouring batches have to run under the kernels of the current one:
+//
+//   caller        submit(k+2) ............................................. wait(k)
+//   front thread  validate + k-mer code (k+1) | H2D (k+1) on s_in | launches (k+1) on the compute stream
+//   GPU           kernels (k) ............................. | kernels (k+1) ...
+//   copy-out      ............... D2H rows/state (k-1) on s_out
+//   back thread   ............... unpack (k-1) into the caller's arrays -> done
+//
+// Stream order does all GPU-side synchronisation (events between the three streams); the only host
+// waits are the back thread's hipEventSynchronize on a batch's last D2H and the caller's wait().
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+using dynk::ReadState;
+using dynk::SegRow;
+using dynmath::Emis;
+
+namespace dyneng {
+
+namespace {
+
+int hip_fail(dyn_batch* b, hipError_t e, const char* what) {
+  b->error = std::string("HIP error: ") + hipGetErrorString(e) + " at " + what;
+  (void)hipGetLastError();
+  return e == hipErrorOutOfMemory ? DYN_ERR_OUT_OF_MEMORY : DYN_ERR_DEVICE;
+}
+
+#define P_TRY(b, expr)                                        \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return hip_fail((b), _e, #expr);    \
+  } while (0)
+
+int helper_threads() {
+  const unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::min<unsigned>(6, std::max<unsigned>(2, hc / 2));
+}
+
+}  // namespace
+
+Pipeline::Pipeline(dyn_aligner* al) : a(al), helpers(helper_threads()) {
+  t_front = std::thread([this] { front_loop(); });
+  t_back = std::thread([this] { back_loop(); });
+}
+
+Pipeline::~Pipeline() {
+  drain();
+  {
+    std::lock_guard<std::mutex> lk(m);
+    stop = true;
+  }
+  cv_front.notify_all();
+  cv_back.notify_all();
+  if (t_front.joinable()) t_front.join();
+  if (t_back.joinable()) t_back.join();
+}
+
+void Pipeline::submit(dyn_batch* b) {
+  {
+    std::lock_guard<std::mutex> lk(m);
+    q_front.push_back(b);
+    ++in_flight;
+  }
+  cv_front.notify_one();
+}
+
+int Pipeline::wait(dyn_batch* b) {
+  std::unique_lock<std::mutex> lk(m);
+  cv_done.wait(lk, [&] { return b->done; });
+  return b->rc;
+}
+
+void Pipeline::drain() {
+  std::unique_lock<std::mutex> lk(m);
+  cv_done.wait(lk, [&] { return in_flight == 0; });
+}
+
+void Pipeline::front_loop() {
+  if (!a->host_only) (void)hipSetDevice(a->device);
+  for (;;) {
+    dyn_batch* b = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv_front.wait(lk, [&] { return stop || !q_front.empty(); });
+      if (q_front.empty()) return;  // stop requested and nothing left
+      b = q_front.front();
+      q_front.pop_front();
+    }
+    const int rc = front_stage(b);
+    {
+      std::lock_guard<std::mutex> lk(m);
+      b->rc = rc;
+      q_back.push_back(b);  // failed batches pass through the back thread too: completion stays in order
+    }
+    cv_back.notify_one();
+  }
+}
+
+void Pipeline::back_loop() {
+  if (!a->host_only) (void)hipSetDevice(a->device);
+  for (;;) {
+    dyn_batch* b = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv_back.wait(lk, [&] { return stop || !q_back.empty(); });
+      if (q_back.empty()) return;
+      b = q_back.front();
+      q_back.pop_front();
+    }
+    int rc = b->rc;
+    if (rc == DYN_OK) rc = back_stage(b);
+    {
+      std::lock_guard<std::mutex> lk(m);
+      b->rc = rc;
+      b->done = true;
+      --in_flight;
+    }
+    cv_done.notify_all();
+  }
+}
+
+// Host prepare, H2D and every kernel launch of one batch; returns without waiting for the GPU.
+int Pipeline::front_stage(dyn_batch* b) {
+  const uint64_t n = b->n;
+  int rc = host_prepare(b, a->model, true, n, b->in_sig_offsets, b->in_seqs, b->in_seq_offsets, &helpers);
+  if (rc != DYN_OK) {
+    b->error = a->last_error;
+    return rc;
+  }
+  const uint64_t total_sig = n ? b->in_sig_offsets[n] - b->in_sig_offsets[0] : 0;
+  std::lock_guard<std::mutex> lk(a->mu);
+  rc = alloc_batch_buffers(b, total_sig);
+  if (rc != DYN_OK) {
+    b->error = a->last_error;
+    return rc;
+  }
+  for (hipEvent_t* e : {&b->ev_in, &b->ev_done, &b->ev_out})
+    if (!*e) P_TRY(b, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  // H2D on the copy-in stream. Pinned caller memory (dyn_host_alloc) is a true asynchronous DMA;
+  // for pageable memory the runtime stages the copy and this thread blocks for its duration, which
+  // is what the thread is for -- the compute stream keeps running the previous batch meanwhile.
+  if (total_sig)
+    P_TRY(b, hipMemcpyAsync(b->d_sig.p, b->in_signals + b->in_sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->s_in));
+  if (b->total_cols)
+    P_TRY(b, hipMemcpyAsync(b->d_kmers.p, b->h_kmers.p, b->total_cols * 4, hipMemcpyHostToDevice, a->s_in));
+  P_TRY(b, hipEventRecord(b->ev_in, a->s_in));
+  P_TRY(b, hipStreamWaitEvent(a->stream, b->ev_in, 0));
+  if (b->total_cols) {
+    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
+    P_TRY(b, hipGetLastError());
+  }
+  rc = enqueue_job(b, b->job);
+  if (rc != DYN_OK) {
+    b->error = a->last_error;
+    (void)hipStreamSynchronize(a->stream);  // nothing of this batch may still be running when it is torn down
+    return rc;
+  }
+  P_TRY(b, hipEventRecord(b->ev_done, a->stream));
+  P_TRY(b, hipStreamWaitEvent(a->s_out, b->ev_done, 0));
+  // D2H into pinned per-batch buffers on the copy-out stream
+  if (n) P_TRY(b, hipMemcpyAsync(b->h_state.p, b->d_state.p, n * sizeof(ReadState), hipMemcpyDeviceToHost, a->s_out));
+  if (b->job == DynJob::AlignFull && b->capacity) {
+    P_TRY(b, b->h_rows.ensure(b->capacity * sizeof(SegRow)));
+    P_TRY(b, hipMemcpyAsync(b->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost, a->s_out));
+  } else if (b->job == DynJob::Train) {
+    // [colw | cols1 | cols2 | trans] in one pinned buffer; the per-column sums are only needed for the
+    // per-read emission updates and the host-side pooled sum
+    const dyn_train_out* ot = b->out_train;
+    const bool need_cols = (ot->em_code && ot->em_mean && ot->em_stdev) || b->out_pooled;
+    const uint64_t c = need_cols ? b->total_cols : 0;
+    P_TRY(b, b->h_rows.ensure(std::max<uint64_t>(8, (3 * c + 2 * n) * 8)));
+    double* h = b->h_rows.as<double>();
+    if (c) {
+      P_TRY(b, hipMemcpyAsync(h, b->d_colw.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+      P_TRY(b, hipMemcpyAsync(h + c, b->d_cols1.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+      P_TRY(b, hipMemcpyAsync(h + 2 * c, b->d_cols2.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+    }
+    if (n) P_TRY(b, hipMemcpyAsync(h + 3 * c, b->d_trans.p, n * 16, hipMemcpyDeviceToHost, a->s_out));
+  }
+  P_TRY(b, hipEventRecord(b->ev_out, a->s_out));
+  return DYN_OK;
+}
+
+// Wait for the batch's last D2H, then turn the device records into the caller's arrays.
+int Pipeline::back_stage(dyn_batch* b) {
+  P_TRY(b, hipEventSynchronize(b->ev_out));
+  int rc = collect_timing(b);
+  if (rc != DYN_OK) {
+    b->error = a->last_error;
+    return rc;
+  }
+  const ReadState* st = b->h_state.as<ReadState>();
+  if (b->job == DynJob::Train) {
+    const dyn_train_out* ot = b->out_train;
+    const bool need_cols = (ot->em_code && ot->em_mean && ot->em_stdev) || b->out_pooled;
+    const uint64_t c = need_cols ? b->total_cols : 0;
+    const double* h = b->h_rows.as<double>();
+    finalise_train(b, st, h, h + c, h + 2 * c, h + 3 * c, b->out_train, b->out_pooled);
+  } else {
+    dyn_align_out* out = b->out_align;
+    const bool want_rows = b->job == DynJob::AlignFull && b->capacity &&
+                           (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
+    unpack_align(b, st, want_rows ? b->h_rows.as<SegRow>() : nullptr, out, &helpers);
+  }
+  return DYN_OK;
+}
+
+}  // namespace dyneng
+
+using namespace dyneng;
+
+namespace {
+
+int submit_common(dyn_aligner* a, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
+                  const char* seqs, const uint64_t* seq_offsets, DynJob job, dyn_align_out* oa,
+                  dyn_train_out* ot, double* pooled, dyn_batch** ticket) {
+  if (!a || !ticket || !sig_offsets || !seq_offsets || (n_reads && (!signals || !seqs))) return DYN_ERR_INVALID_ARGUMENT;
+  *ticket = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(a->mu);
+    int rc = need_device(a);
+    if (rc != DYN_OK) return rc;
+    if (!a->pipe) a->pipe.reset(new Pipeline(a));
+  }
+  const uint64_t cap = dyn_segment_capacity(a, n_reads, seq_offsets);
+  if (oa) {
+    if (!oa->Z || !oa->status) return DYN_ERR_INVALID_ARGUMENT;
+    const bool want_rows = job == DynJob::AlignFull && (oa->sequence_positions || oa->signal_positions || oa->probabilities || oa->states);
+    if (want_rows && oa->capacity < cap) {
+      a->last_error = "dyn_align_out.capacity is smaller than dyn_segment_capacity()";
+      return DYN_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (ot) {
+    if (!ot->Z || !ot->status) return DYN_ERR_INVALID_ARGUMENT;
+    if (ot->em_code && ot->em_mean && ot->em_stdev && ot->capacity < cap) {
+      a->last_error = "dyn_train_out.capacity is smaller than dyn_segment_capacity()";
+      return DYN_ERR_INVALID_ARGUMENT;
+    }
+  }
+  dyn_batch* b = new dyn_batch();
+  b->a = a;
+  attach_cache(b);
+  b->n = n_reads;
+  b->async = true;
+  b->job = job;
+  b->in_signals = signals;
+  b->in_sig_offsets = sig_offsets;
+  b->in_seqs = seqs;
+  b->in_seq_offsets = seq_offsets;
+  b->out_align = oa;
+  b->out_train = ot;
+  b->out_pooled = pooled;
+  a->pipe->submit(b);
+  *ticket = b;
+  return DYN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dyn_batch_align_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                          const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                          int calc_probabilities, dyn_align_out* out, dyn_batch** ticket) {
+  if (!out) return DYN_ERR_INVALID_ARGUMENT;
+  return submit_common(a, n_reads, signals, sig_offsets, seqs, seq_offsets,
+                       calc_probabilities ? DynJob::AlignFull : DynJob::AlignZ, out, nullptr, nullptr, ticket);
+}
+
+int dyn_batch_train_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                          const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                          dyn_train_out* out, double* pooled3n, dyn_batch** ticket) {
+  if (!out) return DYN_ERR_INVALID_ARGUMENT;
+  return submit_common(a, n_reads, signals, sig_offsets, seqs, seq_offsets, DynJob::Train, nullptr, out, pooled3n, ticket);
+}
+
+int dyn_batch_wait(dyn_batch* b) {
+  if (!b) return DYN_ERR_INVALID_ARGUMENT;
+  if (!b->async) return DYN_OK;  // synchronous batches are complete when their call returns
+  dyn_aligner* a = b->a;
+  const int rc = a->pipe->wait(b);
+  if (rc != DYN_OK) a->last_error = b->error;
+  return rc;
+}
+
+}  // extern "C"

@@ -17,7 +17,7 @@
 
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DYN_HD __host__ __device__ __forceinline__
 #else

@@ -1,37 +1,187 @@
 // dynamont_mi.cpp -- C-ABI entry points (include/dynamont_mi.h) and the host batch engine:
-// validation + k-mer coding per read, HBM planning, chunked kernel launches, result marshalling.
+// validation + k-mer coding per read, HBM planning, kernel launches, result marshalling.
 //
 // Reference driver being replaced: NTAligner::align / NTAligner::train
 // (src/cpp/NT_aligner_api.cpp:230-312, 567-639) and the pybind marshalling around them
 // (src/cpp/aligner_bindings.cpp:53-107,132-165). Per-read failures are isolated exactly as the
 // reference's per-read try/except does (src/dynamont/segmentation/segment.py:160-187).
 //
+// Every GPU stage of a batch is ENQUEUED without a host synchronisation (enqueue_job): the
+// synchronous staged API (dyn_batch_create / _align / _fetch) waits for the stream itself, the
+// asynchronous pipeline (async_engine.cpp) lets batch k+1's host work and copies run under batch
+// k's kernels.
+//
 // There is NO CPU compute path here: without a bound GPU every compute entry point fails with
 // DYN_ERR_DEVICE.
-#include "../../include/dynamont_mi.h"
+#include "engine.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <numeric>
 #include <stdexcept>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include <hip/hip_runtime.h>
-
-#include "nt_kernels.hpp"
-#include "pore_model.hpp"
 
 using dynhost::PoreModel;
 using dynk::ReadDesc;
 using dynk::ReadState;
 using dynk::SegRow;
 using dynmath::Emis;
+using namespace dyneng;
+
+namespace dyneng {
+
+// ---- buffers -----------------------------------------------------------------------------------
+size_t BufCache::round_up(size_t want) {
+  size_t g = (size_t)1 << 16;
+  while (g * 16 < want) g <<= 1;  // granule between want/16 and want/8: <= 12.5 % over-allocation
+  return (want + g - 1) / g * g;
+}
+
+hipError_t BufCache::take(bool pinned, size_t want, void** p, size_t* got) {
+  {
+    std::lock_guard<std::mutex> lk(m);
+    auto& mp = pinned ? pin : dev;
+    auto it = mp.lower_bound(want);
+    if (it != mp.end() && it->first <= 2 * want + ((size_t)1 << 20)) {
+      *p = it->second;
+      *got = it->first;
+      mp.erase(it);
+      return hipSuccess;
+    }
+  }
+  const size_t ask = round_up(want);
+  hipError_t e = pinned ? hipHostMalloc(p, ask, hipHostMallocDefault) : hipMalloc(p, ask);
+  if (e != hipSuccess) {  // give everything cached back to the runtime and try once more
+    (void)hipGetLastError();
+    purge();
+    e = pinned ? hipHostMalloc(p, ask, hipHostMallocDefault) : hipMalloc(p, ask);
+  }
+  if (e == hipSuccess) *got = ask;
+  return e;
+}
+
+void BufCache::give(bool pinned, void* p, size_t bytes) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(m);
+  (pinned ? pin : dev).emplace(bytes, p);
+}
+
+void BufCache::purge() {
+  std::lock_guard<std::mutex> lk(m);
+  for (auto& kv : dev) (void)hipFree(kv.second);
+  for (auto& kv : pin) (void)hipHostFree(kv.second);
+  dev.clear();
+  pin.clear();
+}
+
+hipError_t DevBuf::ensure(size_t want, double headroom) {
+  if (want <= bytes) return hipSuccess;
+  release();
+  if (cache) return cache->take(false, want, &p, &bytes);
+  size_t ask = (size_t)((double)want * headroom);
+  if (ask < want) ask = want;
+  hipError_t e = hipMalloc(&p, ask);
+  if (e != hipSuccess && ask > want) {  // no room for the headroom: take exactly what is needed
+    (void)hipGetLastError();
+    ask = want;
+    e = hipMalloc(&p, ask);
+  }
+  if (e == hipSuccess) bytes = ask;
+  else p = nullptr;
+  return e;
+}
+
+void DevBuf::release() {
+  if (p) {
+    if (cache) cache->give(false, p, bytes);
+    else (void)hipFree(p);
+  }
+  p = nullptr;
+  bytes = 0;
+}
+
+hipError_t PinnedBuf::ensure(size_t want) {
+  if (want <= bytes) return hipSuccess;
+  release();
+  if (cache) return cache->take(true, want, &p, &bytes);
+  const size_t ask = want + want / 8;
+  hipError_t e = hipHostMalloc(&p, ask, hipHostMallocDefault);
+  if (e == hipSuccess) bytes = ask;
+  else p = nullptr;
+  return e;
+}
+
+void PinnedBuf::release() {
+  if (p) {
+    if (cache) cache->give(true, p, bytes);
+    else (void)hipHostFree(p);
+  }
+  p = nullptr;
+  bytes = 0;
+}
+
+// ---- helper pool -------------------------------------------------------------------------------
+HelperPool::HelperPool(int n_threads) {
+  for (int i = 1; i < n_threads; ++i) workers_.emplace_back([this] { worker(); });
+}
+
+HelperPool::~HelperPool() {
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  for (auto& t : workers_) t.join();
+}
+
+void HelperPool::worker() {
+  uint64_t seen = 0;
+  std::unique_lock<std::mutex> lk(m_);
+  for (;;) {
+    cv_work_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < n_); });
+    if (stop_) return;
+    seen = gen_;
+    while (next_ < n_) {
+      const int task = next_++;
+      ++active_;
+      const auto* fn = fn_;
+      lk.unlock();
+      (*fn)(task);
+      lk.lock();
+      --active_;
+    }
+    if (active_ == 0) cv_done_.notify_all();
+  }
+}
+
+void HelperPool::parallel_for(int n_tasks, const std::function<void(int)>& fn) {
+  if (n_tasks <= 0) return;
+  if (n_tasks == 1 || workers_.empty()) {
+    for (int i = 0; i < n_tasks; ++i) fn(i);
+    return;
+  }
+  std::unique_lock<std::mutex> lk(m_);
+  fn_ = &fn;
+  n_ = n_tasks;
+  next_ = 0;
+  ++gen_;
+  cv_work_.notify_all();
+  while (next_ < n_) {  // the caller takes part
+    const int task = next_++;
+    ++active_;
+    lk.unlock();
+    fn(task);
+    lk.lock();
+    --active_;
+  }
+  cv_done_.wait(lk, [&] { return active_ == 0 && next_ >= n_; });
+  fn_ = nullptr;
+  n_ = 0;
+}
+
+}  // namespace dyneng
 
 namespace {
 
@@ -42,99 +192,6 @@ void copy_msg(char* buf, uint64_t cap, const std::string& s) {
   buf[n] = 0;
 }
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  // grow-only. `headroom` > 1 over-allocates when the buffer has to grow: releasing and re-allocating
-  // a 70 GB lattice pool costs 4-5 s on an MI355X (measured, tools/batch_latency.py), which a stream
-  // of batches of slightly different size would otherwise pay every time a new maximum shows up.
-  hipError_t ensure(size_t want, double headroom = 1.0) {
-    if (want <= bytes) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-    size_t ask = (size_t)((double)want * headroom);
-    if (ask < want) ask = want;
-    hipError_t e = hipMalloc(&p, ask);
-    if (e != hipSuccess && ask > want) {  // no room for the headroom: take exactly what is needed
-      (void)hipGetLastError();
-      ask = want;
-      e = hipMalloc(&p, ask);
-    }
-    if (e == hipSuccess) bytes = ask;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-  template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-}  // namespace
-
-// grow-only pinned host buffer: D2H of the result rows runs at PCIe speed into it, and it is not
-// re-allocated (and page-faulted in) per batch like a std::vector would be
-struct PinnedBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  hipError_t ensure(size_t want) {
-    if (want <= bytes) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    bytes = 0;
-    const size_t ask = want + want / 8;
-    hipError_t e = hipHostMalloc(&p, ask, hipHostMallocDefault);
-    if (e == hipSuccess) bytes = ask;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-};
-
-struct dyn_aligner {
-  PoreModel model;
-  int device = -1;
-  bool host_only = false;
-  int threads = 1;
-  hipStream_t stream = nullptr;
-  DevBuf d_model;
-  DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
-  uint64_t mem_budget = 0;
-  std::string last_error;
-  // grow-only lattice workspace pool, reused across batches
-  DevBuf ws, lpe, bits, pp, pathn, descs;
-  PinnedBuf h_rows;  // staging of dyn_batch_fetch
-};
-
-struct HostRead {
-  uint64_t S = 0, L = 0, kc = 0;
-  uint64_t sig_off = 0, flat_off = 0 /* into kmers / per-column tables */, seg_off = 0;
-  int32_t status = 0;
-  char bad = 0;
-};
-
-struct dyn_batch {
-  dyn_aligner* a = nullptr;
-  uint64_t n = 0;
-  std::vector<HostRead> reads;
-  std::vector<int32_t> kmers;  // flat, ok reads only
-  uint64_t capacity = 0;       // sum of kc over ALL reads with L >= k (segment rows)
-  uint64_t total_cols = 0;     // sum of kc over ok reads
-  uint32_t max_T = 0, max_N = 0;
-  DevBuf d_sig, d_kmers, d_par, d_state, d_rows, d_segrow, d_medhi, d_medlo;
-  DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled;
-  dyn_timing timing{};
-  bool aligned = false, trained = false;
-  int last_calc = 0;
-};
-
-namespace {
-
 #define HIP_TRY(a, expr)                                                                  \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
@@ -143,6 +200,22 @@ namespace {
       return _e == hipErrorOutOfMemory ? DYN_ERR_OUT_OF_MEMORY : DYN_ERR_DEVICE;          \
     }                                                                                     \
   } while (0)
+
+uint64_t lattice_bytes_per_row(bool calc, bool lpe_separate) {
+  // [T][P] bE slots (8 B) [+ float LPE per slot] + decision bits + per-row path arrays
+  return calc ? (uint64_t)dynk::P * (lpe_separate ? 12 : 8) + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
+}
+
+}  // namespace
+
+namespace dyneng {
+void attach_cache(dyn_batch* b) {
+  dyneng::BufCache* c = &b->a->cache;
+  for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
+    d->cache = c;
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows}) h->cache = c;
+}
 
 int need_device(dyn_aligner* a) {
   if (a->host_only) {
@@ -159,47 +232,79 @@ int need_device(dyn_aligner* a) {
 }
 
 // Host front half of align()/train(): validateInput then sequenceToKmers
-// (NT_aligner_api.cpp:236-238).
-void prepare_reads(const PoreModel& m, uint64_t n, const uint64_t* sig_offsets, const char* seqs,
-                   const uint64_t* seq_offsets, std::vector<HostRead>& reads,
-                   std::vector<int32_t>& kmers, uint64_t* capacity, uint64_t* total_cols) {
-  reads.resize(n);
-  uint64_t cap = 0, reserve = 0;
+// (NT_aligner_api.cpp:236-238). Reads are independent: k-mer coding runs on the helper pool.
+// Every read that passes validateInput gets its slice of the flat k-mer array up front; a read that
+// then fails in sequenceToKmers ("Invalid nucleotide") simply leaves its slice unused.
+int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, const uint64_t* sig_offsets,
+                 const char* seqs, const uint64_t* seq_offsets, HelperPool* pool) {
+  b->n = n;
+  b->reads.assign(n, HostRead());
+  uint64_t cap = 0, flat = 0;
   for (uint64_t i = 0; i < n; ++i) {
-    HostRead& r = reads[i];
+    HostRead& r = b->reads[i];
     r.S = sig_offsets[i + 1] - sig_offsets[i];
     r.L = seq_offsets[i + 1] - seq_offsets[i];
-    r.sig_off = sig_offsets[i];
+    r.sig_off = sig_offsets[i] - sig_offsets[0];
     r.seg_off = cap;
     r.kc = r.L >= (uint64_t)m.k ? r.L - (uint64_t)m.k + 1 : 0;
     cap += r.kc;
     r.status = m.validate(r.S, r.L);
-    if (r.status == DYN_READ_OK) reserve += r.kc;
-  }
-  kmers.resize(reserve);
-  uint64_t flat = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    HostRead& r = reads[i];
-    if (r.status != DYN_READ_OK) continue;
-    r.status = m.encode(seqs + seq_offsets[i], r.L, kmers.data() + flat, &r.bad);
     if (r.status == DYN_READ_OK) {
       r.flat_off = flat;
       flat += r.kc;
     }
   }
-  kmers.resize(flat);
-  *capacity = cap;
-  *total_cols = flat;
+  b->capacity = cap;
+  b->total_cols = flat;
+  if (pinned) {
+    if (b->h_kmers.ensure(std::max<uint64_t>(4, flat * 4)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (b->a) b->a->last_error = "out of pinned host memory for the k-mer codes";
+      return DYN_ERR_OUT_OF_MEMORY;
+    }
+  } else {  // dyn_validate_batch needs no GPU: plain memory, no HIP call
+    b->h_kmers.release();
+    b->h_kmers.cache = nullptr;
+    b->h_kmers.p = std::malloc(std::max<uint64_t>(4, flat * 4));
+    b->h_kmers.bytes = 0;  // marks "malloc'ed": freed by the caller of host_prepare
+    if (!b->h_kmers.p) return DYN_ERR_OUT_OF_MEMORY;
+  }
+  int32_t* km = b->h_kmers.as<int32_t>();
+  auto encode_range = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      HostRead& r = b->reads[i];
+      if (r.status != DYN_READ_OK) continue;
+      r.status = m.encode(seqs + seq_offsets[i], r.L, km + r.flat_off, &r.bad);
+    }
+  };
+  const int parts = (pool && n >= 64) ? std::min<int>(pool->size() * 2, (int)(n / 16)) : 1;
+  if (parts <= 1) encode_range(0, n);
+  else pool->parallel_for(parts, [&](int t) { encode_range(n * t / parts, n * (t + 1) / parts); });
+  b->max_T = b->max_N = 0;
+  for (HostRead& r : b->reads) {
+    if (r.status != DYN_READ_OK) continue;
+    if (r.S + 1 > 0x7fffffffull || r.kc + 1 > 0x7fffffffull) {
+      r.status = DYN_READ_TOO_LARGE;  // 32-bit lattice indices; isolated per read like any other failure
+      continue;
+    }
+    b->max_T = std::max<uint32_t>(b->max_T, (uint32_t)(r.S + 1));
+    b->max_N = std::max<uint32_t>(b->max_N, (uint32_t)(r.kc + 1));
+  }
+  return DYN_OK;
 }
 
-struct Chunk { std::vector<uint32_t> idx; };
-
-uint64_t lattice_bytes_per_row(bool calc, bool lpe_separate) {
-  // [T][P] bE slots (8 B) [+ float LPE per slot] + decision bits + per-row path arrays
-  return calc ? (uint64_t)dynk::P * (lpe_separate ? 12 : 8) + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
+int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig) {
+  dyn_aligner* a = b->a;
+  HIP_TRY(a, b->d_sig.ensure(std::max<uint64_t>(8, total_sig * 8)));
+  HIP_TRY(a, b->d_kmers.ensure(std::max<uint64_t>(4, b->total_cols * 4)));
+  HIP_TRY(a, b->d_par.ensure(std::max<uint64_t>(sizeof(Emis), b->total_cols * sizeof(Emis))));
+  HIP_TRY(a, b->d_state.ensure(std::max<uint64_t>(sizeof(ReadState), b->n * sizeof(ReadState))));
+  HIP_TRY(a, b->d_rows.ensure(std::max<uint64_t>(sizeof(SegRow), b->capacity * sizeof(SegRow))));
+  HIP_TRY(a, b->h_state.ensure(std::max<uint64_t>(sizeof(ReadState), b->n * sizeof(ReadState))));
+  return DYN_OK;
 }
 
-}  // namespace
+}  // namespace dyneng
 
 extern "C" {
 
@@ -254,7 +359,8 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   auto fail = [&](hipError_t e, const char* what) {
     copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
                               " (the MI355X build has no CPU compute path)");
-    if (a->stream) (void)hipStreamDestroy(a->stream);
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+      if (s) (void)hipStreamDestroy(s);
     a->d_model.release();
     a->d_sptab.release();
     delete a;
@@ -268,6 +374,8 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   a->device = device;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&a->s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&a->s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
   if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
                      hipMemcpyHostToDevice)) != hipSuccess)
@@ -285,8 +393,10 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
 
 void dyn_aligner_destroy(dyn_aligner* a) {
   if (!a) return;
+  a->pipe.reset();  // drains and joins the pipeline threads
   if (!a->host_only) {
     (void)hipSetDevice(a->device);
+    (void)hipDeviceSynchronize();
     a->d_model.release();
     a->d_sptab.release();
     a->ws.release();
@@ -294,9 +404,10 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->bits.release();
     a->pp.release();
     a->pathn.release();
-    a->descs.release();
     a->h_rows.release();
-    if (a->stream) (void)hipStreamDestroy(a->stream);
+    a->cache.purge();
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+      if (s) (void)hipStreamDestroy(s);
   }
   delete a;
 }
@@ -346,6 +457,7 @@ int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
     case DYN_READ_Z_MISMATCH: s = "Alignment failed: alignment scores do not match"; break;
     case DYN_READ_TRAIN_Z_MISMATCH: s = "Training failed: alignment scores do not match"; break;
     case DYN_READ_INTERNAL: s = "Traceback left the lattice"; break;
+    case DYN_READ_TOO_LARGE: s = "Read too large for the device memory budget"; break;
     default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
   }
   copy_msg(buf, cap, s);
@@ -365,20 +477,38 @@ int dyn_validate_batch(const dyn_aligner* a, uint64_t n_reads, const uint64_t* s
                        const char* seqs, const uint64_t* seq_offsets, int32_t* status,
                        char* bad_char, int32_t* kmers_out, uint64_t kmers_cap) {
   if (!a) return DYN_ERR_INVALID_ARGUMENT;
-  std::vector<HostRead> reads;
-  std::vector<int32_t> kmers;
-  uint64_t cap = 0, cols = 0;
-  prepare_reads(a->model, n_reads, sig_offsets, seqs, seq_offsets, reads, kmers, &cap, &cols);
-  for (uint64_t i = 0; i < n_reads; ++i) {
-    if (status) status[i] = reads[i].status;
-    if (bad_char) bad_char[i] = reads[i].bad;
-    if (kmers_out && reads[i].status == DYN_READ_OK) {
-      // k-mers of read i are written at the read's segment offset (capacity layout)
-      if (reads[i].seg_off + reads[i].kc > kmers_cap) return DYN_ERR_INVALID_ARGUMENT;
-      std::memcpy(kmers_out + reads[i].seg_off, kmers.data() + reads[i].flat_off, sizeof(int32_t) * reads[i].kc);
+  dyn_batch b;  // scratch, host memory only
+  int rc = host_prepare(&b, a->model, false, n_reads, sig_offsets, seqs, seq_offsets, nullptr);
+  if (rc == DYN_OK) {
+    for (uint64_t i = 0; i < n_reads; ++i) {
+      if (status) status[i] = b.reads[i].status;
+      if (bad_char) bad_char[i] = b.reads[i].bad;
+      if (kmers_out && b.reads[i].status == DYN_READ_OK) {
+        // k-mers of read i are written at the read's segment offset (capacity layout)
+        if (b.reads[i].seg_off + b.reads[i].kc > kmers_cap) {
+          rc = DYN_ERR_INVALID_ARGUMENT;
+          break;
+        }
+        std::memcpy(kmers_out + b.reads[i].seg_off, b.kmers() + b.reads[i].flat_off, sizeof(int32_t) * b.reads[i].kc);
+      }
     }
   }
-  return DYN_OK;
+  std::free(b.h_kmers.p);
+  b.h_kmers.p = nullptr;
+  return rc;
+}
+
+void* dyn_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void dyn_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 }  // extern "C"
@@ -399,32 +529,23 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
                 dyn_batch** out) {
   if (!a || !out) return DYN_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  std::lock_guard<std::mutex> lk(a->mu);
   int rc = need_device(a);
   if (rc != DYN_OK) return rc;
   dyn_batch* b = new dyn_batch();
   b->a = a;
-  b->n = n_reads;
+  attach_cache(b);
   // DYN_TRACE_HOST=1: wall time of the host stages of batch creation on stderr (tools/batch_latency.py)
   static const bool trace_host = std::getenv("DYN_TRACE_HOST") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now_ms();
-  prepare_reads(a->model, n_reads, sig_offsets, seqs, seq_offsets, b->reads, b->kmers, &b->capacity,
-                &b->total_cols);
-  const double t_prepared = now_ms();
-  for (const HostRead& r : b->reads) {
-    if (r.status != DYN_READ_OK) continue;
-    if (r.S + 1 > 0x7fffffffull || r.kc + 1 > 0x7fffffffull) {
-      a->last_error = "read too long for 32-bit lattice indices";
-      delete b;
-      return DYN_ERR_INVALID_ARGUMENT;
-    }
-    b->max_T = std::max<uint32_t>(b->max_T, (uint32_t)(r.S + 1));
-    b->max_N = std::max<uint32_t>(b->max_N, (uint32_t)(r.kc + 1));
-  }
   auto cleanup = [&](int code) {
     dyn_batch_destroy(b);
     return code;
   };
+  rc = host_prepare(b, a->model, true, n_reads, sig_offsets, seqs, seq_offsets, nullptr);
+  if (rc != DYN_OK) return cleanup(rc);
+  const double t_prepared = now_ms();
 #define B_TRY(expr)                                                                        \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \
@@ -434,8 +555,10 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
     }                                                                                      \
   } while (0)
   const uint64_t total_sig = n_reads ? sig_offsets[n_reads] - sig_offsets[0] : 0;
-  B_TRY(b->d_sig.ensure(std::max<uint64_t>(8, total_sig * 8)));
-  DevBuf d_raw, d_norm, d_offs, d_shift, d_scale;  // preprocessing scratch, freed on return
+  rc = alloc_batch_buffers(b, total_sig);
+  if (rc != DYN_OK) return cleanup(rc);
+  DevBuf d_raw, d_norm, d_offs, d_shift, d_scale;  // preprocessing scratch, back to the cache on return
+  for (DevBuf* d : {&d_raw, &d_norm, &d_offs, &d_shift, &d_scale}) d->cache = &a->cache;
   struct Scratch {
     DevBuf* v[5];
     ~Scratch() { for (DevBuf* d : v) d->release(); }
@@ -462,21 +585,18 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
     dynk::launch_preprocess(d_raw.p, rs->dtype, rs->compute_f32, d_offs.as<uint64_t>(), d_shift.as<double>(),
                             d_scale.as<double>(), d_norm.p, b->d_sig.as<double>(), (int)n_reads, max_len, rs->window,
                             rs->n_sigmas, a->stream);
+    B_TRY(hipGetLastError());
   }
-  for (HostRead& r : b->reads) r.sig_off -= n_reads ? sig_offsets[0] : 0;
-  B_TRY(b->d_kmers.ensure(std::max<uint64_t>(4, b->total_cols * 4)));
-  B_TRY(b->d_par.ensure(std::max<uint64_t>(sizeof(Emis), b->total_cols * sizeof(Emis))));
   if (b->total_cols) {
-    B_TRY(hipMemcpyAsync(b->d_kmers.p, b->kmers.data(), b->total_cols * 4, hipMemcpyHostToDevice, a->stream));
+    B_TRY(hipMemcpyAsync(b->d_kmers.p, b->h_kmers.p, b->total_cols * 4, hipMemcpyHostToDevice, a->stream));
     dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
+    B_TRY(hipGetLastError());
   }
-  B_TRY(b->d_state.ensure(std::max<uint64_t>(sizeof(ReadState), n_reads * sizeof(ReadState))));
-  B_TRY(b->d_rows.ensure(std::max<uint64_t>(sizeof(SegRow), b->capacity * sizeof(SegRow))));
   const double t_enqueued = now_ms();
-  B_TRY(hipStreamSynchronize(a->stream));
+  B_TRY(hipStreamSynchronize(a->stream));  // the scratch buffers go back to the cache on return
 #undef B_TRY
   if (trace_host)
-    std::fprintf(stderr, "[dyn] batch create: validate+encode %.2f ms, alloc+enqueue (H2D of pageable memory is synchronous) %.2f ms, drain %.2f ms\n",
+    std::fprintf(stderr, "[dyn] batch create: validate+encode %.2f ms, alloc+enqueue %.2f ms, drain %.2f ms\n",
                  t_prepared - t_start, t_enqueued - t_prepared, now_ms() - t_enqueued);
   *out = b;
   return DYN_OK;
@@ -524,38 +644,31 @@ int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count) {
 
 void dyn_batch_destroy(dyn_batch* b) {
   if (!b) return;
+  if (b->async && !b->done && b->a && b->a->pipe) (void)b->a->pipe->wait(b);
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
-                    &b->d_medlo, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
     d->release();
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows}) h->release();
+  for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {b->ev_in, b->ev_done, b->ev_out})
+    if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
 }  // extern "C"
 
-namespace {
+namespace dyneng {
 
-// Shared engine of dyn_batch_align / dyn_batch_train: LPT order, HBM planning, chunked launches.
-enum class Job { AlignZ, AlignFull, Train };
-
-int run_job(dyn_batch* b, Job job) {
+// Shared engine of align / train: LPT order, HBM planning, chunked launches -- all ENQUEUED on the
+// handle's compute stream, no host synchronisation. Host-side inputs of the launches (read
+// descriptors, initial per-read state) live in pinned per-batch buffers until the batch is destroyed.
+int enqueue_job(dyn_batch* b, DynJob job) {
   dyn_aligner* a = b->a;
-  int rc = need_device(a);
-  if (rc != DYN_OK) return rc;
-  const bool lattice = job != Job::AlignZ;
-  const bool calc = job == Job::AlignFull;
+  const bool lattice = job != DynJob::AlignZ;
+  const bool calc = job == DynJob::AlignFull;
   const PoreModel& m = a->model;
-  const int z_fail = job == Job::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
-
-  // per-read state (status of host-side failures is final; ok reads start at 0)
-  std::vector<ReadState> st(b->n);
-  for (uint64_t i = 0; i < b->n; ++i) {
-    st[i].Zb = 0.0;
-    st[i].Zf = 0.0;
-    st[i].status = b->reads[i].status;
-    st[i].n_segments = 0;
-  }
-  if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st.data(), b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
+  const int z_fail = job == DynJob::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
 
   // longest reads first (they bound the tail of each launch)
   std::vector<uint32_t> order;
@@ -568,7 +681,7 @@ int run_job(dyn_batch* b, Job job) {
     HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));
     HIP_TRY(a, b->d_medlo.ensure(std::max<uint64_t>(8, b->capacity * 8)));
   }
-  if (job == Job::Train) {
+  if (job == DynJob::Train) {
     HIP_TRY(a, b->d_colw.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_cols1.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_cols2.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
@@ -597,47 +710,44 @@ int run_job(dyn_batch* b, Job job) {
   }
   const uint64_t row_bytes = lattice_bytes_per_row(calc, lpe_separate);
 
-  // greedy chunks in LPT order
-  std::vector<Chunk> chunks;
-  uint64_t used_max = 0;
-  {
-    Chunk cur;
-    uint64_t used = 0;
+  // per-read state (status of host-side failures is final; ok reads start at 0). A read whose lattice
+  // alone exceeds the budget fails on its own (the reference would die of std::bad_alloc for that read
+  // only, segment.py:172-176), it does not take the batch with it.
+  ReadState* st = b->h_state.as<ReadState>();
+  for (uint64_t i = 0; i < b->n; ++i) {
+    st[i].Zb = 0.0;
+    st[i].Zf = 0.0;
+    st[i].status = b->reads[i].status;
+    st[i].n_segments = 0;
+  }
+  if (lattice) {
+    size_t w = 0;
     for (uint32_t i : order) {
-      const uint64_t need = lattice ? (b->reads[i].S + 2) * row_bytes : 0;  // T rows + the -inf row T
-      if (lattice && need > budget) {
-        a->last_error = "a single read's lattice does not fit the HBM budget";
-        return DYN_ERR_OUT_OF_MEMORY;
-      }
-      if (!cur.idx.empty() && used + need > budget) {
-        chunks.push_back(std::move(cur));
-        cur = Chunk();
+      if ((b->reads[i].S + 2) * row_bytes > budget) st[i].status = DYN_READ_TOO_LARGE;
+      else order[w++] = i;
+    }
+    order.resize(w);
+  }
+  if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st, b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
+
+  // greedy chunks in LPT order; a chunk holds at most 65 535 reads (gridDim.y of the per-read kernels)
+  struct Chunk { size_t begin, end; uint64_t ws_rows, rows_total; uint32_t max_T, max_N; };
+  std::vector<Chunk> chunks;
+  HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), order.size() * sizeof(ReadDesc))));
+  ReadDesc* descs = b->h_descs.as<ReadDesc>();
+  dyn_timing tm{};
+  {
+    Chunk cur{0, 0, 0, 0, 0, 0};
+    uint64_t used = 0;
+    for (size_t k = 0; k < order.size(); ++k) {
+      const uint32_t i = order[k];
+      const HostRead& r = b->reads[i];
+      const uint64_t need = lattice ? (r.S + 2) * row_bytes : 0;  // T rows + the -inf row T
+      if (cur.end > cur.begin && (used + need > budget || cur.end - cur.begin >= 65535)) {
+        chunks.push_back(cur);
+        cur = Chunk{k, k, 0, 0, 0, 0};
         used = 0;
       }
-      cur.idx.push_back(i);
-      used += need;
-      used_max = std::max(used_max, used);
-    }
-    if (!cur.idx.empty()) chunks.push_back(std::move(cur));
-  }
-  // pool growth headroom (see DevBuf::ensure), never beyond the budget
-  const double headroom = used_max ? std::min(1.25, std::max(1.0, (double)budget / (double)used_max)) : 1.0;
-
-  dyn_timing tm{};
-  hipEvent_t ev[4];
-  for (auto& e : ev) HIP_TRY(a, hipEventCreate(&e));
-  struct EvGuard {
-    hipEvent_t* e;
-    ~EvGuard() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); }
-  } guard{ev};
-
-  std::vector<ReadDesc> descs;
-  for (const Chunk& ch : chunks) {
-    descs.clear();
-    uint64_t rows_total = 0, ws_rows = 0;  // the lattice workspace holds T+1 rows per read
-    uint32_t max_T = 0, max_N = 0;
-    for (uint32_t i : ch.idx) {
-      const HostRead& r = b->reads[i];
       ReadDesc d{};
       d.T = (uint32_t)(r.S + 1);
       d.N = (uint32_t)(r.kc + 1);
@@ -647,19 +757,35 @@ int run_job(dyn_batch* b, Job job) {
       d.sig_off = r.sig_off;
       d.par_off = r.flat_off;
       d.seg_off = r.seg_off;
-      d.ws_off = ws_rows * dynk::P;
-      d.bits_off = rows_total * dynk::CPL;
-      d.path_off = rows_total;
-      rows_total += d.T;
-      ws_rows += d.T + 1;
-      max_T = std::max(max_T, d.T);
-      max_N = std::max(max_N, d.N);
-      descs.push_back(d);
+      d.ws_off = cur.ws_rows * dynk::P;
+      d.bits_off = cur.rows_total * dynk::CPL;
+      d.path_off = cur.rows_total;
+      cur.rows_total += d.T;
+      cur.ws_rows += d.T + 1;
+      cur.max_T = std::max(cur.max_T, d.T);
+      cur.max_N = std::max(cur.max_N, d.N);
+      descs[k] = d;
+      cur.end = k + 1;
+      used += need;
       tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
       tm.samples += r.S;
     }
-    const int nr = (int)descs.size();
-    HIP_TRY(a, a->descs.ensure(descs.size() * sizeof(ReadDesc)));
+    if (cur.end > cur.begin) chunks.push_back(cur);
+  }
+  // the pools must hold the largest chunk before anything of this batch is launched: growing one
+  // releases the old buffer, which earlier work on the compute stream may still be using
+  {
+    uint64_t ws_rows = 0, rows_total = 0;
+    for (const Chunk& c : chunks) {
+      ws_rows = std::max(ws_rows, c.ws_rows);
+      rows_total = std::max(rows_total, c.rows_total);
+    }
+    const uint64_t used_max = ws_rows * row_bytes;
+    const double headroom = used_max ? std::min(1.25, std::max(1.0, (double)budget / (double)used_max)) : 1.0;
+    const bool grow = (lattice && a->ws.bytes < ws_rows * dynk::P * 8) ||
+                      (calc && ((lpe_separate && a->lpe.bytes < ws_rows * dynk::P * 4) || a->bits.bytes < rows_total * dynk::CPL * 8 ||
+                                a->pp.bytes < rows_total * 8 || a->pathn.bytes < rows_total * 4));
+    if (grow) HIP_TRY(a, hipStreamSynchronize(a->stream));
     if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8, headroom));
     if (calc) {
       if (lpe_separate) HIP_TRY(a, a->lpe.ensure(ws_rows * dynk::P * 4, headroom));
@@ -667,39 +793,68 @@ int run_job(dyn_batch* b, Job job) {
       HIP_TRY(a, a->pp.ensure(rows_total * 8, headroom));
       HIP_TRY(a, a->pathn.ensure(rows_total * 4, headroom));
     }
-    // the previous chunk still reads a->descs: stream order makes the copy safe
-    HIP_TRY(a, hipMemcpyAsync(a->descs.p, descs.data(), descs.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
-    HIP_TRY(a, hipStreamSynchronize(a->stream));  // descs is a host vector reused by the next chunk
+  }
+  HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), order.size() * sizeof(ReadDesc))));
+  if (!order.empty())
+    HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, order.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
 
-    const ReadDesc* dd = a->descs.as<ReadDesc>();
+  while (b->events.size() < 4 * chunks.size()) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(a, hipEventCreate(&e));
+    b->events.push_back(e);  // owned by the batch from here on: destroyed with it whatever happens next
+  }
+  b->n_chunks = (uint32_t)chunks.size();
+
+  const dynmath::SoftplusNode* sp = a->d_sptab.as<dynmath::SoftplusNode>();
+  for (size_t c = 0; c < chunks.size(); ++c) {
+    const Chunk& ch = chunks[c];
+    hipEvent_t* ev = &b->events[4 * c];
+    const int nr = (int)(ch.end - ch.begin);
+    const ReadDesc* dd = b->d_descs.as<ReadDesc>() + ch.begin;
     const double* sig = b->d_sig.as<double>();
     const Emis* par = b->d_par.as<Emis>();
     ReadState* dst = b->d_state.as<ReadState>();
     HIP_TRY(a, hipEventRecord(ev[0], a->stream));
-    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
+    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, sp, a->stream);
     HIP_TRY(a, hipEventRecord(ev[1], a->stream));
-    if (job == Job::Train) {
+    if (job == DynJob::Train) {
       dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
+      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, sp, a->stream);
     } else {
-      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, a->d_sptab.as<dynmath::SoftplusNode>(), a->stream);
+      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, sp, a->stream);
     }
     HIP_TRY(a, hipEventRecord(ev[2], a->stream));
     if (calc) {
       dynk::TraceBuffers tb{a->pp.as<double>(), a->pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
                             b->d_medhi.as<double>(), b->d_medlo.as<double>()};
-      dynk::launch_trace(dd, nr, max_T, max_N, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), sig, par, dst, tb,
+      dynk::launch_trace(dd, nr, ch.max_T, ch.max_N, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), sig, par, dst, tb,
                          b->d_rows.as<SegRow>(), m.k, m.log_m1, z_fail, a->stream);
     } else {
       dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
-      if (job == Job::Train) {
+      if (job == DynJob::Train) {
         dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-        dynk::launch_pool_stats(dd, nr, max_N, dst, b->d_kmers.as<int32_t>(), tb, b->d_pooled.as<double>(), m.num_kmers, a->stream);
+        dynk::launch_pool_stats(dd, nr, ch.max_N, dst, b->d_kmers.as<int32_t>(), tb, b->d_pooled.as<double>(), m.num_kmers, a->stream);
       }
     }
     HIP_TRY(a, hipEventRecord(ev[3], a->stream));
     HIP_TRY(a, hipGetLastError());
-    HIP_TRY(a, hipStreamSynchronize(a->stream));
+  }
+  tm.reads_ok = order.size();
+  tm.launches_backward = tm.launches_forward = (uint32_t)chunks.size();
+  tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
+  b->timing = tm;
+  b->aligned = job != DynJob::Train;
+  b->trained = job == DynJob::Train;
+  b->last_calc = calc ? 1 : 0;
+  return DYN_OK;
+}
+
+int collect_timing(dyn_batch* b) {
+  dyn_aligner* a = b->a;
+  dyn_timing& tm = b->timing;
+  tm.ms_backward = tm.ms_forward = tm.ms_trace = tm.ms_total = 0.0;
+  for (uint32_t c = 0; c < b->n_chunks; ++c) {
+    hipEvent_t* ev = &b->events[4 * c];
     float ms01 = 0, ms12 = 0, ms23 = 0;
     HIP_TRY(a, hipEventElapsedTime(&ms01, ev[0], ev[1]));
     HIP_TRY(a, hipEventElapsedTime(&ms12, ev[1], ev[2]));
@@ -708,16 +863,133 @@ int run_job(dyn_batch* b, Job job) {
     tm.ms_forward += ms12;
     tm.ms_trace += ms23;
     tm.ms_total += ms01 + ms12 + ms23;
-    tm.launches_backward += 1;
-    tm.launches_forward += 1;
-    tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
   }
-  tm.reads_ok = order.size();
-  b->timing = tm;
-  b->aligned = job != Job::Train;
-  b->trained = job == Job::Train;
-  b->last_calc = calc ? 1 : 0;
   return DYN_OK;
+}
+
+// array-of-rows -> the caller's columns; reads are independent, so contiguous ranges of reads go to
+// the helper threads (2 M segments per 1 024-read batch take ~10 ms on one core)
+void unpack_align(const dyn_batch* b, const ReadState* st, const SegRow* rows, dyn_align_out* out,
+                  HelperPool* pool) {
+  const bool want_rows = rows != nullptr;
+  auto unpack = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      const HostRead& r = b->reads[i];
+      const bool ok = st[i].status == DYN_READ_OK;
+      out->status[i] = st[i].status;
+      out->Z[i] = ok ? st[i].Zb : 0.0;  // Result::Z = Zb (NT_aligner_api.cpp:293)
+      if (out->bad_char) out->bad_char[i] = r.bad;
+      if (out->seg_offsets) out->seg_offsets[i] = r.seg_off;
+      const uint64_t ns = (ok && b->last_calc) ? st[i].n_segments : 0;
+      if (out->n_segments) out->n_segments[i] = ns;
+      if (want_rows) {
+        for (uint64_t s = 0; s < ns; ++s) {
+          const SegRow& row = rows[r.seg_off + s];
+          if (out->sequence_positions) out->sequence_positions[r.seg_off + s] = row.sequence_pos;
+          if (out->signal_positions) out->signal_positions[r.seg_off + s] = row.signal_pos;
+          if (out->probabilities) out->probabilities[r.seg_off + s] = row.probability;
+          if (out->states) out->states[r.seg_off + s] = 'M';
+        }
+      }
+    }
+  };
+  const int parts = (pool && want_rows && b->capacity > (1u << 16)) ? (int)std::min<uint64_t>(pool->size(), std::max<uint64_t>(1, b->n / 64)) : 1;
+  if (parts <= 1) unpack(0, b->n);
+  else pool->parallel_for(parts, [&](int t) { unpack(b->n * t / parts, b->n * (t + 1) / parts); });
+  if (out->seg_offsets) out->seg_offsets[b->n] = b->capacity;
+}
+
+// Host finalisation of runTraining (NT_aligner_api.cpp:516-535) from per-column sums, and of
+// trainTransition (:703-722) from the two linear-domain transition sums.
+void finalise_train(const dyn_batch* b, const ReadState* st, const double* cw, const double* c1,
+                    const double* c2, const double* tr, dyn_train_out* out, double* pooled3n) {
+  const PoreModel& m = b->a->model;
+  const bool want_em = out->em_code && out->em_mean && out->em_stdev;
+  const int32_t* kmers = b->kmers();
+  std::vector<std::pair<int32_t, uint64_t>> keyed;
+  for (uint64_t i = 0; i < b->n; ++i) {
+    const HostRead& r = b->reads[i];
+    const bool ok = st[i].status == DYN_READ_OK;
+    out->status[i] = st[i].status;
+    out->Z[i] = ok ? st[i].Zb : 0.0;
+    if (out->bad_char) out->bad_char[i] = r.bad;
+    if (out->em_offsets) out->em_offsets[i] = r.seg_off;
+    uint64_t count = 0;
+    if (out->transitions) {
+      double m1 = 0.0, e2 = 0.0;
+      if (ok) {
+        const double sm = tr[2 * i], se = tr[2 * i + 1];
+        const double tot = sm + se;
+        if (tot > 0.0 && !std::isinf(tot)) {
+          m1 = sm / tot;
+          e2 = se / tot;
+        }
+      }
+      out->transitions[3 * i] = m1;
+      out->transitions[3 * i + 1] = ok ? std::exp(m.log_e1) : 0.0;
+      out->transitions[3 * i + 2] = e2;
+    }
+    if (out->trans_counts) {
+      out->trans_counts[2 * i] = ok ? tr[2 * i] : 0.0;
+      out->trans_counts[2 * i + 1] = ok ? tr[2 * i + 1] : 0.0;
+    }
+    if (ok && (want_em || pooled3n)) {
+      // group the read's lattice columns by k-mer code, columns in ascending order
+      keyed.clear();
+      for (uint64_t c = 0; c < r.kc; ++c) keyed.emplace_back(kmers[r.flat_off + c], r.flat_off + c);
+      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      size_t p = 0;
+      while (p < keyed.size()) {
+        const int32_t code = keyed[p].first;
+        double w = 0.0, s1 = 0.0, s2 = 0.0;
+        for (; p < keyed.size() && keyed[p].first == code; ++p) {
+          w += cw[keyed[p].second];
+          s1 += c1[keyed[p].second];
+          s2 += c2[keyed[p].second];
+        }
+        if (pooled3n) {
+          pooled3n[code] += w;
+          pooled3n[m.num_kmers + code] += s1;
+          pooled3n[2 * m.num_kmers + code] += s2;
+        }
+        if (want_em && w > 0.0) {
+          const double mean = s1 / w;
+          double var = s2 / w - mean * mean;
+          if (var < 1e-12) var = 1e-12;
+          const uint64_t o = r.seg_off + count;
+          out->em_code[o] = code;
+          out->em_mean[o] = mean;
+          out->em_stdev[o] = std::sqrt(var);
+          if (out->em_weight) out->em_weight[o] = w;
+          if (out->em_sum) out->em_sum[o] = s1;
+          if (out->em_sumsq) out->em_sumsq[o] = s2;
+          ++count;
+        }
+      }
+    }
+    if (out->em_count) out->em_count[i] = count;
+  }
+  if (out->em_offsets) out->em_offsets[b->n] = b->capacity;
+}
+
+}  // namespace dyneng
+
+namespace {
+
+int run_job_sync(dyn_batch* b, DynJob job) {
+  dyn_aligner* a = b->a;
+  {
+    std::lock_guard<std::mutex> lk(a->mu);
+    int rc = need_device(a);
+    if (rc != DYN_OK) return rc;
+    rc = enqueue_job(b, job);
+    if (rc != DYN_OK) {
+      (void)hipStreamSynchronize(a->stream);
+      return rc;
+    }
+  }
+  HIP_TRY(a, hipStreamSynchronize(a->stream));
+  return collect_timing(b);
 }
 
 }  // namespace
@@ -726,12 +998,12 @@ extern "C" {
 
 int dyn_batch_align(dyn_batch* b, int calc_probabilities) {
   if (!b) return DYN_ERR_INVALID_ARGUMENT;
-  return run_job(b, calc_probabilities ? Job::AlignFull : Job::AlignZ);
+  return run_job_sync(b, calc_probabilities ? DynJob::AlignFull : DynJob::AlignZ);
 }
 
 int dyn_batch_train(dyn_batch* b) {
   if (!b) return DYN_ERR_INVALID_ARGUMENT;
-  return run_job(b, Job::Train);
+  return run_job_sync(b, DynJob::Train);
 }
 
 int dyn_batch_timing(const dyn_batch* b, dyn_timing* t) {
@@ -770,38 +1042,10 @@ int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out) {
     HIP_TRY(a, hipMemcpy(a->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost));
     rows = static_cast<const SegRow*>(a->h_rows.p);
   }
-  // array-of-rows -> the caller's columns; reads are independent, so contiguous ranges of reads go to
-  // a few threads (2 M segments per 1 024-read batch take ~10 ms on one core)
-  auto unpack = [&](uint64_t lo, uint64_t hi) {
-    for (uint64_t i = lo; i < hi; ++i) {
-      const HostRead& r = b->reads[i];
-      const bool ok = st[i].status == DYN_READ_OK;
-      out->status[i] = st[i].status;
-      out->Z[i] = ok ? st[i].Zb : 0.0;  // Result::Z = Zb (NT_aligner_api.cpp:293)
-      if (out->bad_char) out->bad_char[i] = r.bad;
-      if (out->seg_offsets) out->seg_offsets[i] = r.seg_off;
-      const uint64_t ns = (ok && b->last_calc) ? st[i].n_segments : 0;
-      if (out->n_segments) out->n_segments[i] = ns;
-      if (want_rows) {
-        for (uint64_t s = 0; s < ns; ++s) {
-          const SegRow& row = rows[r.seg_off + s];
-          if (out->sequence_positions) out->sequence_positions[r.seg_off + s] = row.sequence_pos;
-          if (out->signal_positions) out->signal_positions[r.seg_off + s] = row.signal_pos;
-          if (out->probabilities) out->probabilities[r.seg_off + s] = row.probability;
-          if (out->states) out->states[r.seg_off + s] = 'M';
-        }
-      }
-    }
-  };
-  const uint64_t n_thr = (want_rows && b->capacity > (1u << 16)) ? std::min<uint64_t>(4, std::max<uint64_t>(1, b->n / 64)) : 1;
-  if (n_thr <= 1) {
-    unpack(0, b->n);
-  } else {
-    std::vector<std::thread> pool;
-    for (uint64_t k = 0; k < n_thr; ++k) pool.emplace_back(unpack, b->n * k / n_thr, b->n * (k + 1) / n_thr);
-    for (auto& th : pool) th.join();
-  }
-  if (out->seg_offsets) out->seg_offsets[b->n] = b->capacity;
+  static HelperPool pool(4);
+  static std::mutex pool_mu;
+  std::lock_guard<std::mutex> lk(pool_mu);
+  unpack_align(b, st.data(), rows, out, &pool);
   return DYN_OK;
 }
 
@@ -817,8 +1061,6 @@ int dyn_align_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
   return rc;
 }
 
-// Host finalisation of runTraining (NT_aligner_api.cpp:516-535) from per-column sums, and of
-// trainTransition (:703-722) from the two linear-domain transition sums.
 int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n) {
   if (!b || !out || !out->Z || !out->status) return DYN_ERR_INVALID_ARGUMENT;
   dyn_aligner* a = b->a;
@@ -828,7 +1070,11 @@ int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n) {
   }
   int rc = need_device(a);
   if (rc != DYN_OK) return rc;
-  const PoreModel& m = a->model;
+  const bool want_em = out->em_code && out->em_mean && out->em_stdev;
+  if (want_em && out->capacity < b->capacity) {
+    a->last_error = "dyn_train_out.capacity is smaller than dyn_segment_capacity()";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
   std::vector<ReadState> st(b->n);
   std::vector<double> cw(b->total_cols), c1(b->total_cols), c2(b->total_cols), tr(2 * b->n);
   if (b->n) {
@@ -840,75 +1086,7 @@ int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n) {
     HIP_TRY(a, hipMemcpy(c1.data(), b->d_cols1.p, b->total_cols * 8, hipMemcpyDeviceToHost));
     HIP_TRY(a, hipMemcpy(c2.data(), b->d_cols2.p, b->total_cols * 8, hipMemcpyDeviceToHost));
   }
-  const bool want_em = out->em_code && out->em_mean && out->em_stdev;
-  if (want_em && out->capacity < b->capacity) {
-    a->last_error = "dyn_train_out.capacity is smaller than dyn_segment_capacity()";
-    return DYN_ERR_INVALID_ARGUMENT;
-  }
-  std::vector<std::pair<int32_t, uint64_t>> keyed;
-  for (uint64_t i = 0; i < b->n; ++i) {
-    const HostRead& r = b->reads[i];
-    const bool ok = st[i].status == DYN_READ_OK;
-    out->status[i] = st[i].status;
-    out->Z[i] = ok ? st[i].Zb : 0.0;
-    if (out->bad_char) out->bad_char[i] = r.bad;
-    if (out->em_offsets) out->em_offsets[i] = r.seg_off;
-    uint64_t count = 0;
-    if (out->transitions) {
-      double m1 = 0.0, e2 = 0.0;
-      if (ok) {
-        const double sm = tr[2 * i], se = tr[2 * i + 1];
-        const double tot = sm + se;
-        if (tot > 0.0 && !std::isinf(tot)) {
-          m1 = sm / tot;
-          e2 = se / tot;
-        }
-      }
-      out->transitions[3 * i] = m1;
-      out->transitions[3 * i + 1] = ok ? std::exp(m.log_e1) : 0.0;
-      out->transitions[3 * i + 2] = e2;
-    }
-    if (out->trans_counts) {
-      out->trans_counts[2 * i] = ok ? tr[2 * i] : 0.0;
-      out->trans_counts[2 * i + 1] = ok ? tr[2 * i + 1] : 0.0;
-    }
-    if (ok && (want_em || pooled3n)) {
-      // group the read's lattice columns by k-mer code, columns in ascending order
-      keyed.clear();
-      for (uint64_t c = 0; c < r.kc; ++c) keyed.emplace_back(b->kmers[r.flat_off + c], r.flat_off + c);
-      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-      size_t p = 0;
-      while (p < keyed.size()) {
-        const int32_t code = keyed[p].first;
-        double w = 0.0, s1 = 0.0, s2 = 0.0;
-        for (; p < keyed.size() && keyed[p].first == code; ++p) {
-          w += cw[keyed[p].second];
-          s1 += c1[keyed[p].second];
-          s2 += c2[keyed[p].second];
-        }
-        if (pooled3n) {
-          pooled3n[code] += w;
-          pooled3n[m.num_kmers + code] += s1;
-          pooled3n[2 * m.num_kmers + code] += s2;
-        }
-        if (want_em && w > 0.0) {
-          const double mean = s1 / w;
-          double var = s2 / w - mean * mean;
-          if (var < 1e-12) var = 1e-12;
-          const uint64_t o = r.seg_off + count;
-          out->em_code[o] = code;
-          out->em_mean[o] = mean;
-          out->em_stdev[o] = std::sqrt(var);
-          if (out->em_weight) out->em_weight[o] = w;
-          if (out->em_sum) out->em_sum[o] = s1;
-          if (out->em_sumsq) out->em_sumsq[o] = s2;
-          ++count;
-        }
-      }
-    }
-    if (out->em_count) out->em_count[i] = count;
-  }
-  if (out->em_offsets) out->em_offsets[b->n] = b->capacity;
+  finalise_train(b, st.data(), cw.data(), c1.data(), c2.data(), tr.data(), out, pooled3n);
   return DYN_OK;
 }
 
@@ -926,7 +1104,7 @@ int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
 
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
   if (!b || !b->trained) return DYN_ERR_INVALID_ARGUMENT;
-  // filled on the device by k_pool_stats during dyn_batch_train (run_job)
+  // filled on the device by k_pool_stats during dyn_batch_train (enqueue_job)
   if (d_pooled3n) *d_pooled3n = b->d_pooled.p;
   if (count) *count = 3 * b->a->model.num_kmers;
   return DYN_OK;

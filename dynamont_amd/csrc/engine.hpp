@@ -1,0 +1,202 @@
+// engine.hpp -- host-side state shared by the C-ABI entry points (dynamont_mi.cpp) and the
+// asynchronous batch pipeline (async_engine.cpp).
+//
+// The reference keeps its worker processes permanently fed (src/dynamont/segmentation/segment.py:
+// 301-325: a multiprocessing pool over generate_jobs with a listener process draining results).
+// The GPU counterpart of that is a three-stage pipeline per handle:
+//   front thread : validateInput + sequenceToKmers of batch k+1, staging into pinned memory, H2D on
+//                  the copy-in stream, kernel launches on the compute stream (no host sync)
+//   GPU          : kernels of batch k (compute stream), D2H of batch k-1 (copy-out stream)
+//   back thread  : unpack of batch k-1 into the caller's columns
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/dynamont_mi.h"
+#include "nt_kernels.hpp"
+#include "pore_model.hpp"
+
+namespace dyneng {
+
+// Recycles device and pinned-host allocations of finished batches: hipFree synchronises the whole
+// device and hipHostMalloc of a 160 MB buffer costs tens of milliseconds, either of which would
+// stall a pipeline that has other batches in flight. Sizes are rounded up to a granule so that a
+// stream of batches of slightly different size keeps hitting the same buffers.
+struct BufCache {
+  std::mutex m;
+  std::multimap<size_t, void*> dev, pin;
+  static size_t round_up(size_t want);
+  hipError_t take(bool pinned, size_t want, void** p, size_t* got);
+  void give(bool pinned, void* p, size_t bytes);
+  void purge();  // frees everything (handle destruction; device idle)
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  BufCache* cache = nullptr;  // nullptr: grow-only buffer owned by the handle (lattice pools)
+  // grow-only. `headroom` > 1 over-allocates when the buffer has to grow: releasing and re-allocating
+  // a 70 GB lattice pool costs 4-5 s on an MI355X (measured, tools/batch_latency.py), which a stream
+  // of batches of slightly different size would otherwise pay every time a new maximum shows up.
+  hipError_t ensure(size_t want, double headroom = 1.0);
+  void release();
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  BufCache* cache = nullptr;
+  hipError_t ensure(size_t want);
+  void release();
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Small persistent worker pool for the host stages that are plain memory work (staging copies into
+// pinned memory, rows -> columns unpack, k-mer coding).
+class HelperPool {
+ public:
+  explicit HelperPool(int n_threads);
+  ~HelperPool();
+  // fn(task) for task in [0, n_tasks); returns when all are done. The calling thread takes part.
+  void parallel_for(int n_tasks, const std::function<void(int)>& fn);
+  int size() const { return (int)workers_.size() + 1; }
+
+ private:
+  void worker();
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int next_ = 0, n_ = 0, active_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+struct Pipeline;
+
+}  // namespace dyneng
+
+struct dyn_aligner {
+  dynhost::PoreModel model;
+  int device = -1;
+  bool host_only = false;
+  int threads = 1;
+  hipStream_t stream = nullptr;  // compute stream: every kernel of every batch of this handle, in submission order
+  hipStream_t s_in = nullptr;    // H2D of the asynchronous pipeline
+  hipStream_t s_out = nullptr;   // D2H of the asynchronous pipeline
+  dyneng::DevBuf d_model;
+  dyneng::DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
+  uint64_t mem_budget = 0;
+  std::string last_error;
+  // grow-only lattice workspace pool, reused across batches (only ever touched by work on `stream`,
+  // whose order serialises the batches that share it)
+  dyneng::DevBuf ws, lpe, bits, pp, pathn;
+  dyneng::PinnedBuf h_rows;  // staging of the synchronous dyn_batch_fetch
+  dyneng::BufCache cache;
+  // serialises GPU enqueue work on this handle between the caller's thread and the pipeline threads
+  std::mutex mu;
+  std::unique_ptr<dyneng::Pipeline> pipe;  // started by the first asynchronous submit
+};
+
+struct HostRead {
+  uint64_t S = 0, L = 0, kc = 0;
+  uint64_t sig_off = 0, flat_off = 0 /* into kmers / per-column tables */, seg_off = 0;
+  int32_t status = 0;
+  char bad = 0;
+};
+
+enum class DynJob { AlignZ, AlignFull, Train };
+
+struct dyn_batch {
+  dyn_aligner* a = nullptr;
+  uint64_t n = 0;
+  std::vector<HostRead> reads;
+  dyneng::PinnedBuf h_kmers;   // flat int32 codes, ok reads only
+  uint64_t capacity = 0;       // sum of kc over ALL reads with L >= k (segment rows)
+  uint64_t total_cols = 0;     // sum of kc over ok reads
+  uint32_t max_T = 0, max_N = 0;
+  dyneng::DevBuf d_sig, d_kmers, d_par, d_state, d_rows, d_segrow, d_medhi, d_medlo, d_descs;
+  dyneng::DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled;
+  dyneng::PinnedBuf h_descs, h_state, h_rows;  // h_state/h_rows: D2H targets of the asynchronous path
+  std::vector<hipEvent_t> events;              // 4 per launch group (chunk)
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+  uint32_t n_chunks = 0;
+  dyn_timing timing{};
+  bool aligned = false, trained = false;
+  int last_calc = 0;
+  // ---- asynchronous submission (async_engine.cpp) ----
+  bool async = false;
+  DynJob job = DynJob::AlignFull;
+  const double* in_signals = nullptr;
+  const uint64_t* in_sig_offsets = nullptr;
+  const char* in_seqs = nullptr;
+  const uint64_t* in_seq_offsets = nullptr;
+  dyn_align_out* out_align = nullptr;
+  dyn_train_out* out_train = nullptr;
+  double* out_pooled = nullptr;
+  int rc = DYN_OK;             // result of the pipeline stages
+  std::string error;           // message for rc != DYN_OK (copied to the handle by dyn_batch_wait)
+  bool done = false;
+  const int32_t* kmers() const { return h_kmers.as<int32_t>(); }
+};
+
+namespace dyneng {
+
+// ---- shared between dynamont_mi.cpp and async_engine.cpp -------------------------------------
+int need_device(dyn_aligner* a);
+// per-batch buffers come from / go back to the handle's BufCache
+void attach_cache(dyn_batch* b);
+// validateInput + sequenceToKmers of every read; fills b->reads / b->h_kmers / capacity / max_T / max_N
+// (pinned: k-mer codes go to pinned memory for an asynchronous H2D; false = plain malloc, no HIP call)
+int host_prepare(dyn_batch* b, const dynhost::PoreModel& m, bool pinned, uint64_t n_reads,
+                 const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets, HelperPool* pool);
+// allocate the per-batch device buffers (from the handle's cache)
+int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig);
+// enqueue every kernel of `job` on the handle's compute stream without synchronising the host
+int enqueue_job(dyn_batch* b, DynJob job);
+// after the compute stream has passed the batch: read the event timings into b->timing
+int collect_timing(dyn_batch* b);
+// rows/state (host copies) -> the caller's columns
+void unpack_align(const dyn_batch* b, const dynk::ReadState* st, const dynk::SegRow* rows, dyn_align_out* out,
+                  HelperPool* pool);
+// host finalisation of runTraining / trainTransition from host copies of the per-column sums
+void finalise_train(const dyn_batch* b, const dynk::ReadState* st, const double* cw, const double* c1,
+                    const double* c2, const double* tr, dyn_train_out* out, double* pooled3n);
+
+struct Pipeline {
+  explicit Pipeline(dyn_aligner* a);
+  ~Pipeline();
+  void submit(dyn_batch* b);
+  int wait(dyn_batch* b);
+  void drain();
+
+  dyn_aligner* a;
+  HelperPool helpers;
+  std::thread t_front, t_back;
+  std::mutex m;
+  std::condition_variable cv_front, cv_back, cv_done;
+  std::deque<dyn_batch*> q_front, q_back;
+  uint64_t in_flight = 0;
+  bool stop = false;
+
+ private:
+  void front_loop();
+  void back_loop();
+  int front_stage(dyn_batch* b);
+  int back_stage(dyn_batch* b);
+};
+
+}  // namespace dyneng

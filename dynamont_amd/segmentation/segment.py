@@ -32,6 +32,7 @@ POLYA = "AAAAAAAAA"
 RAW_CACHE: OrderedDict | None = None
 RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
 ZSTD_WORKERS = 0    # compression threads of the writer (0: up to 8 host cores; level 3 as the reference)
+ZSTD_PARALLEL_FRAMES = False  # --parallel-zstd-frames: consecutive independent frames instead of the reference's one
 
 
 def parse(argv=None) -> Namespace:
@@ -51,6 +52,9 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
     p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same bytes)")
+    p.add_argument("--parallel-zstd-frames", action="store_true",
+                   help="compress the CSV on several threads as consecutive zstd frames (faster; readers must read across frames, "
+                        "python-zstandard's defaults stop after the first frame). Default: one frame, like the reference")
     return p.parse_args(argv)
 
 
@@ -60,7 +64,7 @@ def listener(q, outfile: str) -> None:
     errfile = splitext(splitext(outfile)[0])[0] + ".errors"
     num_err = 0
     with open(outfile, "wb") as raw:
-        with open_writer(raw, level=3, threads=ZSTD_WORKERS) as output:
+        with open_writer(raw, level=3, threads=ZSTD_WORKERS, parallel_frames=ZSTD_PARALLEL_FRAMES) as output:
             output.write(CSV_HEADER)
             while True:
                 result = q.get()
@@ -308,6 +312,8 @@ def main(argv=None) -> None:
         model_path = get_model(args.pore)
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
+    global ZSTD_PARALLEL_FRAMES
+    ZSTD_PARALLEL_FRAMES = bool(args.parallel_zstd_frames)
     segment(args.raw, args.basecalls, args.processes, outfile, model_path, args.pore, args.mode, args.qscore,
             device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget,
             host_preprocess=args.host_preprocess)

@@ -11,9 +11,10 @@
  * Conventions: plain pointers and sizes only; no exceptions cross the ABI; functions return
  * a dyn_status; message texts equal the reference's exception texts (callers print them
  * into the `.errors` file, segment.py:172-176, so they are observable output).
- * A handle is bound to ONE GPU (one process per GPU; shard reads across handles/ranks).
- * A handle is not re-entrant: serialise calls per handle (the reference keeps one Aligner per
- * worker process, segment.py:34-45).
+ * A handle is bound to ONE GPU (one process per GPU; shard reads across handles/ranks, or use
+ * dyn_multi_* below, which owns one handle per device). GPU work of one handle is serialised
+ * internally, so calls on DIFFERENT batches of one handle may come from different threads; a
+ * single batch object must not be used from two threads at once.
  */
 #ifndef DYNAMONT_MI_H
 #define DYNAMONT_MI_H
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 1
+#define DYN_ABI_VERSION 2
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -61,7 +62,10 @@ enum dyn_read_status {
   DYN_READ_INVALID_NT = 4,       /* "Invalid nucleotide: X"                  aligner.cpp:180-196 */
   DYN_READ_Z_MISMATCH = 5,       /* "Alignment failed: alignment scores do not match"  NT_aligner_api.cpp:288-291 */
   DYN_READ_TRAIN_Z_MISMATCH = 6, /* "Training failed: alignment scores do not match"   NT_aligner_api.cpp:622-625 */
-  DYN_READ_INTERNAL = 7          /* traceback left the lattice (cannot happen once the Z check passed) */
+  DYN_READ_INTERNAL = 7,         /* traceback left the lattice (cannot happen once the Z check passed) */
+  DYN_READ_TOO_LARGE = 8         /* "Read too large for the device memory budget": this read's lattice alone exceeds
+                                    the HBM budget (or 2^31 rows); the reference would raise std::bad_alloc for that
+                                    read only (segment.py:172-176), so it is a per-read status, not a batch error */
 };
 
 typedef struct dyn_aligner dyn_aligner;
@@ -239,6 +243,32 @@ int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, vo
  * dyn_batch_train, for an RCCL all-reduce. */
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count);
 int dyn_batch_timing(const dyn_batch* b, dyn_timing* t);
+
+/* ---- asynchronous form: a stream of batches with H2D, kernels, D2H and host marshalling of
+ * neighbouring batches overlapped (the reference keeps its worker pool permanently fed,
+ * segment.py:301-325) ----
+ *
+ * dyn_batch_align_async == dyn_align_batch, but returns at once with a ticket: validateInput /
+ * sequenceToKmers, the H2D copy, every kernel, the D2H copy and the unpacking into `out` run on the
+ * handle's pipeline threads and streams. Batches of one handle complete in submission order.
+ * EVERYTHING the call was given (signals, offsets, seqs, `out` and the arrays it points to) must stay
+ * valid and untouched until dyn_batch_wait(ticket) has returned. After the wait the ticket behaves
+ * like an aligned batch: dyn_batch_timing and dyn_batch_device_results work on it. Release it with
+ * dyn_batch_destroy (which waits first if need be). Inputs allocated with dyn_host_alloc are copied
+ * by DMA without staging. */
+int dyn_batch_align_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                          const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                          int calc_probabilities, dyn_align_out* out, dyn_batch** ticket);
+/* dyn_train_batch in the same form (pooled3n as there; it is accumulated into when the batch completes). */
+int dyn_batch_train_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
+                          const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
+                          dyn_train_out* out, double* pooled3n, dyn_batch** ticket);
+/* Block until the batch behind the ticket is complete; returns its status code, with the message in
+ * dyn_aligner_last_error. Returns DYN_OK at once for batches of the synchronous calls. */
+int dyn_batch_wait(dyn_batch* ticket);
+/* Page-locked host memory for inputs/outputs of the asynchronous calls (NULL on failure). */
+void* dyn_host_alloc(uint64_t bytes);
+void dyn_host_free(void* p);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,126 @@
+"""GPU (-m gpu): the asynchronous pipeline (dyn_batch_align_async / _train_async / _wait) must
+return exactly what the synchronous calls return -- several batches in flight, failed reads isolated
+per read, pageable and page-locked caller memory -- and stay correct against the CPU oracle."""
+import numpy as np
+import pytest
+
+from dynamont_amd import Aligner, synth
+from dynamont_amd._dynamont import pinned_empty
+from oracle.pyoracle import Oracle
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib", "oracle_built")]
+
+
+def _batches(models, n_batches, n_reads, seed0=900, bases=(60, 400)):
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    out = []
+    for j in range(n_batches):
+        reads = synth.make_reads(seed0 + j, n_reads + j, "rna004", mean, sd, bases)
+        out.append((reads, synth.pack_reads(reads)))
+    return out
+
+
+def _same(a, b):
+    assert np.array_equal(a.status, b.status)
+    assert np.array_equal(a.Z, b.Z)
+    assert np.array_equal(a.n_segments, b.n_segments)
+    assert np.array_equal(a.seg_offsets, b.seg_offsets)
+    for i in range(a.n):
+        lo, hi = int(a.seg_offsets[i]), int(a.seg_offsets[i]) + int(a.n_segments[i])
+        assert np.array_equal(a.signal_positions[lo:hi], b.signal_positions[lo:hi])
+        assert np.array_equal(a.sequence_positions[lo:hi], b.sequence_positions[lo:hi])
+        assert np.array_equal(a.probabilities[lo:hi], b.probabilities[lo:hi])
+        assert np.array_equal(a.states[lo:hi], b.states[lo:hi])
+
+
+def test_async_equals_sync_with_batches_in_flight(models):
+    al = Aligner(models["syn9"], "rna004", device=0)
+    data = _batches(models, 6, 24)
+    want = []
+    for reads, _ in data:
+        want.append(al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True))
+    tickets = [al.align_async(*packed, True) for _, packed in data]  # all six in flight at once
+    for t, w in zip(tickets, want):
+        _same(t.wait(), w)
+        tm = t.timing()
+        assert tm["reads_ok"] == int((w.status == 0).sum()) and tm["ms_total"] > 0
+        ptr, cap, st = t.device_results()
+        assert ptr and st and cap == w.seg_offsets[-1]
+    for t in tickets:
+        t.close()
+    # result objects can be refilled by later batches
+    t = al.align_async(*data[0][1], True, out=want[3])
+    _same(t.wait(), al.align_batch([r.signal for r in data[0][0]], [r.sequence for r in data[0][0]], True))
+    t.close()
+    al.close()
+
+
+def test_async_isolates_failed_reads_and_matches_oracle(models):
+    al = Aligner(models["syn9"], "rna004", device=0)
+    orc = Oracle(models["syn9"], 1)
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(77, 10, "rna004", mean, sd, (80, 300))
+    sigs = [r.signal for r in reads]
+    seqs = [r.sequence for r in reads]
+    seqs[2] = seqs[2][:40] + "N" + seqs[2][41:]           # Invalid nucleotide: N
+    sigs[5] = sigs[5][:50]                                 # Signal too short compared to sequence
+    seqs[7] = "ACGT"                                       # Sequence shorter than model kmer size
+    sigs[8] = np.zeros(0)                                  # Signal is empty
+    packed = synth.pack_reads([synth.SynthRead(np.asarray(s, dtype=np.float64), q) for s, q in zip(sigs, seqs)])
+    t = al.align_async(*packed, True)
+    res = t.wait()
+    assert [res.error(i) for i in (2, 5, 7, 8)] == ["Invalid nucleotide: N", "Signal too short compared to sequence",
+                                                    "Sequence shorter than model kmer size", "Signal is empty"]
+    for i in (0, 1, 3, 4, 6, 9):
+        got, ref = res.read(i), orc.align(sigs[i], seqs[i], True)
+        assert np.array_equal(got["signal_positions"], ref["signal_positions"])
+        assert np.array_equal(got["sequence_positions"], ref["sequence_positions"])
+        assert np.abs(got["probabilities"] - ref["probabilities"]).max() <= 1e-6
+        assert abs(got["Z"] - ref["Z"]) <= 1e-9 * abs(ref["Z"])
+    t.close()
+    # Z only
+    t = al.align_async(*packed, False)
+    rz = t.wait()
+    assert np.array_equal(rz.status, res.status) and int(rz.n_segments.sum()) == 0
+    ok = res.status == 0
+    assert np.array_equal(rz.Z[ok], res.Z[ok])
+    t.close()
+    al.close()
+
+
+def test_async_pinned_inputs_and_unwaited_destroy(models):
+    al = Aligner(models["syn9"], "rna004", device=0)
+    (reads, (sig, sig_off, seqs, seq_off)), = _batches(models, 1, 32, seed0=31)
+    want = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    ps = pinned_empty(sig.size, np.float64)
+    ps[:] = sig
+    t = al.align_async(ps, sig_off, seqs, seq_off, True)
+    _same(t.wait(), want)
+    t.close()
+    t = al.align_async(ps, sig_off, seqs, seq_off, True)
+    t.close()  # never waited for: destroy waits
+    al.close()  # handle destruction drains the pipeline
+
+
+def test_train_async_equals_train(models):
+    al = Aligner(models["syn9"], "rna004", device=0)
+    data = _batches(models, 3, 6, seed0=400, bases=(60, 200))
+    for reads, packed in data:
+        want = al.train_batch([r.signal for r in reads], [r.sequence for r in reads], pooled=True)
+        t = al.train_async(*packed, pooled=True)
+        got = t.wait()
+        assert np.array_equal(got.status, want.status) and np.array_equal(got.Z, want.Z)
+        assert np.array_equal(got.transitions, want.transitions)
+        assert np.array_equal(got.em_count, want.em_count)
+        n = int(got.em_offsets[-1])
+        assert np.array_equal(got.em_code[:n], want.em_code[:n]) and np.array_equal(got.em_mean[:n], want.em_mean[:n])
+        assert np.array_equal(got.pooled, want.pooled)
+        ptr, cnt = t.device_pooled()
+        assert ptr and cnt == 3 * al.num_kmers
+        t.close()
+        # statistics-only form: no per-read emission arrays, same Z / transition counts
+        t = al.train_async(*packed, pooled=False, emissions=False)
+        lean = t.wait()
+        assert np.array_equal(lean.Z, want.Z) and np.array_equal(lean.trans_counts, want.trans_counts)
+        t.close()
+    al.close()

@@ -185,6 +185,42 @@ def test_zstd_parallel_frames_roundtrip(threads, chunk):
     assert empty.getvalue()[:4] == b"\x28\xb5\x2f\xfd" and zstd_io.decompress(empty.getvalue()) == b""
 
 
+def test_cli_writer_is_one_frame_by_default(tmp_path):
+    """python-zstandard's default readers stop after the first frame, so the CLI must write ONE frame
+    like the reference (segment.py:74-79) unless the user opts into parallel frames."""
+    rng = np.random.default_rng(2)
+    payload = b"".join(b"r%d,%d,%f\n" % (i, i * 7, x) for i, x in enumerate(rng.standard_normal(600000)))
+    assert len(payload) > 3 * (4 << 20)               # several chunks of the parallel writer
+    one, many = io.BytesIO(), io.BytesIO()
+    with zstd_io.open_writer(one) as w:
+        for i in range(0, len(payload), 1 << 20):
+            w.write(payload[i:i + (1 << 20)])
+    with zstd_io.open_writer(many, parallel_frames=True) as w:
+        w.write(payload)
+    assert zstd_io.count_frames(one.getvalue()) == 1
+    assert zstd_io.count_frames(many.getvalue()) > 1
+    assert zstd_io.decompress(one.getvalue()) == payload and zstd_io.decompress(many.getvalue()) == payload
+    # the listener (what dynamont-resquiggle runs) uses the default
+    out = tmp_path / "big.csv.zst"
+    q = queue.Queue()
+    q.put(payload)
+    q.put("kill")
+    seg.listener(q, str(out))
+    assert zstd_io.count_frames(out.read_bytes()) == 1
+
+
+def test_cli_output_reads_with_zstandard_defaults(tmp_path):
+    zstandard = pytest.importorskip("zstandard")      # not in the build image; runs wherever it is installed
+    payload = b"".join(b"r%d,%d\n" % (i, i * 7) for i in range(1500000))
+    out = tmp_path / "big.csv.zst"
+    q = queue.Queue()
+    q.put(payload)
+    q.put("kill")
+    seg.listener(q, str(out))
+    with zstandard.ZstdDecompressor().stream_reader(io.BytesIO(out.read_bytes())) as r:
+        assert r.read() == seg.CSV_HEADER + payload
+
+
 @pytest.mark.parametrize("pore", ["rna004", "dna_r10_400bps"])
 def test_job_generation_and_preprocessing(models, tmp_path, pore):
     _, mean, sd = synth.read_model_file(model_for(models, pore))
