@@ -35,10 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
-KFWD_BYTES_PER_CELL = 12.125     # dominant kernel of align: read bE 8 B + write float LPE 4 B + 1 decision bit
-KFWD_INPLACE_BYTES_PER_CELL = 16.125  # footprint-limited layout: read bE 8 B + write (float LPM, float LPE) 8 B + 1 bit
-KBWD_BYTES_PER_CELL = 8.0        # write bE
-KTRAIN_BYTES_PER_CELL = 8.0      # dominant kernel of train (k_forward_train): read bE
+# ALGORITHMIC bytes per in-band lattice cell of k_read_queue, the one kernel that runs a read's whole pipeline:
+KBWD_BYTES_PER_CELL = 8.0        # backward sweep: write bE
+KFWD_BYTES_PER_CELL = 12.125     # forward sweep: read bE 8 B + write float LPE 4 B + 1 decision bit
+KFWD_INPLACE_BYTES_PER_CELL = 16.125  # page-starved layout: read bE 8 B + write (float LPM, float LPE) 8 B + 1 bit
+KTRAIN_BYTES_PER_CELL = 8.0      # forward sweep of train(): read bE
 
 WORKLOADS = {
     # name -> (synth config, reads per batch, default number of distinct batches)
@@ -223,10 +224,12 @@ def main():
                     dist.gather(h, [torch.empty_like(h) for _ in range(n_gpus)] if rank == 0 else None, dst=0)
         if timed:
             tm = t.timing()
-            for key in ("ms_backward", "ms_forward", "ms_trace", "ms_total"):
+            for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy"):
                 kern[key] += tm[key]
-            for key in ("launches_forward", "launches_backward", "cells", "lp_inplace"):
+            for key in ("launches", "cells", "lp_inplace"):
                 launches[key] += tm[key]
+            launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
+            launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
             done_steps[0] += 1
         t.close()
         if args.mode == "align":
@@ -289,29 +292,34 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = total_samples / elapsed / 1e6
         cells_total = launches["cells"]
-        n_fwd = max(1, launches["launches_forward"])
-        ms_fwd = kern["ms_forward"] / n_fwd          # average launch duration of the dominant kernel (HIP events on its stream)
-        ms_bwd = kern["ms_backward"] / max(1, launches["launches_backward"])
-        cells_per_launch = cells_total / n_fwd
+        n_launch = max(1, launches["launches"])
+        ms_dp = kern["ms_dp"] / n_launch             # average duration of the dominant kernel (HIP events on its stream)
+        cells_per_launch = cells_total / n_launch
         inplace = bool(launches["lp_inplace"])
         traffic = load_traffic() or {}
         if args.mode == "train":
-            kname, bpc = "k_forward_train (forward + Baum-Welch statistics, fused)", KTRAIN_BYTES_PER_CELL
-            tbytes = traffic.get("k_forward_train_bytes_per_launch") if workload == "cfg5_share" and not args.reads else None
+            kname = "k_read_queue<JOB_TRAIN> (per read: backward sweep, forward sweep + Baum-Welch statistics)"
+            bpc_f, tkey = KTRAIN_BYTES_PER_CELL, "k_read_queue_train_bytes_per_launch"
         else:
-            kname = "k_forward<POST> (forward + posterior + posterior-Viterbi, fused)"
-            bpc = KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL
-            tbytes = traffic.get("k_forward_bytes_per_launch") if (workload == "cfg2" and not args.reads and not inplace) else None
-        achieved = cells_per_launch * bpc / (ms_fwd * 1e-3) / 1e9 if ms_fwd else 0.0
+            kname = "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else "")
+            bpc_f, tkey = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "k_read_queue_align_bytes_per_launch"
+        bpc = KBWD_BYTES_PER_CELL + bpc_f
+        tbytes = traffic.get(tkey) if (workload == traffic.get("workload") and not args.reads and not inplace) else None
+        achieved = cells_per_launch * bpc / (ms_dp * 1e-3) / 1e9 if ms_dp else 0.0
+        share = lambda key: kern[key] / kern["ms_dp"] if kern["ms_dp"] else 0.0
         roofline = {
             "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": tbytes,
-            "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": n_fwd,
-            "avg_launch_ms": round(ms_fwd, 3),
-            "k_backward": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "avg_launch_ms": round(ms_bwd, 3),
-                           "achieved": round(cells_per_launch * KBWD_BYTES_PER_CELL / (ms_bwd * 1e-3) / 1e9, 1) if ms_bwd else None},
+            "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": n_launch,
+            "avg_launch_ms": round(ms_dp, 3),
+            # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
+            "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
+                                "waiting_for_pages": round(kern["wave_wait_share"] / steps, 4)},
+            "wave_occupancy": round(kern["wave_occupancy"] / steps, 4),
+            "page_pool": {"pages": launches["pool_pages"], "rows_per_page": launches["page_rows"],
+                          "reads_with_reserved_pages": launches["n_static"], "waves": launches["n_waves"]},
         }
         what = "calc_probabilities=true" if args.mode == "align" else "train()"
         line = {
@@ -326,7 +334,7 @@ def main():
                        "parallelism": f"reads sharded x{n_gpus}" + ((", RCCL gather of segment rows to rank 0" if args.mode == "align" else ", RCCL all-reduce of pooled statistics") if use_dist else "")},
             "reads_per_s": round(total_reads / elapsed, 1),
             "reads_ok_last_batch": ok,
-            "kernel_ms_per_step": {k_: round(v / steps, 3) for k_, v in kern.items()},
+            "kernel_ms_per_step": {k_: round(v / steps, 3) for k_, v in kern.items() if k_.startswith("ms_")},
             "kernel_resident_Msamp_s": round(resident["samples"] / resident["ms_total"] / 1e3, 3) if resident and resident["ms_total"] else None,
             "pipeline_efficiency": round((total_samples / n_gpus / elapsed / 1e6) / (resident["samples"] / resident["ms_total"] / 1e3), 4) if resident and resident["ms_total"] else None,
             "roofline": roofline,

@@ -45,9 +45,11 @@ class DynTrainOut(C.Structure):
 
 
 class DynTiming(C.Structure):
-    _fields_ = [("ms_total", C.c_double), ("ms_backward", C.c_double), ("ms_forward", C.c_double),
-                ("ms_trace", C.c_double), ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
-                ("launches_backward", C.c_uint32), ("launches_forward", C.c_uint32), ("lp_inplace", C.c_uint32)]
+    _fields_ = [("ms_total", C.c_double), ("ms_dp", C.c_double), ("ms_backward", C.c_double), ("ms_forward", C.c_double),
+                ("ms_trace", C.c_double), ("wave_wait_share", C.c_double), ("wave_occupancy", C.c_double),
+                ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
+                ("launches", C.c_uint32), ("lp_inplace", C.c_uint32), ("pool_pages", C.c_uint32),
+                ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)

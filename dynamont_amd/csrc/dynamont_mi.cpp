@@ -201,10 +201,6 @@ void copy_msg(char* buf, uint64_t cap, const std::string& s) {
     }                                                                                     \
   } while (0)
 
-uint64_t lattice_bytes_per_row(bool calc, bool lpe_separate) {
-  // [T][P] bE slots (8 B) [+ float LPE per slot] + decision bits + per-row path arrays
-  return calc ? (uint64_t)dynk::P * (lpe_separate ? 12 : 8) + dynk::CPL * 8 + 8 + 4 : (uint64_t)dynk::P * 8;
-}
 
 }  // namespace
 
@@ -212,9 +208,10 @@ namespace dyneng {
 void attach_cache(dyn_batch* b) {
   dyneng::BufCache* c = &b->a->cache;
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
-                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
+                    &b->d_pathn})
     d->cache = c;
-  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows}) h->cache = c;
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats}) h->cache = c;
 }
 
 int need_device(dyn_aligner* a) {
@@ -373,6 +370,8 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   }
   a->device = device;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipDeviceGetAttribute(&a->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail(e, "hipDeviceGetAttribute");
+  if (const char* f = std::getenv("DYN_QUEUE_CUS")) a->n_cus = std::max(1, std::atoi(f));  // experiments: fewer persistent workgroups
   if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -402,8 +401,8 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->ws.release();
     a->lpe.release();
     a->bits.release();
-    a->pp.release();
-    a->pathn.release();
+    a->free_list.release();
+    a->ctl.release();
     a->h_rows.release();
     a->cache.purge();
     for (hipStream_t s : {a->stream, a->s_in, a->s_out})
@@ -647,9 +646,10 @@ void dyn_batch_destroy(dyn_batch* b) {
   if (b->async && !b->done && b->a && b->a->pipe) (void)b->a->pipe->wait(b);
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
-                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled})
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
+                    &b->d_pathn})
     d->release();
-  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows}) h->release();
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats}) h->release();
   for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : {b->ev_in, b->ev_done, b->ev_out})
     if (e) (void)hipEventDestroy(e);
@@ -660,9 +660,13 @@ void dyn_batch_destroy(dyn_batch* b) {
 
 namespace dyneng {
 
-// Shared engine of align / train: LPT order, HBM planning, chunked launches -- all ENQUEUED on the
-// handle's compute stream, no host synchronisation. Host-side inputs of the launches (read
-// descriptors, initial per-read state) live in pinned per-batch buffers until the batch is destroyed.
+// Shared engine of align / train. Every ok read of the batch goes, longest first, into ONE launch of
+// persistent waves (k_read_queue): a wave runs a read's whole pipeline and then takes the next read
+// off the queue. The lattice of a read lives in pages of a pool that only has to hold the reads in
+// flight (at most 4 per CU); the pages of the first round are reserved here, later reads take theirs
+// from the pool's free list on the device. Everything is ENQUEUED on the handle's compute stream
+// without a host synchronisation; host-side inputs of the launches (read descriptors, initial
+// per-read state) live in pinned per-batch buffers until the batch is destroyed.
 int enqueue_job(dyn_batch* b, DynJob job) {
   dyn_aligner* a = b->a;
   const bool lattice = job != DynJob::AlignZ;
@@ -670,7 +674,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   const PoreModel& m = a->model;
   const int z_fail = job == DynJob::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
 
-  // longest reads first (they bound the tail of each launch)
+  // longest reads first: the tail of the launch is then made of the shortest reads
   std::vector<uint32_t> order;
   for (uint64_t i = 0; i < b->n; ++i)
     if (b->reads[i].status == DYN_READ_OK) order.push_back((uint32_t)i);
@@ -690,25 +694,41 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->stream));
   }
 
-  // HBM budget for lattice workspaces
+  // HBM budget for the page pool
   uint64_t budget = a->mem_budget;
   if (lattice) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + a->pp.bytes + a->pathn.bytes;
+    const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes;
     const uint64_t avail = (uint64_t)((double)(free_b + pool) * 0.90);
     if (budget == 0 || budget > avail) budget = avail;
   }
-  // Posterior layout (nt_kernels.hip, k_forward): the separate float LPE array makes k_forward 17 %
-  // faster but costs 12 instead of 8 bytes of HBM per band slot. When the batch does not fit one
-  // launch that way, more reads per launch are worth more than the faster kernel: in place then.
+
+  // rows per page: the longest read must fit the waves' PT_MAX-entry page tables
+  uint32_t max_T = 0;
+  for (uint32_t i : order) max_T = std::max<uint32_t>(max_T, (uint32_t)(b->reads[i].S + 1));
+  int log_r = 8;
+  while (((uint64_t)max_T + 1 + ((1ull << log_r) - 1)) >> log_r > (uint64_t)dynk::PT_MAX) ++log_r;
+  const uint64_t page_rows = 1ull << log_r;
+  auto pages_of = [&](uint64_t S) { return (uint32_t)((S + 2 + page_rows - 1) >> log_r); };  // rows 0 .. T = S+1
+  const size_t n_slots = std::min<size_t>(order.size(), (size_t)a->n_cus * 4);
+  uint64_t wanted = 0;  // pages that keep every wave slot busy: the n_slots longest reads at once
+  for (size_t k = 0; k < n_slots; ++k) wanted += pages_of(b->reads[order[k]].S);
+
+  // Posterior layout (nt_kernels.hip, forward_sweep): the separate float LPE array makes the forward sweep
+  // 17 % faster but costs 12 instead of 8 bytes of HBM per band slot. When the pool cannot hold a
+  // separate-layout lattice for every wave slot, waves wait for pages; in place then, if the wider
+  // concurrency is worth more than the faster sweep.
+  const uint64_t row_sep = (uint64_t)dynk::P * 12 + dynk::CPL * 8, row_inp = (uint64_t)dynk::P * 8 + dynk::CPL * 8;
   bool lpe_separate = calc;
   if (calc) {
-    uint64_t need_sep = 0;
-    for (uint32_t i : order) need_sep += (b->reads[i].S + 2) * lattice_bytes_per_row(true, true);
-    if (need_sep > budget) lpe_separate = false;
+    const double c_sep = std::min(1.0, (double)budget / ((double)wanted * page_rows * row_sep + 1.0));
+    const double c_inp = std::min(1.0, (double)budget / ((double)wanted * page_rows * row_inp + 1.0));
+    if (c_sep < 1.0 && c_inp * 0.92 > c_sep) lpe_separate = false;
+    if (const char* f = std::getenv("DYN_FORCE_LAYOUT")) lpe_separate = std::string(f) != "inplace";
   }
-  const uint64_t row_bytes = lattice_bytes_per_row(calc, lpe_separate);
+  const uint64_t row_bytes = calc ? (lpe_separate ? row_sep : row_inp) : (uint64_t)dynk::P * 8;
+  const uint64_t page_bytes = page_rows * row_bytes;
 
   // per-read state (status of host-side failures is final; ok reads start at 0). A read whose lattice
   // alone exceeds the budget fails on its own (the reference would die of std::bad_alloc for that read
@@ -721,148 +741,177 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     st[i].n_segments = 0;
   }
   if (lattice) {
-    size_t w = 0;
+    size_t wr = 0;
     for (uint32_t i : order) {
-      if ((b->reads[i].S + 2) * row_bytes > budget) st[i].status = DYN_READ_TOO_LARGE;
-      else order[w++] = i;
+      if ((uint64_t)pages_of(b->reads[i].S) * page_bytes > budget) st[i].status = DYN_READ_TOO_LARGE;
+      else order[wr++] = i;
     }
-    order.resize(w);
+    if (wr != order.size()) {
+      order.resize(wr);
+      wanted = 0;
+      for (size_t k = 0; k < std::min(n_slots, order.size()); ++k) wanted += pages_of(b->reads[order[k]].S);
+    }
   }
   if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st, b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
 
-  // greedy chunks in LPT order; a chunk holds at most 65 535 reads (gridDim.y of the per-read kernels)
-  struct Chunk { size_t begin, end; uint64_t ws_rows, rows_total; uint32_t max_T, max_N; };
-  std::vector<Chunk> chunks;
+  // the pool: grow-only, shared by every batch of the handle (stream order serialises them)
+  dynk::PagePool pool{};
+  pool.log_rows = log_r;
+  if (lattice && !order.empty()) {
+    const uint64_t cap_pages = budget / page_bytes;
+    const uint64_t target = std::min<uint64_t>(wanted, cap_pages);
+    const uint64_t ws_pp = page_rows * dynk::P * 8, lpe_pp = page_rows * dynk::P * 4, bits_pp = page_rows * dynk::CPL * 8;
+    const bool grow = a->ws.bytes < target * ws_pp || (calc && lpe_separate && a->lpe.bytes < target * lpe_pp) ||
+                      (calc && a->bits.bytes < target * bits_pp);
+    if (grow) {  // growing releases the old buffer, which earlier work on the compute stream may still be using
+      HIP_TRY(a, hipStreamSynchronize(a->stream));
+      const double headroom = std::min(1.15, std::max(1.0, (double)cap_pages / (double)std::max<uint64_t>(1, target)));
+      HIP_TRY(a, a->ws.ensure(target * ws_pp, headroom));
+      if (calc && lpe_separate) HIP_TRY(a, a->lpe.ensure(target * lpe_pp, headroom));
+      if (calc) HIP_TRY(a, a->bits.ensure(target * bits_pp, headroom));
+    }
+    uint64_t n_pages = a->ws.bytes / ws_pp;
+    if (calc && lpe_separate) n_pages = std::min<uint64_t>(n_pages, a->lpe.bytes / lpe_pp);
+    if (calc) n_pages = std::min<uint64_t>(n_pages, a->bits.bytes / bits_pp);
+    n_pages = std::min<uint64_t>(n_pages, 0xfffffff0ull >> log_r);  // pool rows are 32-bit
+    if (a->free_list.bytes < n_pages * 4) {
+      HIP_TRY(a, hipStreamSynchronize(a->stream));
+      HIP_TRY(a, a->free_list.ensure(n_pages * 4, 1.0));
+    }
+    pool.ws = a->ws.as<double>();
+    pool.lpe = (calc && lpe_separate) ? a->lpe.as<float>() : nullptr;
+    pool.bits = calc ? a->bits.as<uint64_t>() : nullptr;
+    pool.free_list = a->free_list.as<uint32_t>();
+    pool.n_pages = (uint32_t)n_pages;
+  }
+  HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));
+  pool.ctl = a->ctl.as<uint32_t>();
+
+  // read descriptors in processing order; pages of the first round reserved here
   HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), order.size() * sizeof(ReadDesc))));
   ReadDesc* descs = b->h_descs.as<ReadDesc>();
   dyn_timing tm{};
-  {
-    Chunk cur{0, 0, 0, 0, 0, 0};
-    uint64_t used = 0;
-    for (size_t k = 0; k < order.size(); ++k) {
-      const uint32_t i = order[k];
-      const HostRead& r = b->reads[i];
-      const uint64_t need = lattice ? (r.S + 2) * row_bytes : 0;  // T rows + the -inf row T
-      if (cur.end > cur.begin && (used + need > budget || cur.end - cur.begin >= 65535)) {
-        chunks.push_back(cur);
-        cur = Chunk{k, k, 0, 0, 0, 0};
-        used = 0;
-      }
-      ReadDesc d{};
-      d.T = (uint32_t)(r.S + 1);
-      d.N = (uint32_t)(r.kc + 1);
-      d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
-      d.read = i;
-      d.ratio = (double)d.N / (double)d.T;
-      d.sig_off = r.sig_off;
-      d.par_off = r.flat_off;
-      d.seg_off = r.seg_off;
-      d.ws_off = cur.ws_rows * dynk::P;
-      d.bits_off = cur.rows_total * dynk::CPL;
-      d.path_off = cur.rows_total;
-      cur.rows_total += d.T;
-      cur.ws_rows += d.T + 1;
-      cur.max_T = std::max(cur.max_T, d.T);
-      cur.max_N = std::max(cur.max_N, d.N);
-      descs[k] = d;
-      cur.end = k + 1;
-      used += need;
-      tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
-      tm.samples += r.S;
+  uint64_t rows_total = 0;
+  uint32_t used_pages = 0, n_static = 0, max_N = 0;
+  bool reserving = true;
+  for (size_t k = 0; k < order.size(); ++k) {
+    const uint32_t i = order[k];
+    const HostRead& r = b->reads[i];
+    ReadDesc d{};
+    d.T = (uint32_t)(r.S + 1);
+    d.N = (uint32_t)(r.kc + 1);
+    d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
+    d.read = i;
+    d.ratio = (double)d.N / (double)d.T;
+    d.sig_off = r.sig_off;
+    d.par_off = r.flat_off;
+    d.seg_off = r.seg_off;
+    d.path_off = rows_total;
+    d.n_pages = lattice ? pages_of(r.S) : 0;
+    d.first_page = dynk::NO_PAGE;
+    if (reserving && k < n_slots && (!lattice || (uint64_t)used_pages + d.n_pages <= pool.n_pages)) {
+      d.first_page = lattice ? used_pages : 0;
+      used_pages += d.n_pages;
+      n_static = (uint32_t)(k + 1);
+    } else {
+      reserving = false;  // the queue is FIFO: later reads wait for pages on the device
     }
-    if (cur.end > cur.begin) chunks.push_back(cur);
+    rows_total += d.T;
+    max_N = std::max(max_N, d.N);
+    descs[k] = d;
+    tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
+    tm.samples += r.S;
   }
-  // the pools must hold the largest chunk before anything of this batch is launched: growing one
-  // releases the old buffer, which earlier work on the compute stream may still be using
-  {
-    uint64_t ws_rows = 0, rows_total = 0;
-    for (const Chunk& c : chunks) {
-      ws_rows = std::max(ws_rows, c.ws_rows);
-      rows_total = std::max(rows_total, c.rows_total);
-    }
-    const uint64_t used_max = ws_rows * row_bytes;
-    const double headroom = used_max ? std::min(1.25, std::max(1.0, (double)budget / (double)used_max)) : 1.0;
-    const bool grow = (lattice && a->ws.bytes < ws_rows * dynk::P * 8) ||
-                      (calc && ((lpe_separate && a->lpe.bytes < ws_rows * dynk::P * 4) || a->bits.bytes < rows_total * dynk::CPL * 8 ||
-                                a->pp.bytes < rows_total * 8 || a->pathn.bytes < rows_total * 4));
-    if (grow) HIP_TRY(a, hipStreamSynchronize(a->stream));
-    if (lattice) HIP_TRY(a, a->ws.ensure(ws_rows * dynk::P * 8, headroom));
-    if (calc) {
-      if (lpe_separate) HIP_TRY(a, a->lpe.ensure(ws_rows * dynk::P * 4, headroom));
-      HIP_TRY(a, a->bits.ensure(rows_total * dynk::CPL * 8, headroom));
-      HIP_TRY(a, a->pp.ensure(rows_total * 8, headroom));
-      HIP_TRY(a, a->pathn.ensure(rows_total * 4, headroom));
-    }
+  if (calc) {
+    HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
+    HIP_TRY(a, b->d_pathn.ensure(std::max<uint64_t>(4, rows_total * 4)));
   }
   HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), order.size() * sizeof(ReadDesc))));
   if (!order.empty())
     HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, order.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(a, b->h_stats.ensure(dynk::QUEUE_CTL_WORDS * 4));
+  std::memset(b->h_stats.p, 0, dynk::QUEUE_CTL_WORDS * 4);
 
-  while (b->events.size() < 4 * chunks.size()) {
+  while (b->events.size() < 3) {
     hipEvent_t e = nullptr;
     HIP_TRY(a, hipEventCreate(&e));
     b->events.push_back(e);  // owned by the batch from here on: destroyed with it whatever happens next
   }
-  b->n_chunks = (uint32_t)chunks.size();
-
-  const dynmath::SoftplusNode* sp = a->d_sptab.as<dynmath::SoftplusNode>();
-  for (size_t c = 0; c < chunks.size(); ++c) {
-    const Chunk& ch = chunks[c];
-    hipEvent_t* ev = &b->events[4 * c];
-    const int nr = (int)(ch.end - ch.begin);
-    const ReadDesc* dd = b->d_descs.as<ReadDesc>() + ch.begin;
-    const double* sig = b->d_sig.as<double>();
-    const Emis* par = b->d_par.as<Emis>();
-    ReadState* dst = b->d_state.as<ReadState>();
-    HIP_TRY(a, hipEventRecord(ev[0], a->stream));
-    dynk::launch_backward(dd, nr, sig, par, a->ws.as<double>(), dst, m.log_m1, m.log_e2, lattice, sp, a->stream);
-    HIP_TRY(a, hipEventRecord(ev[1], a->stream));
-    if (job == DynJob::Train) {
-      dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-      dynk::launch_forward_train(dd, nr, sig, par, a->ws.as<double>(), dst, tb, m.log_m1, m.log_e2, sp, a->stream);
-    } else {
-      dynk::launch_forward(dd, nr, sig, par, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), dst, m.log_m1, m.log_e2, calc, sp, a->stream);
-    }
-    HIP_TRY(a, hipEventRecord(ev[2], a->stream));
-    if (calc) {
-      dynk::TraceBuffers tb{a->pp.as<double>(), a->pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
+  hipEvent_t* ev = b->events.data();
+  const int nr = (int)order.size();
+  dynk::QueueArgs q{};
+  q.descs = b->d_descs.as<ReadDesc>();
+  q.n_reads = nr;
+  q.n_static = (int)n_static;
+  q.sig = b->d_sig.as<double>();
+  q.par = b->d_par.as<Emis>();
+  q.pool = pool;
+  q.st = b->d_state.as<ReadState>();
+  q.tb = dynk::TraceBuffers{b->d_pp.as<double>(), b->d_pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(),
                             b->d_medhi.as<double>(), b->d_medlo.as<double>()};
-      dynk::launch_trace(dd, nr, ch.max_T, ch.max_N, a->ws.as<double>(), lpe_separate ? a->lpe.as<float>() : nullptr, a->bits.as<uint64_t>(), sig, par, dst, tb,
-                         b->d_rows.as<SegRow>(), m.k, m.log_m1, z_fail, a->stream);
-    } else {
-      dynk::launch_zcheck(dd, nr, dst, z_fail, a->stream);
-      if (job == DynJob::Train) {
-        dynk::TrainBuffers tb{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-        dynk::launch_pool_stats(dd, nr, ch.max_N, dst, b->d_kmers.as<int32_t>(), tb, b->d_pooled.as<double>(), m.num_kmers, a->stream);
-      }
-    }
-    HIP_TRY(a, hipEventRecord(ev[3], a->stream));
-    HIP_TRY(a, hipGetLastError());
-  }
+  q.tr = dynk::TrainBuffers{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
+  q.m1 = m.log_m1;
+  q.e2 = m.log_e2;
+  q.sp_tab = a->d_sptab.as<dynmath::SoftplusNode>();
+  q.z_fail_status = z_fail;
+  const dynk::QueueJob qjob = job == DynJob::Train ? dynk::JOB_TRAIN
+                              : !calc              ? dynk::JOB_Z
+                              : lpe_separate       ? dynk::JOB_ALIGN
+                                                   : dynk::JOB_ALIGN_INPLACE;
+  dynk::launch_pool_init(pool, used_pages, (int)n_static, a->stream);
+  HIP_TRY(a, hipEventRecord(ev[0], a->stream));
+  dynk::launch_read_queue(qjob, q, a->n_cus, a->stream);
+  HIP_TRY(a, hipEventRecord(ev[1], a->stream));
+  if (calc) dynk::launch_segments(q.descs, nr, max_T, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
+  if (job == DynJob::Train)
+    dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers, a->stream);
+  HIP_TRY(a, hipEventRecord(ev[2], a->stream));
+  HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(a, hipGetLastError());
   tm.reads_ok = order.size();
-  tm.launches_backward = tm.launches_forward = (uint32_t)chunks.size();
+  tm.launches = nr ? 1 : 0;
   tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
+  tm.pool_pages = pool.n_pages;
+  tm.page_rows = (uint32_t)page_rows;
+  tm.n_static = n_static;
+  tm.n_waves = (uint32_t)std::min<size_t>((order.size() + 3) / 4 * 4, (size_t)a->n_cus * 4);
   b->timing = tm;
+  b->n_chunks = nr ? 1 : 0;
   b->aligned = job != DynJob::Train;
   b->trained = job == DynJob::Train;
   b->last_calc = calc ? 1 : 0;
   return DYN_OK;
 }
 
+// After the compute stream has passed the batch (and the statistics copy behind it).
 int collect_timing(dyn_batch* b) {
   dyn_aligner* a = b->a;
   dyn_timing& tm = b->timing;
-  tm.ms_backward = tm.ms_forward = tm.ms_trace = tm.ms_total = 0.0;
-  for (uint32_t c = 0; c < b->n_chunks; ++c) {
-    hipEvent_t* ev = &b->events[4 * c];
-    float ms01 = 0, ms12 = 0, ms23 = 0;
-    HIP_TRY(a, hipEventElapsedTime(&ms01, ev[0], ev[1]));
-    HIP_TRY(a, hipEventElapsedTime(&ms12, ev[1], ev[2]));
-    HIP_TRY(a, hipEventElapsedTime(&ms23, ev[2], ev[3]));
-    tm.ms_backward += ms01;
-    tm.ms_forward += ms12;
-    tm.ms_trace += ms23;
-    tm.ms_total += ms01 + ms12 + ms23;
+  tm.ms_backward = tm.ms_forward = tm.ms_trace = tm.ms_total = tm.ms_dp = 0.0;
+  tm.wave_wait_share = tm.wave_occupancy = 0.0;
+  if (!b->n_chunks) return DYN_OK;
+  hipEvent_t* ev = b->events.data();
+  float ms01 = 0, ms12 = 0;
+  HIP_TRY(a, hipEventElapsedTime(&ms01, ev[0], ev[1]));
+  HIP_TRY(a, hipEventElapsedTime(&ms12, ev[1], ev[2]));
+  // wave-cycles per phase, summed over all waves of the launch: backward, forward, traceback (+ state
+  // write-back and page release), waiting for a read / for pages, lifetime; [5] = longest lifetime
+  if (b->h_stats.as<uint32_t>()[3] != 0) {
+    a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
+    return DYN_ERR_DEVICE;
+  }
+  const uint64_t* s = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::QUEUE_STATS);
+  const double life = (double)s[4];
+  tm.ms_dp = ms01;
+  tm.ms_total = ms01 + ms12;
+  if (life > 0) {
+    tm.ms_backward = ms01 * (double)s[0] / life;
+    tm.ms_forward = ms01 * (double)s[1] / life;
+    tm.ms_trace = ms01 * (double)s[2] / life + ms12;
+    tm.wave_wait_share = (double)s[3] / life;
+    if (s[5] && tm.n_waves) tm.wave_occupancy = life / ((double)s[5] * tm.n_waves);
+  } else {
+    tm.ms_trace = ms12;
   }
   return DYN_OK;
 }

@@ -103,7 +103,9 @@ struct dyn_aligner {
   std::string last_error;
   // grow-only lattice workspace pool, reused across batches (only ever touched by work on `stream`,
   // whose order serialises the batches that share it)
-  dyneng::DevBuf ws, lpe, bits, pp, pathn;
+  dyneng::DevBuf ws, lpe, bits;      // page pool of the read queue (nt_kernels.hpp, PagePool)
+  dyneng::DevBuf free_list, ctl;     // its free-page stack and control words
+  int n_cus = 256;                   // compute units: one persistent 4-wave workgroup each
   dyneng::PinnedBuf h_rows;  // staging of the synchronous dyn_batch_fetch
   dyneng::BufCache cache;
   // serialises GPU enqueue work on this handle between the caller's thread and the pipeline threads
@@ -130,10 +132,12 @@ struct dyn_batch {
   uint32_t max_T = 0, max_N = 0;
   dyneng::DevBuf d_sig, d_kmers, d_par, d_state, d_rows, d_segrow, d_medhi, d_medlo, d_descs;
   dyneng::DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled;
+  dyneng::DevBuf d_pp, d_pathn;                // per-row path arrays (traceback -> k_median / k_final)
   dyneng::PinnedBuf h_descs, h_state, h_rows;  // h_state/h_rows: D2H targets of the asynchronous path
-  std::vector<hipEvent_t> events;              // 4 per launch group (chunk)
+  dyneng::PinnedBuf h_stats;                   // wave-cycle statistics of the read-queue launch
+  std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
-  uint32_t n_chunks = 0;
+  uint32_t n_chunks = 0;                       // launches enqueued by the last job (0 or 1)
   dyn_timing timing{};
   bool aligned = false, trained = false;
   int last_calc = 0;

@@ -11,46 +11,54 @@
 //   runTraining            src/cpp/NT_aligner_api.cpp:462-561
 //   trainTransition        src/cpp/NT_aligner_api.cpp:641-725
 //
-// Design (not a translation): the reference streams eight T x B fp64 matrices per read. Here
-//   K_bwd  walks t = T-2..0 and stores ONLY backward-E (bM(t,n) = bE(t+1,n) + e(t+1,n) is one
-//          add away, NT_aligner_api.cpp:200);
-//   K_fwd  walks t = 1..T-1 and fuses forward, posterior (needs Zb, known after K_bwd),
-//          the posterior-Viterbi fill and the traceback decision
-//          (vE == vM_prev + LPE, NT_aligner_api.cpp:448); forward / Viterbi rows never leave
-//          registers; per cell it writes one float, LPE, for the path-probability lookup and
-//          1 decision bit (footprint-limited batches: (float LPM, float LPE) over the bE slot);
-//   K_trace walks the decision bits back one SEGMENT per step (ballot + find-first-set inside
-//          64-row LDS blocks), K_mpost rebuilds LPM for the segment starts, K_median/K_final
-//          produce the per-segment median posterior.
+// Design (not a translation): the reference streams eight T x B fp64 matrices per read. Here, per read,
+//   backward  walks t = T-2..0 and stores ONLY backward-E (bM(t,n) = bE(t+1,n) + e(t+1,n) is one
+//             add away, NT_aligner_api.cpp:200);
+//   forward   walks t = 1..T-1 and fuses forward, posterior (needs Zb, known after the backward sweep),
+//             the posterior-Viterbi fill and the traceback decision
+//             (vE == vM_prev + LPE, NT_aligner_api.cpp:448); forward / Viterbi rows never leave
+//             registers; per cell it writes one float, LPE, for the path-probability lookup and
+//             1 decision bit (footprint-limited launches: (float LPM, float LPE) over the bE slot);
+//   traceback walks the decision bits back one SEGMENT per step (ballot + find-first-set inside
+//             64-row LDS blocks) and rebuilds LPM for the segment starts;
+//   k_median / k_final produce the per-segment median posterior and the output rows.
 // HBM traffic is 20.1 B per in-band cell instead of the 64.1 B of the three-pass formulation
-// (SURVEY.md §8d), and the per-read footprint is 12 B per slot instead of 64 B per cell.
+// (SURVEY.md §8d).
 //
-// Mapping: one 64-lane wave owns one read, four reads share a 256-thread workgroup (one wave per
-// SIMD). Band slot s = n mod P lives in lane s / CPL, register s % CPL: a lane owns CPL CONSECUTIVE
+// Execution: ONE launch of persistent waves per batch (k_read_queue). One 64-lane wave owns one read at
+// a time and runs its whole pipeline -- backward, forward, Z check, traceback -- then takes the next read
+// off a queue until the batch is drained. Four waves share a 256-thread workgroup (one per SIMD of a CU)
+// and nothing but the CU's LDS. Consequences:
+//   * no SIMD idles behind the longest read of a launch (reads of 10 k .. 100 k samples in one batch);
+//   * the lattice of a read exists only while a wave works on it: it lives in PAGES drawn from a pool
+//     sized for the reads in flight (<= 1 024), so a batch of any size runs as one launch, and
+//   * write-only backward sweeps and read-mostly forward sweeps of different reads overlap in time.
+//
+// Mapping: band slot s = n mod P lives in lane s / CPL, register s % CPL: a lane owns CPL CONSECUTIVE
 // slots, so the cross-lane neighbour (n-1 forward, n+1 backward) of all but one of its cells is its
 // own next register and one DPP wave rotate per exchange serves the remaining cell -- no barrier
 // anywhere in the DP loops. In HBM a row stores slot s at position row_pos(s) = (s % CPL)*64 + s / CPL,
 // i.e. register j of all lanes is one contiguous 512-byte run: every row access is CPL fully
 // coalesced operations (a 56-byte lane stride, the "natural" placement of this slot numbering, cost
-// K_bwd 20 % in partial-line writes). The CU's LDS holds the softplus table shared by the four waves
-// (dp_math.hpp) and, in K_fwd, a 4-row-deep ring per wave that is filled straight from HBM by
-// global_load_lds_dwordx4 (see ring_dma_row).
+// the backward sweep 20 % in partial-line writes). The CU's LDS holds the softplus table shared by the
+// four waves (dp_math.hpp), a 4-row-deep ring per wave that the forward sweep fills straight from HBM
+// with global_load_lds_dwordx4 (see ring_dma_row), and each wave's page table.
 #include "nt_kernels.hpp"
 
 #include <algorithm>
 
 // Placement: the SPI packs single-wave workgroups onto one SIMD for as long as its registers
-// allow (measured: a 184-VGPR build of K_bwd ran 1 024 reads as 2 waves on each of 512 SIMDs and
-// took 2x the time of 512 reads; tools/ubench + DESIGN.md). The DP waves are pure fp64 issue
+// allow (measured: a 184-VGPR build of the backward sweep ran 1 024 reads as 2 waves on each of 512
+// SIMDs and took 2x the time of 512 reads; tools/ubench + DESIGN.md). The DP waves are pure fp64 issue
 // streams with 7-way ILP that saturate a SIMD on their own, so they are compiled for exactly one
-// wave per SIMD: the dispatcher must then spread the reads over all 1 024 SIMDs, and the whole
+// wave per SIMD: the dispatcher must then spread the waves over all 1 024 SIMDs, and the whole
 // 512-entry register file is available to keep the interleaved chains out of AGPR spills.
 #define DYN_ONE_WAVE_PER_SIMD __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
-// The DP kernels run FOUR reads per 256-thread workgroup (one wave each, one per SIMD of a CU):
-// the four waves never synchronise after the prologue, they only share the 82 KB softplus table
-// that the workgroup stages into the CU's LDS once (dp_math.hpp, softplus_table_vec).
-#define DYN_READS_PER_GROUP 4
+// FOUR waves per 256-thread workgroup (one per SIMD of a CU): they never synchronise after the
+// prologue, they only share the 82 KB softplus table that the workgroup stages into the CU's LDS once
+// (dp_math.hpp, softplus_table_vec).
+#define DYN_WAVES_PER_GROUP 4
 
 namespace dynk {
 
@@ -64,6 +72,9 @@ using dynmath::log_plus_finish;
 using dynmath::SP_NODES;
 
 namespace {
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 
 __device__ __forceinline__ int pmod(int a) {
   int r = a % P;
@@ -135,14 +146,50 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   return e;
 }
 
-// ---- LDS-DMA row ring (k_forward) -------------------------------------------------------------
-// K_fwd must read one [448]-double bE row per lattice row while it overwrites an older row. With
-// the rows prefetched into VGPRs the single wave of a SIMD stalled on s_waitcnt for 43 % of its
+// ---- paged lattice rows --------------------------------------------------------------------------
+// Lattice row t of the wave's current read is row (pt[t >> log_r] << log_r) + (t mod 2^log_r) of the
+// pool arrays. The sweeps keep the page base in a scalar register and look the table (LDS) up only
+// when a row crosses into another page.
+struct WaveCtx {
+  int lane;
+  lds_u32_t* pt;  // this wave's page table
+  int log_r;
+};
+
+struct RowCursor {
+  int page = -1;
+  uint32_t base = 0;
+  // t is wave-uniform
+  __device__ __forceinline__ uint32_t at(const WaveCtx& w, int t) {
+    const int pg = t >> w.log_r;
+    if (pg != page) {
+      page = pg;
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.pt[pg]) << w.log_r;
+    }
+    return base + ((uint32_t)t & ((1u << w.log_r) - 1u));
+  }
+};
+
+// per-lane row (traceback, segment-start posteriors)
+__device__ __forceinline__ uint32_t pool_row(const WaveCtx& w, int t) {
+  return (w.pt[t >> w.log_r] << w.log_r) + ((uint32_t)t & ((1u << w.log_r) - 1u));
+}
+
+// LDS written by some lanes of this wave, read by others: the wave's LDS operations execute in order,
+// the fence keeps the compiler from moving them and waits for the writes.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- LDS-DMA row ring (forward sweep) ---------------------------------------------------------------
+// The forward sweep must read one [448]-double bE row per lattice row while it overwrites an older row.
+// With the rows prefetched into VGPRs the single wave of a SIMD stalled on s_waitcnt for 43 % of its
 // life (compiler-placed vmcnt(0) behind the previous row's stores, prefetch registers spilled to
 // AGPRs mid-row). The rows now go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, 3 full +
 // 1 half-wave instruction per 3584-byte row), RING_D rows ahead, and are picked up with ds_read_b64
 // behind a hand-counted s_waitcnt. Validated in isolation by tools/ubench/lds_dma_test.hip.
-constexpr int RING_D = 4;  // 2..5 rows deep measure the same: the kernel is bandwidth-, not latency-bound
+constexpr int RING_D = 4;  // 2..5 rows deep measure the same: the sweep is bandwidth-, not latency-bound
 constexpr int ROW_BYTES = P * 8;
 // vmcnt(N) lets the N youngest vector-memory operations stay in flight. Only the DMA instructions
 // themselves are counted (4 per row, RING_D-1 younger rows => 12): loads retire in issue order, so
@@ -151,7 +198,7 @@ constexpr int ROW_BYTES = P * 8;
 constexpr int RING_WAIT = 4 * (RING_D - 1);
 
 // row_lane_ptr = &row[lane*2]; `offset:` advances both the global and the LDS address.
-// Each row is consumed exactly once: the DMA carries the non-temporal hint (-1 % on the kernel).
+// Each row is consumed exactly once: the DMA carries the non-temporal hint (-1 % on the sweep).
 #define DYN_DMA_MOD " nt"
 __device__ __forceinline__ void ring_dma_row(const double* row_lane_ptr, unsigned lds_slot_addr) {
   asm volatile(
@@ -189,59 +236,28 @@ __device__ __forceinline__ void ring_read_row(unsigned lds_lane_addr, double (&b
       : "memory");
 }
 
-// Stage the softplus table into LDS (all 256 threads), then tell the caller which read this
-// wave owns (-1: none; the wave must still have taken part in the barrier).
-__device__ __forceinline__ int stage_table_and_pick_read(SoftplusNode* s_tab, const SoftplusNode* __restrict__ tab,
-                                                         int n_reads) {
-  for (int i = threadIdx.x; i < SP_NODES; i += 256) s_tab[i] = tab[i];
-  __syncthreads();
-  // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
-  // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /
-  // parameter access becomes a vector load.
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int r = blockIdx.x * DYN_READS_PER_GROUP + wave;
-  return r < n_reads ? r : -1;
-}
-
-}  // namespace
-
 // ---------------------------------------------------------------------------------------------
-// per-column emission table: par[i] = model[kmers[i]]  (aligner.cpp:241-245 scoreKmer lookup)
-// ---------------------------------------------------------------------------------------------
-__global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __restrict__ model,
-                              Emis* __restrict__ par, uint64_t total) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) par[i] = model[kmers[i]];
-}
-
-// ---------------------------------------------------------------------------------------------
-// K_bwd: backward recursion, t = T-2 .. 0 (NT_aligner_api.cpp:158-207)
+// backward recursion, t = T-2 .. 0 (NT_aligner_api.cpp:158-207)
 //   e(t+1,n)  = logN(sig[t]; kmers[n-1])                      emission of lattice cell (t+1,n)
 //   bM(t,n)   = bE(t+1,n) + e(t+1,n)                          (n > 0)            :197-200
 //   bE(t,n)   = logPlus( (bM(t+1,n+1) + e(t+1,n+1)) + m1 ,    (n+1 < N)          :192-195
 //                        (bE(t+1,n)   + e(t+1,n))   + e2 )    (n > 0)            :201
 // Columns without a k-mer (n <= 0, n >= N) carry emission -inf, which realises the n > 0 and
 // n+1 < N guards arithmetically; the upper band edge is handled in the window-move block.
+// Returns Zb = bE(0,0) (-inf when the signal holds a non-finite sample).
 // ---------------------------------------------------------------------------------------------
 template <bool STORE>
-__global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ descs,
-                                                  const double* __restrict__ sig,
-                                                  const Emis* __restrict__ par,
-                                                  double* __restrict__ ws,
-                                                  ReadState* __restrict__ st, double m1,
-                                                  double e2, const SoftplusNode* __restrict__ sp_tab,
-                                                  int n_reads) {
-  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
-  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
-  if (ridx < 0) return;
-  const ReadDesc rd = descs[ridx];
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveCtx& w,
+                                                 const double* __restrict__ sig,
+                                                 const Emis* __restrict__ par, double* __restrict__ ws,
+                                                 double m1, double e2, const SoftplusNode* s_tab) {
+  const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ out = ws + rd.ws_off + lane;
+  double* __restrict__ out = ws + lane;
+  RowCursor cur;
 
   bool bad_sample = false;
   int lo = band_mid(T - 1, ratio) - bw;
@@ -249,18 +265,21 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   int n[CPL];
   double bE[CPL], bM[CPL], e[CPL];
   EmisV<CPL> p;
+  {
+    // one row past the lattice, all -inf: bM(T-1, .) = bE(T, .) + e has no successor. It lets the
+    // forward sweep stream row t+1 for every t without a last-row special case in its row loop.
+    const size_t rT = STORE ? (size_t)cur.at(w, T) * P : 0, rT1 = STORE ? (size_t)cur.at(w, T - 1) * P : 0;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int slot = lane * CPL + j;
-    n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
-    bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
-    bM[j] = NEG_INF;
-    if (STORE) {
-      out[(size_t)(T - 1) * P + j * 64] = bE[j];
-      // one row past the lattice, all -inf: bM(T-1, .) = bE(T, .) + e has no successor. It lets
-      // k_forward stream row t+1 for every t without a last-row special case in its row loop.
-      out[(size_t)T * P + j * 64] = NEG_INF;
+    for (int j = 0; j < CPL; ++j) {
+      const int slot = lane * CPL + j;
+      n[j] = lo + pmod(slot - lo);
+      p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
+      bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
+      bM[j] = NEG_INF;
+      if (STORE) {
+        out[rT1 + j * 64] = bE[j];
+        out[rT + j * 64] = NEG_INF;
+      }
     }
   }
 
@@ -322,12 +341,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
         log_normal_pdf_vec<CPL>(xnext, p, e);
       }
       log_plus_finish<CPL>(L, ne);
+      const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         bE[j] = ne[j];
         bM[j] = A[j];
-        // streamed once, read back by k_forward ~70 GB later: non-temporal (-2 % on the kernel)
-        if (STORE) __builtin_nontemporal_store(ne[j], &out[(size_t)t * P + j * 64]);
+        // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
+        if (STORE) __builtin_nontemporal_store(ne[j], &out[rt + j * 64]);
       }
     }
   }
@@ -338,11 +358,11 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
   // reference's behaviour is undefined, fail the same way).
   const bool any_bad = __any(bad_sample);
   // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
-  if (lane == 0) st[rd.read].Zb = any_bad ? NEG_INF : bE[0];
+  return any_bad ? NEG_INF : readlane_f64(bE[0], 0);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_fwd: forward (NT_aligner_api.cpp:110-152) fused with posterior (:213-224,297-300) and the
+// forward (NT_aligner_api.cpp:110-152) fused with posterior (:213-224,297-300) and the
 // posterior-Viterbi fill (:338-363), t = 1 .. T-1:
 //   e(t,n)   = logN(sig[t-1]; kmers[n-1])
 //   fM(t,n)  = (fE(t-1,n-1) + e) + m1                                             :146
@@ -353,42 +373,34 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_backward(const ReadDesc* __restrict__ de
 // Masks: none per row. Emission -inf for k-mer-less columns covers n < 1 and n >= N, and a slot
 // carries its column's k-mer parameters only while the column is inside the band (hand-over in the
 // window-move block that looks one row ahead), so e = -inf empties every out-of-band slot.
+// Returns Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285).
 // ---------------------------------------------------------------------------------------------
 // INPLACE (only with POST): see the comment at lat_lp below
 template <bool POST, bool INPLACE>
-__global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ descs,
-                                                 const double* __restrict__ sig,
-                                                 const Emis* __restrict__ par,
-                                                 const double* __restrict__ ws_rd,
-                                                 float* __restrict__ lp_out,
-                                                 uint64_t* __restrict__ bits,
-                                                 ReadState* __restrict__ st, double m1,
-                                                 double e2, const SoftplusNode* __restrict__ sp_tab,
-                                                 int n_reads) {
-  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
-  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
-  if (ridx < 0) return;
-  const ReadDesc rd = descs[ridx];
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCtx& w,
+                                                const double* __restrict__ sig, const Emis* __restrict__ par,
+                                                const double* __restrict__ ws_rd, float* __restrict__ lp_out,
+                                                uint64_t* __restrict__ bits, double Z, double m1, double e2,
+                                                const SoftplusNode* s_tab, unsigned ring_base) {
+  const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  // Two layouts for the log-posteriors k_trace needs (one cell per row):
+  // Two layouts for the log-posteriors the traceback needs (one cell per row):
   //  * separate (default): the bE rows stay intact and ONE float per slot, LPE, goes to its own array
   //    (same [row][row_pos] indexing); the ~10 % M cells of the path (segment starts) get LPM rebuilt
-  //    from LPE of the diagonal predecessor and two bE cells (k_mpost). 12 B per slot per row here.
+  //    from LPE of the diagonal predecessor and two bE cells (mpost). 12 B per slot per row here.
   //  * INPLACE: (float LPM, float LPE) overwrite the bE slot of row t while rows t+1.. are still
   //    being read (lp_out then aliases ws_rd; no address is read after it has been written within one
-  //    launch). 16 B per slot per row make this kernel HBM-bound, but the footprint is 8 instead of
-  //    12 B per slot: the host picks it when the separate layout would not fit the batch in one launch.
+  //    sweep). 16 B per slot per row make this sweep HBM-bound, but the footprint is 8 instead of
+  //    12 B per slot: the host picks it when the separate layout would starve the waves of pages.
   // ws_rd and lp_out are separate __restrict__ parameters on purpose: with a pointer derived from
   // the load pointer hipcc orders every prefetch behind the previous row's stores (s_waitcnt vmcnt(0)
   // at the top of each row = 43 % of the wave's lifetime spent waiting).
-  const double* __restrict__ lat = ws_rd + rd.ws_off + lane;
-  float* __restrict__ lat_lp = lp_out + (INPLACE ? 2 : 1) * (rd.ws_off + lane);
-  uint64_t* __restrict__ bt = bits + rd.bits_off;
-  const double Z = POST ? st[rd.read].Zb : 0.0;
+  const double* __restrict__ lat = ws_rd + lane;
+  float* __restrict__ lat_lp = lp_out + (INPLACE ? 2 : 1) * lane;
+  RowCursor cur_dma, cur_out;
 
   // Band edges without per-row masks. Lower edge: the slot of a column that leaves the band is
   // handed to column lo+P. Upper edge: a slot carries the k-mer parameters of its column only from
@@ -401,6 +413,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
   double vM[CPL], vE[CPL], bcur[CPL], bnext[CPL];
   EmisV<CPL> p;
   const double x0 = sg[0];
+  const size_t r1 = POST ? (size_t)cur_out.at(w, 1) * P : 0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
@@ -411,23 +424,26 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
     if (POST) {
       vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
       vM[j] = NEG_INF;
-      bcur[j] = lat[(size_t)1 * P + j * 64];
+      bcur[j] = lat[r1 + j * 64];
       bnext[j] = NEG_INF;
     }
   }
   log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
-  __shared__ __attribute__((aligned(16))) double s_ring[DYN_READS_PER_GROUP][RING_D][P];
-  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][0];
   const unsigned ring_lane = ring_base + lane * 8;
-  const double* __restrict__ dma_src = ws_rd + rd.ws_off + lane * 2;
-  if (POST) {  // rows past T repeat the all -inf row T (k_backward): RING_D rows are always in flight
-    for (int r = 2; r <= RING_D + 1; ++r) ring_dma_row(dma_src + (size_t)min(r, T) * P, ring_base + (r % RING_D) * ROW_BYTES);
+  const double* __restrict__ dma_src = ws_rd + lane * 2;
+  if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
+    for (int r = 2; r <= RING_D + 1; ++r)
+      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
   }
 
   for (int tb = 1; tb < T; tb += 64) {
     const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
     const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    // The block's samples must have ARRIVED before the row loop starts: hipcc otherwise places the
+    // s_waitcnt vmcnt(0) for this load in front of its first use INSIDE the loop, where it drains the
+    // DMA ring in every row (+7 % on the sweep). A use here pins the wait to once per 64 rows.
+    asm volatile("" ::"v"(xs));
     const int iend = min(64, T - tb);
 #pragma unroll 1
     for (int i = 0; i < iend; ++i) {
@@ -440,13 +456,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
         // one hand-counted s_waitcnt serves the whole loop, tail included)
         wait_vmcnt<RING_WAIT>();
         ring_read_row(ring_lane + ((t + 1) % RING_D) * ROW_BYTES, bnext);
-        ring_dma_row(dma_src + (size_t)min(t + 1 + RING_D, T) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
+        ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
       }
       from_left(fE, fEl);
       if (POST) from_left(vE, vEl);
       const int next_lo = band_mid(t + 1, ratio) - bw;
       if (next_lo != lo) {  // wave-uniform: the window moves up by one column between rows t and t+1
-        // uniform addresses -> scalar loads (see k_backward)
+        // uniform addresses -> scalar loads (see backward_sweep)
         const Emis none = load_emis(pr, 0, 0);
         const Emis entering = load_emis(pr, lo + W, N);
 #pragma unroll
@@ -504,19 +520,21 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
               "s"((unsigned)bj[6]), "s"((unsigned)(bj[6] >> 32)));
 #undef DYN_WL
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
+        const uint32_t prow = cur_out.at(w, t);
+        const size_t rt = (size_t)prow * P;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {  // read again only by k_trace, one cell per row: non-temporal
+        for (int j = 0; j < CPL; ++j) {  // read again only by the traceback, one cell per row: non-temporal
           if (INPLACE) {
             typedef float dyn_f2 __attribute__((ext_vector_type(2)));
             dyn_f2 v2;
             v2.x = (float)LPM[j];
             v2.y = (float)LPE[j];
-            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * ((size_t)t * P + j * 64)]));
+            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * (rt + j * 64)]));
           } else {
-            __builtin_nontemporal_store((float)LPE[j], &lat_lp[(size_t)t * P + j * 64]);
+            __builtin_nontemporal_store((float)LPE[j], &lat_lp[rt + j * 64]);
           }
         }
-        if (lane < CPL) bt[(size_t)t * CPL + lane] = mybits;
+        if (lane < CPL) bits[(size_t)prow * CPL + lane] = mybits;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           vM[j] = vMn[j];
@@ -533,62 +551,38 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward(const ReadDesc* __restrict__ des
     }
   }
   if (POST) wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
-  // Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285)
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);
+  double zf = 0.0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j)
-    if (j == sf % CPL && lane == sf / CPL) st[rd.read].Zf = fE[j];
+    if (j == sf % CPL) zf = fE[j];
+  return readlane_f64(zf, sf / CPL);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Z check of align()/train() (NT_aligner_api.cpp:285-291 / 619-625) for the calc=false path.
+// Z check of align()/train() (NT_aligner_api.cpp:285-291 / 619-625).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool z_ok(const ReadDesc& rd, const ReadState& s) {
+__device__ __forceinline__ bool z_ok(const ReadDesc& rd, double Zf, double Zb) {
   const double size = (double)((uint64_t)rd.T * (uint64_t)(2 * rd.bw + 3));
-  if (isinf(s.Zf) || isinf(s.Zb)) return false;
-  return !(fabs(s.Zf - s.Zb) / size > 1e-8);
-}
-
-__global__ void k_zcheck(const ReadDesc* __restrict__ descs, int n_reads,
-                         ReadState* __restrict__ st, int fail_status) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_reads) return;
-  const ReadDesc rd = descs[i];
-  ReadState s = st[rd.read];
-  if (s.status != 0) return;
-  if (!z_ok(rd, s)) st[rd.read].status = fail_status;
-  st[rd.read].n_segments = 0;
+  if (isinf(Zf) || isinf(Zb)) return false;
+  return !(fabs(Zf - Zb) / size > 1e-8);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_trace: decodeMAP (NT_aligner_api.cpp:383-456). Start in state E at (T-1, N-1); walk the
+// traceback: decodeMAP (NT_aligner_api.cpp:383-456). Start in state E at (T-1, N-1); walk the
 // decision bits. Each lattice row 1..T-1 holds exactly one path cell, so the walk is recorded
 // as pathn[row] (column, bit31 = state M) and pp[row] = exp(LP of that cell); a segment is the
 // run of rows that share a column, its M cell is the lowest row (segrow).
 // 64 rows of bits are staged in LDS per step so the serial walk pays LDS, not HBM, latency.
+// Returns true when the walk ended in (0, 0).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_trace(const ReadDesc* __restrict__ descs,
-                                               const float* __restrict__ lpe,
-                                               const uint64_t* __restrict__ bits,
-                                               ReadState* __restrict__ st, TraceBuffers tb,
-                                               int fail_status, int inplace) {
-  __shared__ uint64_t sb[64 * CPL];
-  const ReadDesc rd = descs[blockIdx.x];
-  const int lane = threadIdx.x;
-  ReadState s = st[rd.read];
-  if (s.status != 0) return;
-  if (!z_ok(rd, s)) {
-    if (lane == 0) {
-      st[rd.read].status = fail_status;
-      st[rd.read].n_segments = 0;
-    }
-    return;
-  }
+__device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, const float* __restrict__ lp,
+                                          const uint64_t* __restrict__ bits, TraceBuffers tb, bool inplace,
+                                          lds_u64_t* sb) {
+  const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N;
-  // separate layout: float LPE rows [T][P]; in-place layout: (float LPM, float LPE) in the 8-byte bE slots
-  const float* __restrict__ lp = lpe + (inplace ? 2 : 1) * rd.ws_off;
-  const uint64_t* __restrict__ bt = bits + rd.bits_off;
+  // separate layout: float LPE rows [.][P]; in-place layout: (float LPM, float LPE) in the 8-byte bE slots
   double* __restrict__ pp = tb.pp + rd.path_off;
   uint32_t* __restrict__ pathn = tb.pathn + rd.path_off;
   uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
@@ -604,11 +598,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   while (t > 0 && n > 0) {
     const int base = t - 63;
     const int row = base + lane;
+    uint32_t prow = 0;
     if (row >= 1) {
+      prow = pool_row(w, row);
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) sb[lane * CPL + j] = bt[(size_t)row * CPL + j];
+      for (int j = 0; j < CPL; ++j) sb[lane * CPL + j] = bits[(size_t)prow * CPL + j];
     }
-    __syncthreads();
+    wave_lds_sync();
     int my_n = 0, my_slot = 0, my_st = -1;
     const int block_lo = base < 1 ? 1 : base;  // lowest row of this block that exists
     while (t >= block_lo && n > 0) {
@@ -625,8 +621,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         continue;
       }
       // state E in column n at row t: every lane tests its own row for this column
-      const uint64_t w = sb[lane * CPL + (slot % CPL)];  // ballot word of cell index j = slot % CPL
-      const bool bit = (row >= block_lo) && (row <= t) && ((w >> (slot / CPL)) & 1);  // lane = slot / CPL
+      const uint64_t wd = sb[lane * CPL + (slot % CPL)];  // ballot word of cell index j = slot % CPL
+      const bool bit = (row >= block_lo) && (row <= t) && ((wd >> (slot / CPL)) & 1);  // lane = slot / CPL
       const uint64_t m = __ballot(bit);
       const int r = m ? base + (63 - __builtin_clzll(m)) : block_lo - 1;  // highest turning row, or none
       const int e_lo = m ? r : block_lo;  // rows e_lo..t are E cells of column n
@@ -643,109 +639,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     if (my_st >= 0) {
-      // E cell of the path: k_forward stored its log-posterior. M cells (segment starts, ~1 row in 10)
-      // get theirs from k_mpost, one thread per segment, instead of ~6 dependent loads in this walk.
-      const size_t cell = (size_t)row * P + row_pos(my_slot);
+      // E cell of the path: the forward sweep stored its log-posterior. M cells (segment starts, ~1 row in
+      // 10) get theirs from mpost, one lane per segment, instead of ~6 dependent loads in this walk.
+      const size_t cell = (size_t)prow * P + row_pos(my_slot);
       if (inplace) pp[row] = exp((double)lp[2 * cell + (my_st ? 0 : 1)]);
       else if (my_st == 0) pp[row] = exp((double)lp[cell]);
       pathn[row] = (uint32_t)my_n | (my_st ? 0x80000000u : 0u);
       if (my_st) segrow[my_n - 1] = (uint32_t)row;
     }
-    __syncthreads();
+    wave_lds_sync();
   }
-  if (lane == 0) {
-    const bool complete = (t == 0 && n == 0);
-    st[rd.read].status = complete ? 0 : 7;
-    st[rd.read].n_segments = complete ? (uint32_t)(N - 1) : 0;
-  }
+  return t == 0 && n == 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_mpost: posterior of the M cell (segment start) of every segment. k_forward stores only LPE; the
+// mpost: posterior of the M cell (segment start) of every segment. The forward sweep stores only LPE; the
 // M cell (row, n) is preceded on the path by the E cell (row-1, n-1), so
 //   fE(row-1, n-1) = LPE(row-1, n-1) - bE(row-1, n-1) + Zb      (NT_aligner_api.cpp:222 solved for fE)
 //   fM(row, n)     = (fE(row-1, n-1) + e(row, n)) + m1            (:146)
 //   bM(row, n)     = bE(row+1, n) + e(row+1, n)                   (:200; row T of the workspace is -inf)
 //   LPM(row, n)    = (fM + bM) - Zb                               (:222)
-// The float LPE costs <= 6e-8 * |LPE| here; every other term is fp64. One thread per segment.
+// The float LPE costs <= 6e-8 * |LPE| here; every other term is fp64. One lane per segment.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_mpost(const ReadDesc* __restrict__ descs, const double* __restrict__ ws,
-                        const float* __restrict__ lpe, const double* __restrict__ sig,
-                        const Emis* __restrict__ par, const ReadState* __restrict__ st, TraceBuffers tb,
-                        double m1) {
-  const ReadDesc rd = descs[blockIdx.y];
-  const ReadState s = st[rd.read];
-  if (s.status != 0) return;
+__device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ bE,
+                                      const float* __restrict__ lp, const double* __restrict__ sig,
+                                      const Emis* __restrict__ par, TraceBuffers tb, double Zb, double m1) {
   const int T = (int)rd.T, N = (int)rd.N;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x + 1;  // lattice column of the segment, 1 .. N-1
-  if (n >= N) return;
-  const double* __restrict__ bE = ws + rd.ws_off;
-  const float* __restrict__ lp = lpe + rd.ws_off;
   const double* __restrict__ sg = sig + rd.sig_off;
-  const int row = (int)tb.segrow[rd.seg_off + n - 1];
-  const int slot = n % P, pslot = (n - 1) % P;
-  const size_t pcell = (size_t)(row - 1) * P + row_pos(pslot);
-  const double fE_prev = row == 1 ? (n == 1 ? 0.0 : NEG_INF)  // fE(0, 0) = 0, nothing else in row 0 (:120)
-                                  : ((double)lp[pcell] - bE[pcell]) + s.Zb;
-  const Emis em = par[rd.par_off + n - 1];
-  const double e_here = dynmath::log_normal_pdf(sg[row - 1], em);
-  const double e_next = row + 1 < T ? dynmath::log_normal_pdf(sg[row], em) : NEG_INF;
-  const double fM = (fE_prev + e_here) + m1;
-  const double bM = bE[(size_t)(row + 1) * P + row_pos(slot)] + e_next;
-  tb.pp[rd.path_off + row] = exp((fM + bM) - s.Zb);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K_median: formattedMedian (aligner.cpp:247-263) by rank counting. One thread per path row;
-// the segment of column n spans rows [segrow[n-1], segrow[n]) (last column: up to T-1).
-// Ties are broken by row so ranks are a permutation.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
-                         TraceBuffers tb) {
-  const ReadDesc rd = descs[blockIdx.y];
-  if (st[rd.read].status != 0) return;
-  const int T = (int)rd.T, N = (int)rd.N;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  if (t >= T) return;
-  const double* __restrict__ pp = tb.pp + rd.path_off;
-  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
-  const int n = (int)(tb.pathn[rd.path_off + t] & 0x7fffffffu);
-  const int a = (int)segrow[n - 1];
-  const int b = (n < N - 1) ? (int)segrow[n] : T;
-  const int L = b - a;
-  const double x = pp[t];
-  int rank = 0;
-  for (int u = a; u < b; ++u) {
-    const double y = pp[u];
-    rank += (y < x) || (y == x && u < t);
+  for (int n = 1 + w.lane; n < N; n += 64) {  // lattice column of the segment, 1 .. N-1
+    const int row = (int)tb.segrow[rd.seg_off + n - 1];
+    const int slot = n % P, pslot = (n - 1) % P;
+    double fE_prev;
+    if (row == 1) {
+      fE_prev = n == 1 ? 0.0 : NEG_INF;  // fE(0, 0) = 0, nothing else in row 0 (:120)
+    } else {
+      const size_t pcell = (size_t)pool_row(w, row - 1) * P + row_pos(pslot);
+      fE_prev = ((double)lp[pcell] - bE[pcell]) + Zb;
+    }
+    const Emis em = par[rd.par_off + n - 1];
+    const double e_here = dynmath::log_normal_pdf(sg[row - 1], em);
+    const double e_next = row + 1 < T ? dynmath::log_normal_pdf(sg[row], em) : NEG_INF;
+    const double fM = (fE_prev + e_here) + m1;
+    const double bM = bE[(size_t)pool_row(w, row + 1) * P + row_pos(slot)] + e_next;
+    tb.pp[rd.path_off + row] = exp((fM + bM) - Zb);
   }
-  const int mid = L >> 1;
-  if (rank == mid) tb.med_hi[rd.seg_off + n - 1] = x;
-  if (!(L & 1) && rank == mid - 1) tb.med_lo[rd.seg_off + n - 1] = x;
-}
-
-// K_final: one output row per segment (NT_aligner_api.cpp:420-430).
-__global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
-                        TraceBuffers tb, SegRow* __restrict__ rows, int kmer_size) {
-  const ReadDesc rd = descs[blockIdx.y];
-  if (st[rd.read].status != 0) return;
-  const int T = (int)rd.T, N = (int)rd.N;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // segment index = column - 1
-  if (i >= N - 1) return;
-  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
-  const int a = (int)segrow[i];
-  const int b = (i + 1 < N - 1) ? (int)segrow[i + 1] : T;
-  const int L = b - a;
-  const double hi = tb.med_hi[rd.seg_off + i];
-  SegRow r;
-  r.signal_pos = (uint32_t)(a - 1);
-  r.sequence_pos = (uint32_t)(i + kmer_size / 2);
-  r.probability = (L & 1) ? hi : (tb.med_lo[rd.seg_off + i] + hi) / 2.0;
-  rows[rd.seg_off + i] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_fwd_train: forward fused with the Baum-Welch statistics of runTraining / trainTransition.
+// forward fused with the Baum-Welch statistics of runTraining / trainTransition.
 // Per lattice cell (t >= 1, n >= 1), with gamma_M = exp(LPM), gamma_E = exp(LPE):
 //   w[kmer] += gamma_M + gamma_E ; s1 += gamma*x ; s2 += gamma*x*x      NT_aligner_api.cpp:505-512
 // Transition expectations (:683,:690) are rewritten through the recursions they sum over:
@@ -753,28 +694,22 @@ __global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __r
 //   fE(t,n)+e2+e(t+1,n)+bE(t+1,n)     = second logPlus operand of fE(t+1,n) + bE(t+1,n)
 // so both are plain sums of per-cell posteriors (linear domain, relative to Zb).
 // Column sums stay in registers while the column is in the band and are flushed once per column.
+// Returns Zf; the two transition sums go to tb.trans.
 // ---------------------------------------------------------------------------------------------
-__global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict__ descs,
-                                                       const double* __restrict__ sig,
-                                                       const Emis* __restrict__ par,
-                                                       const double* __restrict__ ws,
-                                                       ReadState* __restrict__ st,
-                                                       TrainBuffers tb, double m1, double e2,
-                                                       const SoftplusNode* __restrict__ sp_tab, int n_reads) {
-  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
-  const int ridx = stage_table_and_pick_read(s_tab, sp_tab, n_reads);
-  if (ridx < 0) return;
-  const ReadDesc rd = descs[ridx];
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const WaveCtx& w,
+                                                      const double* __restrict__ sig, const Emis* __restrict__ par,
+                                                      const double* __restrict__ ws, TrainBuffers tb, double Z,
+                                                      double m1, double e2, const SoftplusNode* s_tab) {
+  const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  const double* __restrict__ lat = ws + rd.ws_off + lane;
+  const double* __restrict__ lat = ws + lane;
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
-  const double Z = st[rd.read].Zb;
+  RowCursor cur;
 
   int lo = band_mid(0, ratio) - bw;
   int n[CPL];
@@ -783,16 +718,19 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
   EmisV<CPL> p;
   double sumM = 0.0, sumE2 = 0.0;
   const double x0 = sg[0];
+  {
+    const size_t r1 = (size_t)cur.at(w, 1) * P, r2 = (size_t)cur.at(w, min(2, T)) * P;  // row T is all -inf
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int slot = lane * CPL + j;
-    n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], N));
-    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
-    fM[j] = NEG_INF;
-    bcur[j] = lat[(size_t)1 * P + j * 64];
-    bnext[j] = (T > 2) ? lat[(size_t)2 * P + j * 64] : NEG_INF;
-    aw[j] = a1[j] = a2[j] = 0.0;
+    for (int j = 0; j < CPL; ++j) {
+      const int slot = lane * CPL + j;
+      n[j] = lo + pmod(slot - lo);
+      p.set(j, load_emis(pr, n[j], N));
+      fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
+      fM[j] = NEG_INF;
+      bcur[j] = lat[r1 + j * 64];
+      bnext[j] = lat[r2 + j * 64];
+      aw[j] = a1[j] = a2[j] = 0.0;
+    }
   }
   log_normal_pdf_vec<CPL>(x0, p, e);
 
@@ -807,9 +745,9 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
       const double xn = readlane_f64(xs, i);
       double fEl[CPL], bnn[CPL];
       from_left(fE, fEl);
-      const bool have = (t + 2 < T);
+      const size_t r2 = (size_t)cur.at(w, min(t + 2, T)) * P;  // rows past T-1: the -inf row T
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) bnn[j] = have ? lat[(size_t)(t + 2) * P + j * 64] : NEG_INF;
+      for (int j = 0; j < CPL; ++j) bnn[j] = lat[r2 + j * 64];
       const int new_lo = band_mid(t, ratio) - bw;
       if (new_lo != lo) {
         const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load
@@ -824,7 +762,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
             aw[j] = a1[j] = a2[j] = 0.0;
             n[j] = lo + P;
             p.set(j, fresh);
-            e[j] = NEG_INF;  // empties the slot (see k_forward)
+            e[j] = NEG_INF;  // empties the slot (see forward_sweep)
           }
         }
         lo = new_lo;
@@ -883,15 +821,308 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_forward_train(const ReadDesc* __restrict
     sumM += __shfl_xor(sumM, off);
     sumE2 += __shfl_xor(sumE2, off);
   }
-  const int nf = band_mid(T - 1, ratio);
-  const int sf = pmod(nf);
-#pragma unroll
-  for (int j = 0; j < CPL; ++j)
-    if (j == sf % CPL && lane == sf / CPL) st[rd.read].Zf = fE[j];
   if (lane == 0) {
     tb.trans[2 * rd.read] = sumM;
     tb.trans[2 * rd.read + 1] = sumE2;
   }
+  const int nf = band_mid(T - 1, ratio);
+  const int sf = pmod(nf);
+  double zf = 0.0;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j)
+    if (j == sf % CPL) zf = fE[j];
+  return readlane_f64(zf, sf / CPL);
+}
+
+// ---- read queue and page pool -------------------------------------------------------------------------
+// Shared control words are only ever touched with agent-scope atomics (sc1 accesses: the per-XCD L2s are
+// not coherent with each other, MI355X_MICROARCH.md "inter-workgroup visibility"); a lock serialises the
+// queue head and the free-page stack. It is taken twice per read (take pages, give them back), i.e. every
+// ~20 us at full speed, by ONE lane of the wave.
+__device__ __forceinline__ uint32_t ctl_load(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ctl_store(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every wait below is bounded: a wave that has waited for seconds (a lost lock, a page count that never
+// recovers) raises the abort word, which drains the queue -- the grid always terminates, and the host
+// reports the launch as failed instead of hanging the device.
+constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5;
+constexpr int LOCK_SPINS_MAX = 1 << 24;   // x ~0.3 us
+constexpr int PAGE_WAITS_MAX = 1 << 18;   // x ~30 us
+
+__device__ __forceinline__ void queue_lock(uint32_t* ctl, int lane) {
+  if (lane == 0) {
+    for (int spins = 0;; ++spins) {
+      uint32_t expect = 0;
+      if (__hip_atomic_compare_exchange_strong(&ctl[CTL_LOCK], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+        break;
+      if (spins > LOCK_SPINS_MAX) {
+        ctl_store(&ctl[CTL_ABORT], 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void queue_unlock(uint32_t* ctl, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every access of the critical section has completed
+  if (lane == 0) ctl_store(&ctl[CTL_LOCK], 0u);
+}
+
+// A wave KEEPS the pages of the read it has finished: the queue is sorted longest first, so the next
+// read it claims never needs more (no lock, no fence in the steady state -- one atomic add on the queue
+// head per read). The shared free-page stack (behind the lock) is only touched
+//   * by waves that start without an arena because the pool could not serve every wave (they wait
+//     for pages while holding none, so waiting can never deadlock),
+//   * by waves whose next read needs much less than they hold while some wave is waiting, and
+//   * at exit, while a claimed read still lacks its pages.
+
+// pt[off .. off+count) -> free list. Every store of this wave to those pages must have been written
+// back from this XCD's L2 before a wave on another XCD fills them again (agent-scope release).
+__device__ __forceinline__ void pages_give(const QueueArgs& q, const WaveCtx& w, uint32_t off, uint32_t count) {
+  uint32_t* ctl = q.pool.ctl;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  queue_lock(ctl, w.lane);
+  const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE]));
+  for (uint32_t k = w.lane; k < count; k += 64) ctl_store(&q.pool.free_list[fc + k], w.pt[off + k]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (w.lane == 0) ctl_store(&ctl[CTL_FREE], fc + count);
+  queue_unlock(ctl, w.lane);
+}
+
+// `count` pages from the free list -> pt[0 .. count); the wave holds no pages while it waits.
+// Returns false when the launch was aborted.
+__device__ __forceinline__ bool pages_take(const QueueArgs& q, const WaveCtx& w, uint32_t count) {
+  uint32_t* ctl = q.pool.ctl;
+  if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_WAITING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = false;
+  for (int waits = 0; !ok; ++waits) {
+    if (__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_ABORT])) != 0) break;
+    if (waits > PAGE_WAITS_MAX) {
+      if (w.lane == 0) ctl_store(&ctl[CTL_ABORT], 1u);
+      break;
+    }
+    // look before locking: the lock is only worth taking when the request can be served
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE])) < count) {
+      for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127);  // pages come back every ~20 us at best
+      continue;
+    }
+    queue_lock(ctl, w.lane);
+    const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE]));
+    if (fc >= count) {
+      for (uint32_t k = w.lane; k < count; k += 64) w.pt[k] = ctl_load(&q.pool.free_list[fc - count + k]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (w.lane == 0) ctl_store(&ctl[CTL_FREE], fc - count);
+      ok = true;
+    }
+    queue_unlock(ctl, w.lane);
+  }
+  if (w.lane == 0) __hip_atomic_fetch_sub(&ctl[CTL_WAITING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return ok;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// per-column emission table: par[i] = model[kmers[i]]  (aligner.cpp:241-245 scoreKmer lookup)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __restrict__ model,
+                              Emis* __restrict__ par, uint64_t total) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) par[i] = model[kmers[i]];
+}
+
+__global__ void k_pool_init(PagePool pool, uint32_t first_free, uint32_t n_static) {
+  const uint32_t n_free = pool.n_pages - first_free;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_free) pool.free_list[i] = first_free + i;
+  // queue head and provisioned reads start behind the first round, whose pages the host reserved
+  if (i < QUEUE_CTL_WORDS) pool.ctl[i] = (i == CTL_HEAD || i == CTL_PROVISIONED) ? n_static : (i == CTL_FREE) ? n_free : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The read queue. JOB_Z: align(calc_probabilities=false), Z check only, no stored lattice.
+// JOB_ALIGN / JOB_ALIGN_INPLACE: align(calc_probabilities=true) up to the per-row path arrays
+// (k_median / k_final follow). JOB_TRAIN: train() up to the per-column sums.
+// ---------------------------------------------------------------------------------------------
+// The read-only inputs are separate `const __restrict__` kernel parameters on purpose: as members of the
+// by-value argument struct they carry no no-alias information, and hipcc then turns the wave-uniform
+// loads from them (emission parameters in the window-move blocks, read descriptors) into VECTOR loads
+// guarded by s_waitcnt vmcnt(0) -- which drains the forward sweep's DMA ring every ~13 rows.
+template <int JOB>
+__global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const ReadDesc* __restrict__ descs,
+                                                   const double* __restrict__ sig, const Emis* __restrict__ par,
+                                                   const SoftplusNode* __restrict__ sp_tab) {
+  constexpr bool LATTICE = JOB != JOB_Z;
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
+  __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
+  __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
+  for (int i = threadIdx.x; i < SP_NODES; i += 256) s_tab[i] = sp_tab[i];
+  __syncthreads();
+  // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
+  // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /
+  // parameter access becomes a vector load.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slot = blockIdx.x * DYN_WAVES_PER_GROUP + wave;
+  WaveCtx w;
+  w.lane = threadIdx.x & 63;
+  w.pt = (lds_u32_t*)&s_pt[wave][0];
+  w.log_r = q.pool.log_rows;
+  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[wave][0][0];
+  lds_u64_t* sb = (lds_u64_t*)&s_ring[wave][0][0];  // traceback staging: the ring is idle by then
+
+  uint64_t cyc_b = 0, cyc_f = 0, cyc_t = 0, cyc_w = 0;
+  const uint64_t t_start = __builtin_amdgcn_s_memtime();
+  uint32_t* ctl = q.pool.ctl;
+  uint32_t have = 0;  // pages in this wave's table
+  bool first = true;
+  for (;;) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    int idx;
+    if (first && slot < q.n_static) {
+      idx = slot;  // first round: read and pages assigned by the host
+    } else {
+      uint32_t h = 0;
+      if (w.lane == 0) h = __hip_atomic_fetch_add(&ctl[CTL_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      idx = __builtin_amdgcn_readfirstlane((int)h);
+    }
+    if (idx >= q.n_reads || idx < 0) break;
+    const ReadDesc rd = descs[idx];
+    if (LATTICE) {
+      if (first && rd.first_page != NO_PAGE) {
+        for (uint32_t k = w.lane; k < rd.n_pages; k += 64) w.pt[k] = rd.first_page + k;
+        have = rd.n_pages;
+      } else {
+        if (have < rd.n_pages) {  // a wave without an arena (or, with another queue order, too small a one)
+          if (have) pages_give(q, w, 0, have);
+          have = 0;
+          if (!pages_take(q, w, rd.n_pages)) break;
+          have = rd.n_pages;
+        } else if (have - rd.n_pages >= 8 && 8 * (have - rd.n_pages) >= have &&
+                   __builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_WAITING])) != 0) {
+          pages_give(q, w, rd.n_pages, have - rd.n_pages);  // a wave is waiting: hand over what this read leaves unused
+          have = rd.n_pages;
+        }
+        if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_PROVISIONED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    first = false;
+    wave_lds_sync();
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    cyc_w += t1 - t0;
+
+    const double Zb = backward_sweep<LATTICE>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+    const uint64_t t2 = __builtin_amdgcn_s_memtime();
+    cyc_b += t2 - t1;
+    double Zf;
+    if (JOB == JOB_TRAIN) {
+      Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab);
+    } else if (JOB == JOB_ALIGN) {
+      Zf = forward_sweep<true, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+    } else if (JOB == JOB_ALIGN_INPLACE) {
+      Zf = forward_sweep<true, true>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+    } else {
+      Zf = forward_sweep<false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+    }
+    const uint64_t t3 = __builtin_amdgcn_s_memtime();
+    cyc_f += t3 - t2;
+
+    int status = z_ok(rd, Zf, Zb) ? 0 : q.z_fail_status;
+    uint32_t n_seg = 0;
+    if ((JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE) && status == 0) {
+      const float* lp = JOB == JOB_ALIGN ? q.pool.lpe : reinterpret_cast<const float*>(q.pool.ws);
+      const bool complete = traceback(rd, w, lp, q.pool.bits, q.tb, JOB == JOB_ALIGN_INPLACE, sb);
+      if (complete) {
+        if (JOB == JOB_ALIGN) {
+          // segrow was written by other lanes of this wave through global memory
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          mpost(rd, w, q.pool.ws, q.pool.lpe, sig, par, q.tb, Zb, q.m1);
+        }
+        n_seg = rd.N - 1;
+      } else {
+        status = 7;  // DYN_READ_INTERNAL
+      }
+    }
+    if (w.lane == 0) {
+      ReadState s;
+      s.Zb = Zb;
+      s.Zf = Zf;
+      s.status = status;
+      s.n_segments = n_seg;
+      q.st[rd.read] = s;
+    }
+    cyc_t += __builtin_amdgcn_s_memtime() - t3;
+  }
+  // leaving: while a claimed read still lacks its pages, somebody may be waiting for these
+  if (LATTICE && have && (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_PROVISIONED])) < (uint32_t)q.n_reads)
+    pages_give(q, w, 0, have);
+  if (w.lane == 0) {
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(q.pool.ctl + QUEUE_STATS);
+    atomicAdd(&stats[0], (unsigned long long)cyc_b);
+    atomicAdd(&stats[1], (unsigned long long)cyc_f);
+    atomicAdd(&stats[2], (unsigned long long)cyc_t);
+    atomicAdd(&stats[3], (unsigned long long)cyc_w);
+    const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
+    atomicAdd(&stats[4], life);
+    atomicMax(&stats[5], life);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_median: formattedMedian (aligner.cpp:247-263) by rank counting. One thread per path row;
+// the segment of column n spans rows [segrow[n-1], segrow[n]) (last column: up to T-1).
+// Ties are broken by row so ranks are a permutation.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                         TraceBuffers tb) {
+  const ReadDesc rd = descs[blockIdx.y];
+  if (st[rd.read].status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (t >= T) return;
+  const double* __restrict__ pp = tb.pp + rd.path_off;
+  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+  const int n = (int)(tb.pathn[rd.path_off + t] & 0x7fffffffu);
+  const int a = (int)segrow[n - 1];
+  const int b = (n < N - 1) ? (int)segrow[n] : T;
+  const int L = b - a;
+  const double x = pp[t];
+  int rank = 0;
+  for (int u = a; u < b; ++u) {
+    const double y = pp[u];
+    rank += (y < x) || (y == x && u < t);
+  }
+  const int mid = L >> 1;
+  if (rank == mid) tb.med_hi[rd.seg_off + n - 1] = x;
+  if (!(L & 1) && rank == mid - 1) tb.med_lo[rd.seg_off + n - 1] = x;
+}
+
+// K_final: one output row per segment (NT_aligner_api.cpp:420-430).
+__global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                        TraceBuffers tb, SegRow* __restrict__ rows, int kmer_size) {
+  const ReadDesc rd = descs[blockIdx.y];
+  if (st[rd.read].status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // segment index = column - 1
+  if (i >= N - 1) return;
+  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+  const int a = (int)segrow[i];
+  const int b = (i + 1 < N - 1) ? (int)segrow[i + 1] : T;
+  const int L = b - a;
+  const double hi = tb.med_hi[rd.seg_off + i];
+  SegRow r;
+  r.signal_pos = (uint32_t)(a - 1);
+  r.sequence_pos = (uint32_t)(i + kmer_size / 2);
+  r.probability = (L & 1) ? hi : (tb.med_lo[rd.seg_off + i] + hi) / 2.0;
+  rows[rd.seg_off + i] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -958,15 +1189,21 @@ __global__ void k_hampel(const REAL* __restrict__ norm, const uint64_t* __restri
   }
 }
 
+// per-read kernels put the read index in gridDim.y (<= 65 535): larger batches go in slices
+constexpr int MAX_GRID_Y = 65535;
+
 template <class REAL, class RAW>
 static void preprocess_t(const RAW* raw, const uint64_t* offs, const double* shift, const double* scale,
                          void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double ns,
                          hipStream_t s) {
   const int bx = (int)std::min<uint64_t>(1024, (max_len + 255) / 256);
-  hipLaunchKernelGGL((k_normalise<REAL, RAW>), dim3(bx ? bx : 1, n_reads), dim3(256), 0, s, raw, offs, shift, scale,
-                     (REAL*)norm_tmp, n_reads);
-  hipLaunchKernelGGL((k_hampel<REAL>), dim3(bx ? bx : 1, n_reads), dim3(256), 0, s, (const REAL*)norm_tmp, offs, out,
-                     n_reads, W, ns);
+  for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {  // offs hold absolute sample positions: slices just shift the read index
+    const int nr = std::min(MAX_GRID_Y, n_reads - r0);
+    hipLaunchKernelGGL((k_normalise<REAL, RAW>), dim3(bx ? bx : 1, nr), dim3(256), 0, s, raw, offs + r0, shift + r0,
+                       scale + r0, (REAL*)norm_tmp, nr);
+    hipLaunchKernelGGL((k_hampel<REAL>), dim3(bx ? bx : 1, nr), dim3(256), 0, s, (const REAL*)norm_tmp, offs + r0, out,
+                       nr, W, ns);
+  }
 }
 
 void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
@@ -1020,68 +1257,40 @@ void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint
   hipLaunchKernelGGL(k_prep_params, dim3(grid), dim3(block), 0, s, kmers, model, par, total);
 }
 
-void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                     double* ws, ReadState* st, double m1, double e2, bool store,
-                     const SoftplusNode* sp_tab, hipStream_t s) {
-  if (n_reads <= 0) return;
-  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
-  if (store)
-    hipLaunchKernelGGL(k_backward<true>, grid, block, 0, s, descs, sig, par, ws, st, m1, e2, sp_tab, n_reads);
-  else
-    hipLaunchKernelGGL(k_backward<false>, grid, block, 0, s, descs, sig, par, ws, st, m1, e2, sp_tab, n_reads);
+void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, hipStream_t s) {
+  const uint32_t n = std::max<uint32_t>(pool.n_pages - first_free, QUEUE_CTL_WORDS);
+  hipLaunchKernelGGL(k_pool_init, dim3((n + 255) / 256), dim3(256), 0, s, pool, first_free, (uint32_t)n_static);
 }
 
-void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
-                    const SoftplusNode* sp_tab, hipStream_t s) {
-  if (n_reads <= 0) return;
-  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
-  const double* rd = ws;
-  if (!post)
-    hipLaunchKernelGGL((k_forward<false, false>), grid, block, 0, s, descs, sig, par, rd, (float*)nullptr, bits, st, m1, e2, sp_tab, n_reads);
-  else if (lpe)
-    hipLaunchKernelGGL((k_forward<true, false>), grid, block, 0, s, descs, sig, par, rd, lpe, bits, st, m1, e2, sp_tab, n_reads);
-  else  // in place: the log-posteriors overwrite the bE rows
-    hipLaunchKernelGGL((k_forward<true, true>), grid, block, 0, s, descs, sig, par, rd, reinterpret_cast<float*>(ws), bits, st, m1, e2, sp_tab, n_reads);
+void launch_read_queue(QueueJob job, const QueueArgs& q, int n_cus, hipStream_t s) {
+  if (q.n_reads <= 0) return;
+  const int groups = std::min((q.n_reads + DYN_WAVES_PER_GROUP - 1) / DYN_WAVES_PER_GROUP, std::max(1, n_cus));
+  const dim3 grid(groups), block(256);
+  switch (job) {
+    case JOB_Z: hipLaunchKernelGGL(k_read_queue<JOB_Z>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_ALIGN: hipLaunchKernelGGL(k_read_queue<JOB_ALIGN>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_ALIGN_INPLACE: hipLaunchKernelGGL(k_read_queue<JOB_ALIGN_INPLACE>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_TRAIN: hipLaunchKernelGGL(k_read_queue<JOB_TRAIN>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+  }
 }
 
-void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                          const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
-                          const SoftplusNode* sp_tab, hipStream_t s) {
-  if (n_reads <= 0) return;
-  const dim3 grid((n_reads + DYN_READS_PER_GROUP - 1) / DYN_READS_PER_GROUP), block(256);
-  hipLaunchKernelGGL(k_forward_train, grid, block, 0, s, descs, sig, par, ws, st, tb, m1, e2, sp_tab, n_reads);
+void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
+                     TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s) {
+  for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {
+    const int nr = std::min(MAX_GRID_Y, n_reads - r0);
+    hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb);
+    hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb, rows, kmer_size);
+  }
 }
 
 void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
                        const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,
                        hipStream_t s) {
-  if (n_reads <= 0) return;
-  hipLaunchKernelGGL(k_pool_stats, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, kmers, tb,
-                     pooled, num_kmers);
-}
-
-void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,
-                   hipStream_t s) {
-  if (n_reads <= 0) return;
-  hipLaunchKernelGGL(k_zcheck, dim3((n_reads + 255) / 256), dim3(256), 0, s, descs, n_reads, st,
-                     z_fail_status);
-}
-
-void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
-                  const double* ws, const float* lpe, const uint64_t* bits, const double* sig, const Emis* par,
-                  ReadState* st, TraceBuffers tb, SegRow* rows, int kmer_size, double m1, int z_fail_status,
-                  hipStream_t s) {
-  if (n_reads <= 0) return;
-  if (lpe) {
-    hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, lpe, bits, st, tb, z_fail_status, 0);
-    hipLaunchKernelGGL(k_mpost, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, ws, lpe, sig, par, st, tb, m1);
-  } else {
-    hipLaunchKernelGGL(k_trace, dim3(n_reads), dim3(64), 0, s, descs, reinterpret_cast<const float*>(ws), bits, st, tb, z_fail_status, 1);
+  for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {
+    const int nr = std::min(MAX_GRID_Y, n_reads - r0);
+    hipLaunchKernelGGL(k_pool_stats, dim3((max_N + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, kmers, tb,
+                       pooled, num_kmers);
   }
-  hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb);
-  hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, n_reads), dim3(256), 0, s, descs, st, tb, rows,
-                     kmer_size);
 }
 
 }  // namespace dynk

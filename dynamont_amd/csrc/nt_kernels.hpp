@@ -21,11 +21,16 @@ constexpr int CPL = 7;                       // cells per lane
 constexpr int P = 64 * CPL;                  // 448 slots per row
 constexpr int MAX_HALF_BAND = (P - 2) / 2;   // 2*bw+1 <= P-1  ->  bw <= 223 (band <= 447)
 
+// The lattice of a read lives in PAGES of 2^log_rows rows taken from a pool that all reads of a
+// launch share: a read holds ceil((T+1) / rows_per_page) pages from the moment a wave starts its
+// backward sweep until its traceback is done. A wave keeps the page numbers of its current read in
+// LDS (PT_MAX entries), so rows_per_page is chosen per launch such that the longest read fits.
+constexpr int PT_MAX = 512;
+constexpr uint32_t NO_PAGE = 0xffffffffu;
+
 struct ReadDesc {
   uint64_t sig_off;   // first sample in the signal pool (doubles)
   uint64_t par_off;   // first entry in the per-column emission table; entry n-1 <-> column n
-  uint64_t ws_off;    // lattice workspace [T+1][P] (8 B per slot; row T = -inf)
-  uint64_t bits_off;  // decision bits [T][CPL] (uint64)
   uint64_t path_off;  // per-row path arrays [T]
   uint64_t seg_off;   // first output row of this read
   uint32_t T;         // signal length + 1   (NT_aligner_api.cpp:241)
@@ -33,6 +38,9 @@ struct ReadDesc {
   uint32_t bw;        // min(band/2, N/2)    (NT_aligner_api.cpp:243)
   uint32_t read;      // index into the per-read state arrays
   double ratio;       // double(N)/double(T) (NT_aligner_api.cpp:96)
+  uint32_t first_page;  // pages first_page .. first_page+n_pages-1 were reserved by the host (first round of a
+                        // launch), or NO_PAGE: the wave takes n_pages from the pool's free list
+  uint32_t n_pages;     // lattice rows 0..T in pages; 0 for jobs without a stored lattice
 };
 
 struct ReadState {
@@ -63,6 +71,42 @@ struct TrainBuffers {
   double* trans;      // [2*reads] expected E->M and E->E transition counts (linear domain)
 };
 
+// Page pool + read queue of one launch (device pointers).
+struct PagePool {
+  double* ws;           // [n_pages][rows_per_page][P]   backward-E (8 B per slot); in place: (float LPM, float LPE)
+  float* lpe;           // [n_pages][rows_per_page][P]   float LPE per slot (separate layout) or nullptr
+  uint64_t* bits;       // [n_pages][rows_per_page][CPL] decision ballots
+  uint32_t* free_list;  // stack of free page numbers
+  // ctl (32-bit words): [0] lock of the free-page stack, [1] queue head (next read), [2] free pages on the
+  // stack, [3] abort (a wave gave up waiting: the queue drains, the host reports the launch as failed),
+  // [4] reads whose pages are in place, [5] waves waiting for pages.
+  // ctl + QUEUE_STATS (64-bit words): wave-cycles spent in backward, forward, traceback, waiting for pages,
+  // lifetime (all summed over the waves of the launch), longest lifetime.
+  uint32_t* ctl;
+  int log_rows;         // rows per page = 1 << log_rows
+  uint32_t n_pages;
+};
+constexpr int QUEUE_CTL_WORDS = 32;   // 32-bit words reserved for ctl (stats start at word 8, 8-byte aligned)
+constexpr int QUEUE_STATS = 8;        // first stats word (as uint32 index)
+constexpr int QUEUE_N_STATS = 6;
+
+enum QueueJob { JOB_Z = 0, JOB_ALIGN = 1, JOB_ALIGN_INPLACE = 2, JOB_TRAIN = 3 };
+
+struct QueueArgs {
+  const ReadDesc* descs;   // in processing order
+  int n_reads;
+  int n_static;            // reads [0, n_static) are pre-assigned: wave slot s starts with read s (no queue access)
+  const double* sig;
+  const Emis* par;
+  PagePool pool;
+  ReadState* st;
+  TraceBuffers tb;
+  TrainBuffers tr;
+  double m1, e2;
+  const dynmath::SoftplusNode* sp_tab;
+  int z_fail_status;
+};
+
 // P1/P2 on the device: out[i] = hampel((REAL(raw[i]) - shift) / scale); REAL = float when compute_f32.
 // raw_dtype: 0 float32, 1 int16, 2 float64. norm_tmp: scratch of total samples * sizeof(REAL).
 void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
@@ -70,24 +114,16 @@ void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const ui
                        int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s);
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
                         hipStream_t s);
-// sp_tab: device copy of dynmath::softplus_build_table (SP_NODES entries)
-void launch_backward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                     double* ws, ReadState* st, double m1, double e2, bool store,
-                     const dynmath::SoftplusNode* sp_tab, hipStream_t s);
-// lpe != nullptr: float [rows][P] log-posterior of state E per slot, indexed like ws (ws stays intact);
-// lpe == nullptr (with post): (float LPM, float LPE) overwrite the 8-byte slots of ws in place
-void launch_forward(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                    double* ws, float* lpe, uint64_t* bits, ReadState* st, double m1, double e2, bool post,
-                    const dynmath::SoftplusNode* sp_tab, hipStream_t s);
-void launch_forward_train(const ReadDesc* descs, int n_reads, const double* sig, const Emis* par,
-                          const double* ws, ReadState* st, TrainBuffers tb, double m1, double e2,
-                          const dynmath::SoftplusNode* sp_tab, hipStream_t s);
-void launch_trace(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N,
-                  const double* ws, const float* lpe, const uint64_t* bits, const double* sig, const Emis* par,
-                  ReadState* st, TraceBuffers tb, SegRow* rows, int kmer_size, double m1, int z_fail_status,
-                  hipStream_t s);
-void launch_zcheck(const ReadDesc* descs, int n_reads, ReadState* st, int z_fail_status,
-                   hipStream_t s);
+// free list = pages [first_free, n_pages); queue head = n_static; statistics cleared
+void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, hipStream_t s);
+// The whole per-read pipeline as ONE launch of persistent waves (see nt_kernels.hip): each wave takes
+// reads off the queue until it is empty; per read backward -> forward (+ posterior, Viterbi fill,
+// decision bits | training statistics) -> Z check -> traceback -> segment-start posteriors.
+// n_cus: compute units of the device (one 4-wave workgroup per CU).
+void launch_read_queue(QueueJob job, const QueueArgs& q, int n_cus, hipStream_t s);
+// per-segment median posterior + output rows for all reads of descs (after launch_read_queue)
+void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
+                     TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s);
 // pooled[3*num_kmers] += per-k-mer (w, s1, s2) of the reads in descs (fp64 atomics)
 void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
                        const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,

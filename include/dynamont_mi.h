@@ -130,19 +130,28 @@ typedef struct dyn_train_out {
   uint64_t capacity;      /* >= dyn_segment_capacity() */
 } dyn_train_out;
 
-/* Kernel timings of the last dyn_batch_align / dyn_batch_train on a batch, measured with HIP
- * events on the stream the kernels were launched on. */
+/* Timings of the last dyn_batch_align / dyn_batch_train on a batch, measured with HIP events on the
+ * stream the kernels were launched on. All reads of a batch run in ONE launch of persistent waves
+ * (k_read_queue: per read backward -> forward -> Z check -> traceback), so the per-phase figures are
+ * that launch's duration split by the share of wave time each phase took (device cycle counters). */
 typedef struct dyn_timing {
-  double ms_total;       /* first launch -> last launch complete */
-  double ms_backward;    /* K_bwd  */
-  double ms_forward;     /* K_fwd (forward + posterior + posterior-Viterbi, fused) */
-  double ms_trace;       /* K_trace + K_median + K_final */
+  double ms_total;       /* read-queue launch + per-segment kernels */
+  double ms_dp;          /* the read-queue launch alone */
+  double ms_backward;    /* ms_dp x share of wave time in backward sweeps */
+  double ms_forward;     /* ms_dp x share in forward sweeps (forward + posterior + posterior-Viterbi | training sums) */
+  double ms_trace;       /* ms_dp x share in traceback / write-back, + k_median + k_final (+ k_pool_stats) */
+  double wave_wait_share;  /* share of wave time spent waiting for lattice pages or the queue lock */
+  double wave_occupancy;   /* sum of wave lifetimes / (waves x longest lifetime): 1 = every wave busy to the end */
   uint64_t cells;        /* in-band lattice cells processed: sum over ok reads of T*min(2bw+1,N) */
   uint64_t samples;      /* sum of signal lengths over ok reads */
   uint64_t reads_ok;
-  uint32_t launches_backward, launches_forward; /* >1 when the batch was split to fit HBM */
-  uint32_t lp_inplace;   /* 1: the batch did not fit one launch with the separate LPE array (12 B per band slot),
-                            the posteriors overwrote the backward rows in place (8 B per slot, slower kernel) */
+  uint32_t launches;     /* read-queue launches (1; 0 for a batch without an ok read) */
+  uint32_t lp_inplace;   /* 1: the page pool could not hold a separate-layout lattice (12 B per band slot) for every
+                            wave, the posteriors overwrote the backward rows in place (8 B per slot, slower sweep) */
+  uint32_t pool_pages;   /* pages in the lattice pool */
+  uint32_t page_rows;    /* lattice rows per page */
+  uint32_t n_static;     /* reads whose pages were reserved by the host (first round) */
+  uint32_t n_waves;      /* persistent waves launched */
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,

@@ -206,16 +206,32 @@ def test_order_and_chunking_invariance(models, al9):
     with al9.batch(sigs, seqs) as b:
         b.align(True)
         base = b.fetch()
-        assert b.timing()["launches_forward"] == 1 and b.timing()["lp_inplace"] == 0
+        tm = b.timing()
+        assert tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == len(reads)
     perm = np.random.default_rng(3).permutation(len(reads))
     shuf = al9.align_batch([sigs[i] for i in perm], [seqs[i] for i in perm], True)
     small = Aligner(models["syn9"], "rna004", device=0)
-    small.set_mem_budget(80 << 20)  # forces several launches (each read needs 20-30 MB)
+    small.set_mem_budget(80 << 20)  # a pool for 2-4 reads at a time (each read needs 20-30 MB): the rest queue for pages
     with small.batch(sigs, seqs) as b:
         b.align(True)
         chunked = b.fetch()
-        # a batch that does not fit one launch keeps its posteriors in place (8 instead of 12 B per slot)
-        assert b.timing()["launches_forward"] > 1 and b.timing()["lp_inplace"] == 1
+        # a pool that cannot serve every wave keeps the posteriors in place (8 instead of 12 B per slot);
+        # still one launch: reads past the first round take their pages from the free list on the device
+        tm = b.timing()
+        assert tm["launches"] == 1 and tm["lp_inplace"] == 1 and 0 < tm["n_static"] < len(reads)
+    os.environ["DYN_FORCE_LAYOUT"] = "separate"   # the same starved pool with the separate LPE layout
+    try:
+        with small.batch(sigs, seqs) as b:
+            b.align(True)
+            starved_sep = b.fetch()
+            tm = b.timing()
+            assert tm["lp_inplace"] == 0 and 0 < tm["n_static"] < len(reads) and tm["wave_wait_share"] > 0
+    finally:
+        del os.environ["DYN_FORCE_LAYOUT"]
+    for i in range(len(reads)):
+        a, s2 = base.read(i), starved_sep.read(i)
+        assert np.array_equal(a["signal_positions"], s2["signal_positions"]) and a["Z"] == s2["Z"]
+        assert np.array_equal(a["probabilities"], s2["probabilities"])  # same layout, same arithmetic: bitwise
     for j, i in enumerate(perm):
         a, s, c = base.read(int(i)), shuf.read(j), chunked.read(int(i))
         assert np.array_equal(a["signal_positions"], s["signal_positions"])
