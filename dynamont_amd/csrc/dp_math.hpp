@@ -293,6 +293,51 @@ DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
   for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
 }
 
+// log_plus_finish plus the logistic value sigma(d) = e^d / (1 + e^d) at the SAME argument d = lo - hi:
+// sigma is the first derivative of the softplus, so it is the derivative of the same Taylor polynomial
+// about the same node (4 more FMAs; truncation <= |g6|/120 * (1/256)^5 = 1.9e-15 * u, relative to a
+// value in (0, 1/2]). exp(lo - logPlus(x, y)) = sigma and exp(hi - logPlus(x, y)) = 1 - sigma: the
+// shares of the two operands in the sum, which is what the training pass needs (nt_kernels.hip,
+// forward_train_sweep) -- without an exponential. d <= -40 (and -inf, NaN) gives sigma = 0 exactly.
+template <int M>
+DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
+  double u[M], w[M], uw[M], p[M], q[M], dp[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) u[j] = L.s[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
+#pragma unroll
+  for (int j = 0; j < M; ++j) dp[j] = fma_(p[j] * 5.0, L.r[j], q[j] * 4.0);     // derivative: 5 c5 r + 4 c4
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], uw[j] * 0.5);         // + 3 c3
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], uw[j] * (1.0 / 6.0));
+#pragma unroll
+  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], u[j]);                // + 2 c2
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], u[j] * 0.5);
+#pragma unroll
+  for (int j = 0; j < M; ++j) sig[j] = fma_(dp[j], L.r[j], L.s[j]);             // + c1
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.s[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
+}
+
 // exp(d) for M independent arguments, d clamped to [-1000, 700] (posterior exponents are <= ~0).
 // Same reduction and degree-9 kernel as exp_nonpos above, written stage-by-stage across cells.
 template <int M>

@@ -693,84 +693,99 @@ __device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, cons
 //   fE(t,n)+m1+e(t+1,n+1)+bM(t+1,n+1) = fM(t+1,n+1)+bM(t+1,n+1)  ->  sum exp(LPM) over cells
 //   fE(t,n)+e2+e(t+1,n)+bE(t+1,n)     = second logPlus operand of fE(t+1,n) + bE(t+1,n)
 // so both are plain sums of per-cell posteriors (linear domain, relative to Zb).
-// Column sums stay in registers while the column is in the band and are flushed once per column.
+//
+// ONE exponential per cell instead of three. fE(t,n) = logPlus(x1, op2) with x1 = fM(t-1,n) + e(t,n)
+// (arrival from M) and op2 = fE(t-1,n) + e(t,n) + e2 (arrival from E), and an M cell has exactly one
+// way on, M(t-1,n) -> E(t,n) with e1 = 1. The posterior mass of E(t,n) therefore splits into the two
+// arrivals in proportion to the two operands of that logPlus:
+//   exp(LPM(t-1,n))                  = gamma_E(t,n) * exp(x1  - fE(t,n))     [= exp(fM + bM - Zb), bM = bE(t,n)+e(t,n)]
+//   E->E transition posterior (t,n)  = gamma_E(t,n) * exp(op2 - fE(t,n))
+// and the two factors are sigma(d) and 1 - sigma(d), d = min - max of the operands: the logistic value
+// the softplus lookup yields for four extra FMAs (dp_math.hpp, log_plus_finish_sigma). gamma_M of row
+// t-1 is thus accumulated one row late, with the sample of row t-1; gamma_M(T-1, .) = 0 (no successor).
+// Only bE(t, .) is needed per row, streamed through the LDS-DMA ring like in forward_sweep.
+//
+// Column sums stay in registers while the column is in the band. Band edges as in forward_sweep (no
+// per-row masks); a slot that has been handed on keeps receiving zeros, so the sums of the column that
+// left are written out at the NEXT window move (or at the end), not in the row loop.
 // Returns Zf; the two transition sums go to tb.trans.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                       const double* __restrict__ sig, const Emis* __restrict__ par,
                                                       const double* __restrict__ ws, TrainBuffers tb, double Z,
-                                                      double m1, double e2, const SoftplusNode* s_tab) {
+                                                      double m1, double e2, const SoftplusNode* s_tab,
+                                                      unsigned ring_base) {
   const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  const double* __restrict__ lat = ws + lane;
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
-  RowCursor cur;
+  RowCursor cur_dma;
 
-  int lo = band_mid(0, ratio) - bw;
+  int lo = band_mid(1, ratio) - bw;  // band of row 1
   int n[CPL];
-  double fM[CPL], fE[CPL], e[CPL], bcur[CPL], bnext[CPL];
+  double fM[CPL], fE[CPL], e[CPL], bcur[CPL];
   double aw[CPL], a1[CPL], a2[CPL];
   EmisV<CPL> p;
   double sumM = 0.0, sumE2 = 0.0;
   const double x0 = sg[0];
-  {
-    const size_t r1 = (size_t)cur.at(w, 1) * P, r2 = (size_t)cur.at(w, min(2, T)) * P;  // row T is all -inf
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const int slot = lane * CPL + j;
-      n[j] = lo + pmod(slot - lo);
-      p.set(j, load_emis(pr, n[j], N));
-      fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
-      fM[j] = NEG_INF;
-      bcur[j] = lat[r1 + j * 64];
-      bnext[j] = lat[r2 + j * 64];
-      aw[j] = a1[j] = a2[j] = 0.0;
-    }
+  for (int j = 0; j < CPL; ++j) {
+    const int slot = lane * CPL + j;
+    n[j] = lo + pmod(slot - lo);
+    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
+    fM[j] = NEG_INF;
+    aw[j] = a1[j] = a2[j] = 0.0;
   }
-  log_normal_pdf_vec<CPL>(x0, p, e);
+  log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
+  // ring prologue: rows 1 .. RING_D (row r lives in ring slot r % RING_D); rows past T repeat the -inf row T
+  const unsigned ring_lane = ring_base + lane * 8;
+  const double* __restrict__ dma_src = ws + lane * 2;
+  for (int r = 1; r <= RING_D; ++r)
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
 
-  double xcur = x0;  // sample of row t
+  double xt = x0, xp = 0.0;  // samples of rows t and t-1
   for (int tb0 = 1; tb0 < T; tb0 += 64) {
     const int idx = tb0 + lane;
     const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    asm volatile("" ::"v"(xs));  // the load's wait belongs here, not into the row loop (see forward_sweep)
     const int iend = min(64, T - tb0);
 #pragma unroll 1
     for (int i = 0; i < iend; ++i) {
       const int t = tb0 + i;
       const double xn = readlane_f64(xs, i);
-      double fEl[CPL], bnn[CPL];
+      double fEl[CPL];
+      wait_vmcnt<RING_WAIT>();
+      ring_read_row(ring_lane + (t % RING_D) * ROW_BYTES, bcur);  // bE(t, .)
+      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
       from_left(fE, fEl);
-      const size_t r2 = (size_t)cur.at(w, min(t + 2, T)) * P;  // rows past T-1: the -inf row T
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) bnn[j] = lat[r2 + j * 64];
-      const int new_lo = band_mid(t, ratio) - bw;
-      if (new_lo != lo) {
-        const Emis fresh = load_emis(pr, lo + P, N);  // uniform address -> scalar load
+      const int next_lo = band_mid(t + 1, ratio) - bw;
+      if (next_lo != lo) {  // wave-uniform: the window moves up by one column between rows t and t+1
+        const Emis none = load_emis(pr, 0, 0);
+        const Emis entering = load_emis(pr, lo + W, N);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          if (n[j] == lo) {
-            if (n[j] >= 1 && n[j] < N) {  // column leaves the band for good: flush its sums
-              cw[n[j] - 1] = aw[j];
-              cs1[n[j] - 1] = a1[j];
-              cs2[n[j] - 1] = a2[j];
+          // the slot handed on at the PREVIOUS move (column lo-1) has received nothing but zeros since
+          if (n[j] == lo - 1 + P) {
+            if (lo - 1 >= 1 && lo - 1 < N) {
+              cw[lo - 2] = aw[j];
+              cs1[lo - 2] = a1[j];
+              cs2[lo - 2] = a2[j];
             }
             aw[j] = a1[j] = a2[j] = 0.0;
-            n[j] = lo + P;
-            p.set(j, fresh);
-            e[j] = NEG_INF;  // empties the slot (see forward_sweep)
           }
+          const bool leaves = n[j] == lo;  // in the band for the last time in this row (see forward_sweep)
+          n[j] = leaves ? lo + P : n[j];
+          if (leaves) p.set(j, none);
+          if (n[j] == lo + W) p.set(j, entering);
         }
-        lo = new_lo;
+        lo = next_lo;
       }
-      const int hi_n = lo + W - 1;
-      double x1[CPL], op2[CPL], fMn[CPL], fEn[CPL], en[CPL], aM[CPL], aE[CPL], aT[CPL], gM[CPL], gE[CPL], gT[CPL];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) fEl[j] = (n[j] <= hi_n) ? fEl[j] : NEG_INF;
+      double x1[CPL], op2[CPL], fMn[CPL], fEn[CPL], en[CPL], sgm[CPL], aE[CPL], gE[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
 #pragma unroll
@@ -780,40 +795,37 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(x1, op2, L, s_tab);
       log_normal_pdf_vec<CPL>(xn, p, en);
-      log_plus_finish<CPL>(L, fEn);
-      // posteriors: state M, state E, and the E->E transition into (t,n)  (see header comment)
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) aM[j] = (fMn[j] + (bnext[j] + en[j])) - Z;
+      dynmath::log_plus_finish_sigma<CPL>(L, fEn, sgm);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) aE[j] = (fEn[j] + bcur[j]) - Z;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) aT[j] = (op2[j] + bcur[j]) - Z;
-      dynmath::exp_vec<CPL>(aM, gM);
       dynmath::exp_vec<CPL>(aE, gE);
-      dynmath::exp_vec<CPL>(aT, gT);
+      const double xt2 = xt * xt, xp2 = xp * xp;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        const double g = gM[j] + gE[j];
-        aw[j] += g;
-        a1[j] += g * xcur;
-        a2[j] += g * xcur * xcur;
-        sumM += gM[j];
-        sumE2 += gT[j];
+        const double shareE = (op2[j] >= x1[j]) ? 1.0 - sgm[j] : sgm[j];  // share of the arrival from E
+        const double gT = gE[j] * shareE;             // E(t-1,n) -> E(t,n)
+        const double gMp = gE[j] * (1.0 - shareE);    // = exp(LPM(t-1,n))
+        aw[j] = (aw[j] + gE[j]) + gMp;
+        a1[j] = dynmath::fma_(gMp, xp, dynmath::fma_(gE[j], xt, a1[j]));
+        a2[j] = dynmath::fma_(gMp, xp2, dynmath::fma_(gE[j], xt2, a2[j]));
+        sumM += gMp;
+        sumE2 += gT;
         fM[j] = fMn[j];
         fE[j] = fEn[j];
         e[j] = en[j];
-        bcur[j] = bnext[j];
-        bnext[j] = bnn[j];
       }
-      xcur = xn;
+      xp = xt;
+      xt = xn;
     }
   }
+  wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    if (n[j] >= 1 && n[j] < N) {
-      cw[n[j] - 1] = aw[j];
-      cs1[n[j] - 1] = a1[j];
-      cs2[n[j] - 1] = a2[j];
+    const int c = (n[j] == lo - 1 + P) ? lo - 1 : n[j];  // the slot handed on at the last move still holds that column's sums
+    if (c >= 1 && c < N) {
+      cw[c - 1] = aw[j];
+      cs1[c - 1] = a1[j];
+      cs2[c - 1] = a2[j];
     }
   }
   // wave reduction of the two transition sums
@@ -1024,7 +1036,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     cyc_b += t2 - t1;
     double Zf;
     if (JOB == JOB_TRAIN) {
-      Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab);
+      Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
     } else if (JOB == JOB_ALIGN) {
       Zf = forward_sweep<true, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
     } else if (JOB == JOB_ALIGN_INPLACE) {
