@@ -50,6 +50,11 @@ def model_values(k: int, seed: int = 7, stdev: float = 0.15) -> tuple[np.ndarray
 def write_model(path: str, k: int, seed: int = 7, stdev: float = 0.15) -> str:
     """Write a synthetic model TSV; values use repr() so they round-trip exactly."""
     mean, sd = model_values(k, seed, stdev)
+    return write_model_values(path, k, mean, sd)
+
+
+def write_model_values(path: str, k: int, mean: np.ndarray, sd: np.ndarray) -> str:
+    """Model TSV from explicit per-k-mer values in FILE order (lexicographic 5'->3')."""
     names = kmer_strings(k)
     tmp = path + ".tmp%d" % os.getpid()
     with open(tmp, "w") as w:

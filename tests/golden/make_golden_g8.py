@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Generate golden vector G8: the reference's dynamont-train parameter update (the sliding-window
+mean of per-read estimates) over two batches, from the COMPILED REFERENCE's train()/align().
+
+Runs only in the authoring container (needs oracle/_ref built by `make -C oracle ref`).
+
+    python tests/golden/make_golden_g8.py
+
+What is the reference here
+  * per-read numbers: NTAligner::train / ::align of the compiled reference (oracle/_ref, i.e.
+    /root/reference/src/cpp/{aligner,NT_aligner_api}.cpp compiled in place), called exactly where
+    train.py calls them: train() with the model file of the current batch (utils.py:163-182), then
+    align(calc_probabilities=False) with the NEW model file for the Z change (utils.py:184-191);
+  * the update arithmetic: restated below from /root/reference/src/dynamont/segmentation/train.py
+    -- ManagedList (:19-46: deque(maxlen=100), np.mean), the collectors initialised with the start
+    model and {'e1': 1.0, 'm1': 0.03, 'e2': 0.97} (:76-82,:104-106), per read: transitions added first,
+    then the "skip weird trainings" test on the polyA k-mer mean < 0.5, then EVERY k-mer of the dense
+    per-read model added to its window (:186-205), per batch: parameter := window mean, model file
+    written with f-string formatting, params.csv row `epoch,batch,reads,e1,m1,e2,Zchange` (:210-242).
+    The reference script itself cannot be imported here (pysam / pod5 are not installed).
+  * the reads come through OUR reader and preprocessing (dynamont_amd.segmentation.train.read_items,
+    host path: float32 `x -= sm; x /= sd; hampel(x, 7, 5.)` as train.py:163-170; hampel is pinned to the
+    reference's own outputs by G6), from the seeded synthetic dataset the test regenerates.
+
+Pore dna_r10_400bps (9-mer): for DNA pores the model's file order equals the aligner's k-mer-code
+order, so the reference's zip of file keys with code-ordered results (utils.py:171-175) pairs k-mers
+correctly and the golden is free of that quirk (dynamont_amd/segmentation/train.py header).
+
+Scenario "a": polyA mean 0.9 -> every read updates the emission windows. Scenario "b": polyA mean 0.2
+-> every read is a "weird training": transitions are updated, the emission model is not.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+from collections import deque
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from dynamont_amd import synth  # noqa: E402
+from dynamont_amd.segmentation.train import read_items  # noqa: E402
+from oracle.pyoracle import Reference  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+PORE, PORE_ID, K = "dna_r10_400bps", 4, 9
+BATCH, N_BATCHES, SEED = 4, 2, 808
+WINDOW = 100
+
+
+def dataset(tmp, polyA):
+    """Model + synthetic container; the test calls this with the same arguments."""
+    mean, sd = synth.model_values(K, seed=7, stdev=0.15)
+    mean = mean.copy()
+    mean[0] = polyA  # AAAAAAAAA
+    model = synth.write_model_values(os.path.join(tmp, "start.model"), K, mean, sd)
+    reads = synth.make_reads(SEED, BATCH * N_BATCHES, PORE, mean, sd, (120, 300))
+    raw, bam, _ = synth.write_dataset(tmp, "g8", reads, PORE, seed=SEED)
+    return model, mean, sd, raw, bam
+
+
+def write_model_like_reference(path, names, mean, sd):
+    # utils.py:136-153: f'{kmer}\t{mean}\t{stdev}\n' with numpy floats
+    with open(path, "w") as w:
+        w.write("kmer\tlevel_mean\tlevel_stdv\n")
+        for n, m, s in zip(names, mean, sd):
+            w.write(f"{n}\t{m}\t{s}\n")
+
+
+def run(polyA):
+    tmp = tempfile.mkdtemp(prefix="g8_")
+    model_path, mean0, sd0, _raw, bam = dataset(tmp, polyA)
+    names = synth.kmer_strings(K)
+    nk = 4 ** K
+    items = [it for it in read_items(tmp, bam, PORE, 0.0, raw=False) if not isinstance(it, str)]
+    assert len(items) == BATCH * N_BATCHES, len(items)
+    # collectors (train.py:104-106): one deque per parameter, initialised with the start value
+    win_mean = [deque([mean0.copy()], maxlen=WINDOW)]  # every k-mer gets the same sequence of adds -> one deque of vectors
+    win_sd = [deque([sd0.copy()], maxlen=WINDOW)]
+    trans = {"e1": deque([1.0], maxlen=WINDOW), "m1": deque([0.03], maxlen=WINDOW), "e2": deque([0.97], maxlen=WINDOW)}
+    cur_mean, cur_sd = mean0.copy(), sd0.copy()
+    cur_model = model_path
+    out, i = {}, 0
+    touched = set()  # k-mers whose parameters have moved since the start model (cumulative)
+    for cb in range(N_BATCHES):
+        batch = items[cb * BATCH:(cb + 1) * BATCH]
+        ref = Reference(cur_model, PORE_ID)
+        preZ, any_seen = [], False
+        for sig, seq, _rid in batch:
+            r = ref.train(np.asarray(sig, dtype=np.float64), seq, nk)  # pybind forcecast: float32 -> float64
+            i += 1
+            preZ.append(r["Z"])
+            for p in ("m1", "e1", "e2"):
+                trans[p].append(float(r[p]))
+            touched |= set(np.nonzero((r["mean"] != cur_mean) | (r["stdev"] != cur_sd))[0].tolist())
+            if r["mean"][0] < 0.5:  # 'AAAAAAAAA' in newModels and newModels['AAAAAAAAA'][0] < 0.5
+                continue
+            any_seen = True
+            win_mean[0].append(r["mean"])
+            win_sd[0].append(r["stdev"])
+        tp = {p: float(np.mean(trans[p])) for p in ("e1", "m1", "e2")}
+        if any_seen:  # `for kmer in kmers_seen: model[kmer] = [mean of window, ...]` -- dense results: all k-mers seen
+            # np.mean over the deque of ONE k-mer's scalars = a contiguous 1-D reduction (pairwise from 8 values
+            # on); reducing the last, contiguous axis of a (k-mers, window) array performs the same additions
+            cur_mean = np.ascontiguousarray(np.stack(list(win_mean[0])).T).mean(axis=1)
+            cur_sd = np.ascontiguousarray(np.stack(list(win_sd[0])).T).mean(axis=1)
+        cur_model = os.path.join(tmp, f"trained_0_{cb + 1}.model")
+        write_model_like_reference(cur_model, names, cur_mean, cur_sd)
+        ref2 = Reference(cur_model, PORE_ID)
+        postZ = [ref2.align(np.asarray(sig, dtype=np.float64), seq, False)["Z"] for sig, seq, _ in batch]
+        dZ = float(np.mean(np.array(postZ) - np.array(preZ)))
+        t = np.array(sorted(touched), dtype=np.int64)
+        out[f"b{cb}_reads"] = np.int64(i)
+        out[f"b{cb}_trans"] = np.array([tp["e1"], tp["m1"], tp["e2"]])
+        out[f"b{cb}_preZ"] = np.array(preZ)
+        out[f"b{cb}_dZ"] = np.float64(dZ)
+        out[f"b{cb}_codes"] = t
+        out[f"b{cb}_mean"] = cur_mean[t]
+        out[f"b{cb}_stdev"] = cur_sd[t]
+        out[f"b{cb}_untouched_max_dev"] = np.float64(np.abs(np.delete(cur_mean, t) - np.delete(mean0, t)).max())
+        out[f"b{cb}_params_row"] = np.array(f"0,{cb + 1},{i},{tp['e1']},{tp['m1']},{tp['e2']},{dZ}")
+    return out
+
+
+def main():
+    store = {"batch_size": np.int64(BATCH), "n_batches": np.int64(N_BATCHES), "seed": np.int64(SEED)}
+    for tag, polyA in (("a", 0.9), ("b", 0.2)):
+        for key, val in run(polyA).items():
+            store[f"{tag}_{key}"] = val
+        store[f"{tag}_polyA"] = np.float64(polyA)
+    np.savez_compressed(os.path.join(OUT, "g8_train_window_mean.npz"), **store)
+    for key in sorted(store):
+        v = store[key]
+        print(key, v if np.ndim(v) == 0 else (v.shape, v.dtype))
+
+
+if __name__ == "__main__":
+    main()
