@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <queue>
 #include <stdexcept>
 
 using dynhost::PoreModel;
@@ -660,6 +661,170 @@ void dyn_batch_destroy(dyn_batch* b) {
 
 namespace dyneng {
 
+// ---- queue planning for page-starved launches ---------------------------------------------------
+// The persistent waves take reads off the queue in order; a wave keeps its arena and exchanges pages with
+// the pool only when its next read needs more (it then waits with no pages until the pool can serve it)
+// or much less while somebody waits. Every wave sweeps rows at the same rate, so the whole launch can be
+// replayed on the host: simulate_queue returns the makespan in rows for a given queue order.
+static uint64_t simulate_queue(const std::vector<uint32_t>& need, const std::vector<uint64_t>& rows, size_t n_slots,
+                               uint64_t pool) {
+  const size_t n = need.size();
+  struct Ev { uint64_t t; uint32_t slot; bool operator>(const Ev& o) const { return t > o.t; } };
+  std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
+  struct Wait { uint32_t slot, need; size_t idx; };
+  std::vector<Wait> waiting;
+  std::vector<uint32_t> have(n_slots, 0);
+  uint64_t free_pages = pool, end = 0;
+  size_t head = 0;
+  auto serve = [&](uint64_t now) {
+    for (size_t i = 0; i < waiting.size();) {
+      if (free_pages >= waiting[i].need) {
+        free_pages -= waiting[i].need;
+        have[waiting[i].slot] = waiting[i].need;
+        events.push(Ev{now + rows[waiting[i].idx], waiting[i].slot});
+        waiting.erase(waiting.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+  };
+  bool reserving = true;
+  for (size_t s = 0; s < n_slots && s < n; ++s) {  // first round: pages reserved by the host while they last
+    head = s + 1;
+    if (reserving && free_pages >= need[s]) {
+      free_pages -= need[s];
+      have[s] = need[s];
+      events.push(Ev{rows[s], (uint32_t)s});
+    } else {
+      reserving = false;
+      waiting.push_back(Wait{(uint32_t)s, need[s], s});
+    }
+  }
+  while (!events.empty()) {
+    const Ev e = events.top();
+    events.pop();
+    end = std::max(end, e.t);
+    uint32_t& hv = have[e.slot];
+    if (head < n) {
+      const size_t idx = head++;
+      if (hv >= need[idx]) {
+        if (!waiting.empty() && hv - need[idx] >= 8 && 8 * (hv - need[idx]) >= hv) {
+          free_pages += hv - need[idx];
+          hv = need[idx];
+          serve(e.t);
+        }
+        events.push(Ev{e.t + rows[idx], e.slot});
+      } else {
+        free_pages += hv;
+        hv = 0;
+        waiting.push_back(Wait{e.slot, need[idx], idx});
+        serve(e.t);
+      }
+    } else {
+      free_pages += hv;
+      hv = 0;
+      serve(e.t);
+    }
+  }
+  return waiting.empty() ? end : ~0ull;  // a plan that strands a read is no plan
+}
+
+// `order` comes in longest first. When the pool cannot hold a lattice for every wave slot, longest-first
+// leaves the slots beyond the pool's capacity idle until the first long reads finish (config 3: 7.6 % of
+// all wave time, measured). Candidate plans give those slots BRIDGE reads -- shorter reads whose arenas fit
+// beside L long ones -- and start the displaced long reads when the first round's memory comes back:
+//   queue = [ L longest | bridge = ranks [first, last), longest first | everything else, longest first ]
+// The shortest quarter of the batch is never used as bridge (it keeps the launch's tail short). The plan
+// with the smallest simulated makespan wins; plain longest-first is one of the candidates.
+static void plan_queue(std::vector<uint32_t>& order, const std::vector<uint32_t>& need, const std::vector<uint64_t>& rows,
+                       size_t n_slots, uint64_t pool) {
+  const size_t n = order.size();
+  std::vector<uint64_t> pre(n + 1, 0), rpre(n + 1, 0);
+  for (size_t k = 0; k < n; ++k) {
+    pre[k + 1] = pre[k] + need[k];
+    rpre[k + 1] = rpre[k] + rows[k];
+  }
+  size_t L0 = 0;
+  while (L0 < n_slots && pre[L0 + 1] <= pool) ++L0;
+  if (L0 >= n_slots || L0 < 2) return;  // every slot gets its lattice (or nothing sensible to plan)
+  const size_t lo_rank = n - n / 4;
+  auto permute = [&](size_t L, size_t first, size_t last, std::vector<uint32_t>& nd, std::vector<uint64_t>& rw,
+                     std::vector<uint32_t>* ord) {
+    nd.clear();
+    rw.clear();
+    if (ord) ord->clear();
+    auto put = [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; ++k) {
+        nd.push_back(need[k]);
+        rw.push_back(rows[k]);
+        if (ord) ord->push_back(order[k]);
+      }
+    };
+    put(0, L);
+    put(first, last);
+    put(L, first);
+    put(last, n);
+  };
+  std::vector<uint32_t> nd;
+  std::vector<uint64_t> rw;
+  uint64_t best = simulate_queue(need, rows, n_slots, pool);
+  size_t bL = 0, bfirst = 0, blast = 0;
+  const size_t step = std::max<size_t>(1, n_slots / 32);
+  for (size_t L = L0; L + step > step && L >= n_slots / 4; L -= step) {
+    const uint64_t per_slot = (pool - pre[L]) / (n_slots - L);
+    size_t first = std::lower_bound(need.begin() + L, need.begin() + lo_rank, per_slot,
+                                    [](uint32_t a, uint64_t v) { return a > v; }) - need.begin();  // first rank that fits
+    if (lo_rank - first < n_slots - L) continue;
+    const uint64_t target = (uint64_t)(n_slots - L) * rows[L - 1];
+    for (int f = 2; f <= 6; ++f) {  // bridge rows = 0.5 .. 1.5 x "one long read per bridge slot"
+      size_t last = std::lower_bound(rpre.begin() + first, rpre.begin() + lo_rank, rpre[first] + target * f / 4) - rpre.begin();
+      last = std::min(std::max(last, first + (n_slots - L)), lo_rank);
+      permute(L, first, last, nd, rw, nullptr);
+      const uint64_t t = simulate_queue(nd, rw, n_slots, pool);
+      if (t < best) {
+        best = t;
+        bL = L;
+        bfirst = first;
+        blast = last;
+      }
+    }
+  }
+  if (bL) {
+    std::vector<uint32_t> planned;
+    permute(bL, bfirst, blast, nd, rw, &planned);
+    order.swap(planned);
+  }
+}
+
+}  // namespace dyneng
+
+extern "C" int dyn_plan_queue(uint64_t n_reads, const uint32_t* pages, const uint64_t* rows, uint64_t n_slots,
+                              uint64_t pool_pages, uint32_t* order_out, uint64_t* makespan_longest_first,
+                              uint64_t* makespan_planned) {
+  if (!pages || !rows || !order_out || !n_slots) return DYN_ERR_INVALID_ARGUMENT;
+  std::vector<uint32_t> need(pages, pages + n_reads), order(n_reads);
+  std::vector<uint64_t> rw(rows, rows + n_reads);
+  for (uint64_t k = 0; k < n_reads; ++k) {
+    order[k] = (uint32_t)k;
+    if (k && need[k] > need[k - 1]) return DYN_ERR_INVALID_ARGUMENT;  // longest first
+  }
+  if (makespan_longest_first) *makespan_longest_first = dyneng::simulate_queue(need, rw, n_slots, pool_pages);
+  if (n_reads > n_slots) dyneng::plan_queue(order, need, rw, n_slots, pool_pages);
+  if (makespan_planned) {
+    std::vector<uint32_t> nd(n_reads);
+    std::vector<uint64_t> r2(n_reads);
+    for (uint64_t k = 0; k < n_reads; ++k) {
+      nd[k] = need[order[k]];
+      r2[k] = rw[order[k]];
+    }
+    *makespan_planned = dyneng::simulate_queue(nd, r2, n_slots, pool_pages);
+  }
+  std::memcpy(order_out, order.data(), n_reads * sizeof(uint32_t));
+  return DYN_OK;
+}
+
+namespace dyneng {
+
 // Shared engine of align / train. Every ok read of the batch goes, longest first, into ONE launch of
 // persistent waves (k_read_queue): a wave runs a read's whole pipeline and then takes the next read
 // off the queue. The lattice of a read lives in pages of a pool that only has to hold the reads in
@@ -787,6 +952,17 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));
   pool.ctl = a->ctl.as<uint32_t>();
 
+  // Page-starved launches: the queue order is planned (plan_queue above).
+  if (lattice && order.size() > n_slots && !std::getenv("DYN_NO_BRIDGE")) {
+    std::vector<uint32_t> need(order.size());
+    std::vector<uint64_t> rows(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+      need[k] = pages_of(b->reads[order[k]].S);
+      rows[k] = b->reads[order[k]].S + 1;
+    }
+    plan_queue(order, need, rows, n_slots, pool.n_pages);
+  }
+
   // read descriptors in processing order; pages of the first round reserved here
   HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), order.size() * sizeof(ReadDesc))));
   ReadDesc* descs = b->h_descs.as<ReadDesc>();
@@ -814,7 +990,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
       used_pages += d.n_pages;
       n_static = (uint32_t)(k + 1);
     } else {
-      reserving = false;  // the queue is FIFO: later reads wait for pages on the device
+      reserving = false;  // later reads get their pages on the device
     }
     rows_total += d.T;
     max_N = std::max(max_N, d.N);

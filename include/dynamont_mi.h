@@ -253,6 +253,16 @@ int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, vo
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count);
 int dyn_batch_timing(const dyn_batch* b, dyn_timing* t);
 
+/* Planning diagnostic, needs no GPU. A batch runs as ONE launch of persistent waves that take reads off a
+ * queue; the lattice of a read lives in pages of a pool. When the pool cannot hold a lattice for every wave
+ * (long reads: BASELINE config 3), the engine plans the queue order by replaying the launch on the host. This
+ * entry exposes that planner: pages[i] / rows[i] = lattice pages and rows of read i, LONGEST FIRST; n_slots =
+ * persistent waves (4 per CU); pool_pages = pages in the pool. order_out[k] = index of the read at queue position k;
+ * the makespans are in lattice rows per wave (every wave sweeps rows at the same rate). */
+int dyn_plan_queue(uint64_t n_reads, const uint32_t* pages, const uint64_t* rows, uint64_t n_slots,
+                   uint64_t pool_pages, uint32_t* order_out, uint64_t* makespan_longest_first,
+                   uint64_t* makespan_planned);
+
 /* ---- asynchronous form: a stream of batches with H2D, kernels, D2H and host marshalling of
  * neighbouring batches overlapped (the reference keeps its worker pool permanently fed,
  * segment.py:301-325) ----

@@ -45,6 +45,13 @@ int64_t nto_debug_fb(const nto_model* m, const double* sig, uint64_t S, const ch
                      double* fE, double* bE, double* fM, double* bM, uint64_t cap, char* err,
                      uint64_t errcap);
 
+/* smallest |vM - vE| over the on-path traceback decisions of the last nto_align(calc=1) */
+double nto_last_decision_margin(void);
+/* the same over decisions between columns with different k-mers only (see nt_oracle.c) */
+double nto_last_decision_margin_distinct(void);
+/* row / column of the smallest margin and the two values compared there */
+void nto_last_decision_margin_at(uint64_t* t, uint64_t* n, double* vm, double* ve);
+
 double nto_log_normal_pdf(double x, double mean, double stdev);
 double nto_log_plus(double x, double y);
 

@@ -68,6 +68,9 @@ class Oracle(_Base):
         L.nto_log_normal_pdf.argtypes = [C.c_double] * 3
         L.nto_log_plus.restype = C.c_double
         L.nto_log_plus.argtypes = [C.c_double] * 2
+        L.nto_last_decision_margin.restype = C.c_double
+        L.nto_last_decision_margin_distinct.restype = C.c_double
+        L.nto_last_decision_margin_at.argtypes = [_u64p, _u64p, _dp, _dp]
         err = self._err()
         self.h = L.nto_model_load(model_path.encode(), pore, band, err, self.ERRCAP)
         if not self.h:
@@ -115,6 +118,20 @@ class Oracle(_Base):
             raise RuntimeError(err.value.decode())
         return dict(Z=Z.value, sequence_positions=sp[:n].copy(), signal_positions=gp[:n].copy(),
                     probabilities=pr[:n].copy(), states=[chr(c) for c in st.raw[:n]])
+
+    def last_decision_margin(self) -> float:
+        """Smallest |vM - vE| over the on-path traceback decisions of the last align(calc=True)."""
+        return float(self.lib.nto_last_decision_margin())
+
+    def last_decision_margin_distinct(self) -> float:
+        """The same over decisions between columns with different k-mers (structural ties excluded)."""
+        return float(self.lib.nto_last_decision_margin_distinct())
+
+    def last_decision_margin_at(self):
+        """(row, column, vM, vE) of the smallest margin of the last align(calc=True)."""
+        t, n, vm, ve = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_double()
+        self.lib.nto_last_decision_margin_at(C.byref(t), C.byref(n), C.byref(vm), C.byref(ve))
+        return t.value, n.value, vm.value, ve.value
 
     def train(self, signal, seq: str, dense: bool = True) -> dict:
         sig = np.ascontiguousarray(signal, dtype=np.float64)

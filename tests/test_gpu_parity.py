@@ -263,20 +263,39 @@ def test_in_place_posterior_layout_against_oracle(models, pore):
         assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
 
 
-def test_cfg2_full_size_properties_and_spot_parity(models, al9):
-    """BASELINE configs[1]: 1 024 RNA004 reads x ~20 k samples. Size-independent properties on
-    all reads, full parity against the oracle on three of them."""
-    _, mean, sd = synth.read_model_file(models["syn9"])
-    cfg = synth.CONFIGS["cfg2"]
-    reads = synth.make_reads(cfg["seed"], cfg["n_reads"], cfg["pore"], mean, sd, cfg["n_bases"])
-    sig, so, sq, qo = synth.pack_reads(reads)
-    with al9.batch_packed(sig, so, sq, qo) as b:
-        b.align(True)
-        res = b.fetch()
-        tm = b.timing()
+_ORC = None
+
+
+def _orc_init(model, pore_id):
+    global _ORC
+    _ORC = Oracle(model, pore_id)
+
+
+def _orc_align(job):
+    sig, seq = job
+    r = _ORC.align(sig, seq, True)
+    return r["Z"], r["signal_positions"], r["sequence_positions"], r["probabilities"]
+
+
+def _oracle_parity(model, pore_id, reads, res, picks, procs=16):
+    """Full parity of the reads `picks` against the oracle, run in a process pool (the oracle is
+    single-threaded and takes ~2 s per 20 k-sample read)."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(procs, len(picks), os.cpu_count() or 1), initializer=_orc_init,
+                                     initargs=(model, pore_id)) as pool:
+        want = pool.map(_orc_align, [(reads[i].signal, reads[i].sequence) for i in picks], chunksize=1)
+    for i, (Z, sigpos, seqpos, prob) in zip(picks, want):
+        got = res.read(i)
+        assert np.array_equal(got["signal_positions"], sigpos), i
+        assert np.array_equal(got["sequence_positions"], seqpos), i
+        assert np.abs(got["probabilities"] - prob).max() <= PROB_TIGHT, i
+        assert abs(got["Z"] - Z) <= 1e-9 * max(1.0, abs(Z)), i
+
+
+def _full_size_properties(reads, res, k):
+    """Size-independent properties of a segmentation: one segment per k-mer, starts strictly increasing by
+    at least the 2 rows a segment needs, first at 0, base positions 0..Kc-1 (+k/2), posteriors in [0, 1]."""
     assert (res.status == 0).all()
-    assert tm["samples"] == int(so[-1]) and tm["reads_ok"] == len(reads)
-    k = al9.kmer_size
     for i, r in enumerate(reads):
         a, n = int(res.seg_offsets[i]), int(res.n_segments[i])
         assert n == len(r.sequence) - k + 1
@@ -286,13 +305,72 @@ def test_cfg2_full_size_properties_and_spot_parity(models, al9):
         p = res.probabilities[a:a + n]
         assert np.all((p >= 0) & (p <= 1.0 + 1e-6))
     assert np.all(np.isfinite(res.Z))
-    orc = Oracle(models["syn9"], 1)
-    for i in (0, 511, 1023):
-        want = orc.align(reads[i].signal, reads[i].sequence, True)
-        got = res.read(i)
-        assert np.array_equal(got["signal_positions"], want["signal_positions"])
-        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
-        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+
+
+def test_cfg2_full_size_properties_and_parity_on_32_reads(models, al9):
+    """BASELINE configs[1]: 1 024 RNA004 reads x ~20 k samples. Size-independent properties on
+    all reads, full parity against the oracle on 32 of them (every 33rd read)."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    cfg = synth.CONFIGS["cfg2"]
+    reads = synth.make_reads(cfg["seed"], cfg["n_reads"], cfg["pore"], mean, sd, cfg["n_bases"])
+    sig, so, sq, qo = synth.pack_reads(reads)
+    with al9.batch_packed(sig, so, sq, qo) as b:
+        b.align(True)
+        res = b.fetch()
+        tm = b.timing()
+    assert tm["samples"] == int(so[-1]) and tm["reads_ok"] == len(reads)
+    assert tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == len(reads)
+    _full_size_properties(reads, res, al9.kmer_size)
+    # every 33rd read, and EVERY read of this workload in which the reference's traceback takes a decision on a
+    # structural tie (neighbouring columns with the same k-mer: margin 0 in exact arithmetic, 0 .. 1e-8 in the
+    # reference's floating point; tests/decision_margin.py -> tests/golden/g9_cfg2_decision_margin.json). Decisions
+    # between different k-mers have a margin >= 1e-6 over all 20.4 M decisions of the workload.
+    g9 = json.load(open(os.path.join(GOLDEN, "g9_cfg2_decision_margin.json")))
+    assert g9["distinct_kmer_decisions"]["min"] >= 1e-9
+    ties = [t["read"] for t in g9["structural_tie_reads"]]
+    _oracle_parity(models["syn9"], 1, reads, res, sorted(set(list(range(0, 1024, 33)) + [1023] + ties)))
+
+
+def test_cfg4_share_full_size(models, al9):
+    """BASELINE configs[3]'s per-GPU share: 4 096 RNA004 reads x ~20 k samples in ONE batch -- four rounds of
+    the persistent waves, every read past the first 1 024 taken off the queue on the device."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    cfg = synth.CONFIGS["cfg4"]
+    reads = synth.make_reads(cfg["seed"], 4096, cfg["pore"], mean, sd, cfg["n_bases"])
+    sig, so, sq, qo = synth.pack_reads(reads)
+    with al9.batch_packed(sig, so, sq, qo) as b:
+        b.align(True)
+        res = b.fetch()
+        tm = b.timing()
+    assert tm["reads_ok"] == 4096 and tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == 1024
+    _full_size_properties(reads, res, al9.kmer_size)
+    # reads of the first round (longest), of the middle of the queue and of its tail (shortest)
+    order = np.argsort([-len(r.signal) for r in reads], kind="stable")
+    _oracle_parity(models["syn9"], 1, reads, res, [int(order[j]) for j in (0, 1023, 1024, 2500, 4000, 4095)])
+
+
+def test_cfg3_full_size(models):
+    """BASELINE configs[2]: 4 096 DNA r10.4.1 reads of 10 k - 100 k samples in ONE batch: the pool cannot hold a
+    lattice for every wave, so part of the waves start without pages and wait for surplus pages of others."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    cfg = synth.CONFIGS["cfg3"]
+    reads = synth.make_reads(cfg["seed"], cfg["n_reads"], cfg["pore"], mean, sd, cfg["n_bases"])
+    sig, so, sq, qo = synth.pack_reads(reads)
+    al = Aligner(models["syn9"], cfg["pore"], device=0)
+    with al.batch_packed(sig, so, sq, qo) as b:
+        b.align(True)
+        res = b.fetch()
+        tm = b.timing()
+    assert tm["reads_ok"] == 4096 and tm["launches"] == 1 and tm["samples"] == int(so[-1])
+    # page-limited: the pool is smaller than 1 024 lattices of the longest reads, so part of the first round runs
+    # short reads (host plan) and later reads change arena size on the device
+    assert tm["lp_inplace"] == 1 and 0 < tm["n_static"] <= 1024
+    _full_size_properties(reads, res, al.kmer_size)
+    order = np.argsort([-len(r.signal) for r in reads], kind="stable")
+    # the longest read, reads from the long and the short end of the first round, a mid-queue read, the shortest
+    _oracle_parity(models["syn9"], synth.PORES[cfg["pore"]][0], reads, res,
+                   [int(order[j]) for j in (0, 700, 2048, 4000, 4095)], procs=5)
+    al.close()
 
 
 def test_g7_train_against_reference_golden(models):
