@@ -299,12 +299,14 @@ def main():
         traffic = load_traffic() or {}
         if args.mode == "train":
             kname = "k_read_queue<JOB_TRAIN> (per read: backward sweep, forward sweep + Baum-Welch statistics)"
-            bpc_f, tkey = KTRAIN_BYTES_PER_CELL, "k_read_queue_train_bytes_per_launch"
+            bpc_f, tkey = KTRAIN_BYTES_PER_CELL, "train"
         else:
             kname = "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else "")
-            bpc_f, tkey = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "k_read_queue_align_bytes_per_launch"
+            bpc_f, tkey = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "align"
         bpc = KBWD_BYTES_PER_CELL + bpc_f
-        tbytes = traffic.get(tkey) if (workload == traffic.get("workload") and not args.reads and not inplace) else None
+        # PMC traffic is only quoted for the workload (and layout) it was measured on
+        tinfo = traffic.get(tkey) or {}
+        tbytes = tinfo.get("bytes_per_launch") if (workload == tinfo.get("workload") and not args.reads and not inplace) else None
         achieved = cells_per_launch * bpc / (ms_dp * 1e-3) / 1e9 if ms_dp else 0.0
         share = lambda key: kern[key] / kern["ms_dp"] if kern["ms_dp"] else 0.0
         roofline = {
@@ -312,6 +314,7 @@ def main():
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": tbytes,
+            "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
             "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": n_launch,
             "avg_launch_ms": round(ms_dp, 3),
             # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
