@@ -558,3 +558,57 @@ class Aligner:
         """aligner_bindings.cpp:149-163"""
         mean, sd = self.model_table()
         return self.train_batch([signal], [sequence]).read(0, mean, sd)
+
+
+class MultiAligner:
+    """dyn_multi_*: one handle driving several GPUs of a node from ONE process. Reads of a batch are cut into
+    contiguous ranges of equal lattice work, one per device; results come back in the layout of a single-device
+    batch. ``devices``: HIP ordinals (an ordinal may repeat, e.g. ``[0, 0]`` = two pipelines on one GPU)."""
+
+    def __init__(self, model_file: str, pore, devices: Sequence[int], mode: str = "basic", threads: int = 1, band: int = 400):
+        if isinstance(pore, str):
+            pore = pore_type(pore)
+        self._L = N.lib()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        err = C.create_string_buffer(ERRCAP)
+        rc = self._L.dyn_multi_create(str(model_file).encode(), int(pore), str(mode).encode(), int(threads), int(band), ids,
+                                      len(devices), C.byref(h), err, ERRCAP)
+        if rc != N.DYN_OK:
+            _raise(rc, err.value.decode())
+        self._h = h
+        info = N.DynInfo()
+        self._L.dyn_aligner_info(self._L.dyn_multi_handle(h, 0), C.byref(info))
+        self.kmer_size, self.num_kmers, self.n_devices = int(info.kmer_size), int(info.num_kmers), len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dyn_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def last_error(self) -> str:
+        return (self._L.dyn_multi_last_error(self._h) or b"").decode(errors="replace")
+
+    def _cap(self, seq_off) -> int:
+        return int(self._L.dyn_segment_capacity(self._L.dyn_multi_handle(self._h, 0), len(seq_off) - 1, _ptr(seq_off, N.c_u64_p)))
+
+    def align_batch(self, signals: Sequence, sequences: Sequence[str], calc_probabilities: bool = True) -> AlignBatchResult:
+        sig, sig_off, seqs, seq_off = _pack(signals, sequences)
+        out = AlignBatchResult(len(sequences), self._cap(seq_off))
+        rc = self._L.dyn_multi_align_batch(self._h, out.n, _ptr(sig, N.c_double_p), _ptr(sig_off, N.c_u64_p), seqs,
+                                           _ptr(seq_off, N.c_u64_p), int(bool(calc_probabilities)), C.byref(out._c))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return out
+
+    def train_batch(self, signals: Sequence, sequences: Sequence[str], pooled: bool = False) -> TrainBatchResult:
+        sig, sig_off, seqs, seq_off = _pack(signals, sequences)
+        out = TrainBatchResult(len(sequences), self._cap(seq_off), self.num_kmers, pooled)
+        rc = self._L.dyn_multi_train_batch(self._h, out.n, _ptr(sig, N.c_double_p), _ptr(sig_off, N.c_u64_p), seqs,
+                                           _ptr(seq_off, N.c_u64_p), C.byref(out._c),
+                                           _ptr(out.pooled, N.c_double_p) if pooled else None)
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return out

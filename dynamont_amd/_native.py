@@ -97,6 +97,16 @@ SIGNATURES = {
     "dyn_batch_wait": (C.c_int, [C.c_void_p]),
     "dyn_host_alloc": (C.c_void_p, [C.c_uint64]),
     "dyn_host_free": (None, [C.c_void_p]),
+    "dyn_multi_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.c_int,
+                                   C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
+    "dyn_multi_destroy": (None, [C.c_void_p]),
+    "dyn_multi_device_count": (C.c_int, [C.c_void_p]),
+    "dyn_multi_handle": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dyn_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "dyn_multi_align_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p, C.c_int,
+                                        C.POINTER(DynAlignOut)]),
+    "dyn_multi_train_batch": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
+                                        C.POINTER(DynTrainOut), c_double_p]),
 }
 
 

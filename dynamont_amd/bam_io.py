@@ -13,6 +13,8 @@ import gzip
 import struct
 import zlib
 
+import numpy as np
+
 from dynamont_amd.pod5_io import BasecallRecord
 
 _SEQ_DECODE = "=ACMGRSVTWYHKDBN"
@@ -24,7 +26,10 @@ def _parse_sam_tag(field: str):
     if typ == "i":
         return tag, int(val)
     if typ == "f":
-        return tag, float(val)
+        # a SAM `f` tag is a single-precision value (SAM spec 1.5): pysam and the BAM form of the same record yield
+        # the float32-rounded number, so must this (sm/sd feed the normalisation: a double here would change the
+        # low-order bits of every sample compared with the .bam of the same run)
+        return tag, float(np.float32(val))
     return tag, val  # Z, A, H, B kept as text
 
 
@@ -41,63 +46,88 @@ def iter_sam(path: str):
             yield BasecallRecord(p[0], p[9], tags)
 
 
-def _bgzf_bytes(path: str) -> bytes:
-    # BGZF is a series of gzip members; Python's gzip module reads multi-member files
-    with gzip.open(path, "rb") as f:
-        return f.read()
+class _Stream:
+    """Bounded-memory reader over the inflated BGZF stream (a series of gzip members, which Python's gzip module
+    reads as one stream): a multi-GB dorado BAM is never held in memory, and the first record is available after
+    the first block."""
+
+    def __init__(self, path: str):
+        self.f = gzip.open(path, "rb")
+
+    def take(self, n: int) -> bytes:
+        out = self.f.read(n)
+        while len(out) < n:
+            more = self.f.read(n - len(out))
+            if not more:
+                break
+            out += more
+        return out
+
+    def close(self):
+        self.f.close()
 
 
 def iter_bam(path: str):
-    """Records of a BAM file (SAM spec §4): name, sequence and tags of every alignment record."""
-    data = _bgzf_bytes(path)
-    if data[:4] != b"BAM\x01":
-        raise ValueError(f"{path}: not a BAM file")
-    l_text, = struct.unpack_from("<i", data, 4)
-    pos = 8 + l_text
-    n_ref, = struct.unpack_from("<i", data, pos)
-    pos += 4
-    for _ in range(n_ref):
-        l_name, = struct.unpack_from("<i", data, pos)
-        pos += 4 + l_name + 4
-    n = len(data)
-    while pos + 4 <= n:
-        block_size, = struct.unpack_from("<i", data, pos)
-        pos += 4
-        end = pos + block_size
-        (_ref, _p, l_read_name, _mapq, _bin, n_cigar, _flag, l_seq, _nref, _npos, _tlen) = struct.unpack_from("<iiBBHHHiiii", data, pos)
-        q = pos + 32
-        name = data[q:q + l_read_name - 1].decode()
-        q += l_read_name + 4 * n_cigar
-        nb = (l_seq + 1) // 2
-        packed = data[q:q + nb]
-        seq = "".join(_SEQ_DECODE[b >> 4] + _SEQ_DECODE[b & 15] for b in packed)[:l_seq]
-        q += nb + l_seq
-        tags = {}
-        while q < end:
-            tag = data[q:q + 2].decode()
-            typ = chr(data[q + 2])
-            q += 3
-            if typ in _TAG_FMT:
-                fmt = _TAG_FMT[typ]
-                tags[tag], = struct.unpack_from(fmt, data, q)
-                q += struct.calcsize(fmt)
-            elif typ == "A":
-                tags[tag] = chr(data[q])
-                q += 1
-            elif typ in "ZH":
-                e = data.index(b"\0", q)
-                tags[tag] = data[q:e].decode()
-                q = e + 1
-            elif typ == "B":
-                sub = chr(data[q])
-                cnt, = struct.unpack_from("<i", data, q + 1)
-                size = struct.calcsize(_TAG_FMT[sub])
-                tags[tag] = list(struct.unpack_from("<" + _TAG_FMT[sub][1] * cnt, data, q + 5))
-                q += 5 + size * cnt
-            else:
-                raise ValueError(f"{path}: unknown BAM tag type {typ!r}")
-        pos = end
-        yield BasecallRecord(name, seq, tags)
+    """Records of a BAM file (SAM spec §4): name, sequence and tags of every alignment record, streamed."""
+    st = _Stream(path)
+    try:
+        head = st.take(8)
+        if head[:4] != b"BAM\x01":
+            raise ValueError(f"{path}: not a BAM file")
+        l_text, = struct.unpack_from("<i", head, 4)
+        st.take(l_text)
+        n_ref, = struct.unpack("<i", st.take(4))
+        for _ in range(n_ref):
+            l_name, = struct.unpack("<i", st.take(4))
+            st.take(l_name + 4)
+        while True:
+            hdr = st.take(4)
+            if len(hdr) < 4:
+                break
+            block_size, = struct.unpack("<i", hdr)
+            data = st.take(block_size)
+            if len(data) < block_size:
+                raise ValueError(f"{path}: truncated BAM record")
+            yield _parse_bam_record(path, data)
+    finally:
+        st.close()
+
+
+def _parse_bam_record(path: str, data: bytes):
+    pos, end = 0, len(data)
+    (_ref, _p, l_read_name, _mapq, _bin, n_cigar, _flag, l_seq, _nref, _npos, _tlen) = struct.unpack_from("<iiBBHHHiiii", data, pos)
+    q = pos + 32
+    name = data[q:q + l_read_name - 1].decode()
+    q += l_read_name + 4 * n_cigar
+    nb = (l_seq + 1) // 2
+    packed = data[q:q + nb]
+    seq = "".join(_SEQ_DECODE[b >> 4] + _SEQ_DECODE[b & 15] for b in packed)[:l_seq]
+    q += nb + l_seq
+    tags = {}
+    while q < end:
+        tag = data[q:q + 2].decode()
+        typ = chr(data[q + 2])
+        q += 3
+        if typ in _TAG_FMT:
+            fmt = _TAG_FMT[typ]
+            tags[tag], = struct.unpack_from(fmt, data, q)
+            q += struct.calcsize(fmt)
+        elif typ == "A":
+            tags[tag] = chr(data[q])
+            q += 1
+        elif typ in "ZH":
+            e = data.index(b"\0", q)
+            tags[tag] = data[q:e].decode()
+            q = e + 1
+        elif typ == "B":
+            sub = chr(data[q])
+            cnt, = struct.unpack_from("<i", data, q + 1)
+            size = struct.calcsize(_TAG_FMT[sub])
+            tags[tag] = list(struct.unpack_from("<" + _TAG_FMT[sub][1] * cnt, data, q + 5))
+            q += 5 + size * cnt
+        else:
+            raise ValueError(f"{path}: unknown BAM tag type {typ!r}")
+    return BasecallRecord(name, seq, tags)
 
 
 def _sam_tag_text(tag, value):

@@ -293,3 +293,187 @@ int dyn_batch_wait(dyn_batch* b) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Several GPUs behind ONE handle ("one handle may drive 1-8 GPUs"). Reads are
+// independent (NTAligner::align keeps no cross-read state, NT_aligner_api.cpp:230-312), so a batch is
+// cut into n_devices contiguous ranges of equal lattice work (sum of signal lengths); every range goes
+// through its own device's asynchronous pipeline and writes straight into the caller's arrays. No
+// device-to-device traffic: a C/C++ consumer of the library needs neither Python nor RCCL to shard.
+// ---------------------------------------------------------------------------------------------
+struct dyn_multi {
+  std::vector<dyn_aligner*> dev;
+  std::string last_error;
+};
+
+namespace {
+
+// cut points: range d = [cut[d], cut[d+1])
+std::vector<uint64_t> split_by_work(uint64_t n, const uint64_t* sig_offsets, size_t parts) {
+  std::vector<uint64_t> cut(parts + 1, n);
+  cut[0] = 0;
+  const uint64_t total = n ? sig_offsets[n] - sig_offsets[0] : 0;
+  uint64_t i = 0;
+  for (size_t d = 1; d < parts; ++d) {
+    const uint64_t want = sig_offsets[0] + total * d / parts;
+    while (i < n && sig_offsets[i] < want) ++i;
+    cut[d] = i;
+  }
+  return cut;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dyn_multi_create(const char* model_path, int pore, const char* mode, int threads, uint64_t band,
+                     const int* device_ids, int n_devices, dyn_multi** out, char* err, uint64_t errcap) {
+  if (!out || !device_ids || n_devices < 1) return DYN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  dyn_multi* m = new dyn_multi();
+  for (int d = 0; d < n_devices; ++d) {
+    dyn_aligner* a = nullptr;
+    const int rc = dyn_aligner_create(model_path, pore, mode, threads, band, device_ids[d], &a, err, errcap);
+    if (rc != DYN_OK) {
+      for (dyn_aligner* x : m->dev) dyn_aligner_destroy(x);
+      delete m;
+      return rc;
+    }
+    m->dev.push_back(a);
+  }
+  *out = m;
+  return DYN_OK;
+}
+
+void dyn_multi_destroy(dyn_multi* m) {
+  if (!m) return;
+  for (dyn_aligner* a : m->dev) dyn_aligner_destroy(a);
+  delete m;
+}
+
+int dyn_multi_device_count(const dyn_multi* m) { return m ? (int)m->dev.size() : 0; }
+
+dyn_aligner* dyn_multi_handle(dyn_multi* m, int i) {
+  return (m && i >= 0 && i < (int)m->dev.size()) ? m->dev[i] : nullptr;
+}
+
+const char* dyn_multi_last_error(const dyn_multi* m) { return m ? m->last_error.c_str() : ""; }
+
+int dyn_multi_align_batch(dyn_multi* m, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
+                          const char* seqs, const uint64_t* seq_offsets, int calc_probabilities, dyn_align_out* out) {
+  if (!m || !out || !out->Z || !out->status || !sig_offsets || !seq_offsets) return DYN_ERR_INVALID_ARGUMENT;
+  const size_t nd = m->dev.size();
+  const int k = m->dev[0]->model.k;
+  // segment offsets of every read in the caller's arrays (prefix sums of max(0, len - k + 1))
+  std::vector<uint64_t> seg(n_reads + 1, 0);
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    const uint64_t L = seq_offsets[i + 1] - seq_offsets[i];
+    seg[i + 1] = seg[i] + (L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0);
+  }
+  const bool want_rows = calc_probabilities && (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
+  if (want_rows && out->capacity < seg[n_reads]) {
+    m->last_error = "dyn_align_out.capacity is smaller than dyn_segment_capacity()";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  const std::vector<uint64_t> cut = split_by_work(n_reads, sig_offsets, nd);
+  std::vector<dyn_align_out> sub(nd);
+  std::vector<dyn_batch*> ticket(nd, nullptr);
+  int rc = DYN_OK;
+  for (size_t d = 0; d < nd; ++d) {
+    const uint64_t lo = cut[d], hi = cut[d + 1], sb = seg[lo];
+    dyn_align_out& o = sub[d];
+    o = *out;
+    o.Z += lo;
+    o.status += lo;
+    if (o.bad_char) o.bad_char += lo;
+    o.seg_offsets = nullptr;  // rebuilt below: neighbouring ranges would both write the entry at their common border
+    if (o.n_segments) o.n_segments += lo;
+    if (o.sequence_positions) o.sequence_positions += sb;
+    if (o.signal_positions) o.signal_positions += sb;
+    if (o.probabilities) o.probabilities += sb;
+    if (o.states) o.states += sb;
+    o.capacity = seg[hi] - sb;
+    const int r = dyn_batch_align_async(m->dev[d], hi - lo, signals, sig_offsets + lo, seqs, seq_offsets + lo,
+                                        calc_probabilities, &o, &ticket[d]);
+    if (r != DYN_OK) {
+      rc = r;
+      m->last_error = dyn_aligner_last_error(m->dev[d]);
+    }
+  }
+  for (size_t d = 0; d < nd; ++d) {
+    if (!ticket[d]) continue;
+    const int r = dyn_batch_wait(ticket[d]);
+    if (r != DYN_OK && rc == DYN_OK) {
+      rc = r;
+      m->last_error = dyn_aligner_last_error(m->dev[d]);
+    }
+    dyn_batch_destroy(ticket[d]);
+  }
+  if (out->seg_offsets) std::memcpy(out->seg_offsets, seg.data(), (n_reads + 1) * sizeof(uint64_t));
+  return rc;
+}
+
+int dyn_multi_train_batch(dyn_multi* m, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
+                          const char* seqs, const uint64_t* seq_offsets, dyn_train_out* out, double* pooled3n) {
+  if (!m || !out || !out->Z || !out->status || !sig_offsets || !seq_offsets) return DYN_ERR_INVALID_ARGUMENT;
+  const size_t nd = m->dev.size();
+  const int k = m->dev[0]->model.k;
+  const uint64_t K = m->dev[0]->model.num_kmers;
+  std::vector<uint64_t> seg(n_reads + 1, 0);
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    const uint64_t L = seq_offsets[i + 1] - seq_offsets[i];
+    seg[i + 1] = seg[i] + (L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0);
+  }
+  const bool want_em = out->em_code && out->em_mean && out->em_stdev;
+  if (want_em && out->capacity < seg[n_reads]) {
+    m->last_error = "dyn_train_out.capacity is smaller than dyn_segment_capacity()";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  const std::vector<uint64_t> cut = split_by_work(n_reads, sig_offsets, nd);
+  std::vector<dyn_train_out> sub(nd);
+  std::vector<dyn_batch*> ticket(nd, nullptr);
+  // every device sums into its own pooled array (the back threads run concurrently); added up at the end
+  std::vector<std::vector<double>> pooled(pooled3n ? nd : 0, std::vector<double>(pooled3n ? 3 * K : 0, 0.0));
+  int rc = DYN_OK;
+  for (size_t d = 0; d < nd; ++d) {
+    const uint64_t lo = cut[d], hi = cut[d + 1], sb = seg[lo];
+    dyn_train_out& o = sub[d];
+    o = *out;
+    o.Z += lo;
+    o.status += lo;
+    if (o.bad_char) o.bad_char += lo;
+    if (o.transitions) o.transitions += 3 * lo;
+    o.em_offsets = nullptr;
+    if (o.em_count) o.em_count += lo;
+    if (o.em_code) o.em_code += sb;
+    if (o.em_mean) o.em_mean += sb;
+    if (o.em_stdev) o.em_stdev += sb;
+    if (o.em_weight) o.em_weight += sb;
+    if (o.em_sum) o.em_sum += sb;
+    if (o.em_sumsq) o.em_sumsq += sb;
+    if (o.trans_counts) o.trans_counts += 2 * lo;
+    o.capacity = seg[hi] - sb;
+    const int r = dyn_batch_train_async(m->dev[d], hi - lo, signals, sig_offsets + lo, seqs, seq_offsets + lo, &o,
+                                        pooled3n ? pooled[d].data() : nullptr, &ticket[d]);
+    if (r != DYN_OK) {
+      rc = r;
+      m->last_error = dyn_aligner_last_error(m->dev[d]);
+    }
+  }
+  for (size_t d = 0; d < nd; ++d) {
+    if (!ticket[d]) continue;
+    const int r = dyn_batch_wait(ticket[d]);
+    if (r != DYN_OK && rc == DYN_OK) {
+      rc = r;
+      m->last_error = dyn_aligner_last_error(m->dev[d]);
+    }
+    dyn_batch_destroy(ticket[d]);
+  }
+  if (out->em_offsets) std::memcpy(out->em_offsets, seg.data(), (n_reads + 1) * sizeof(uint64_t));
+  if (pooled3n)
+    for (size_t d = 0; d < nd; ++d)
+      for (uint64_t j = 0; j < 3 * K; ++j) pooled3n[j] += pooled[d][j];
+  return rc;
+}
+
+}  // extern "C"

@@ -1091,8 +1091,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
 // ---------------------------------------------------------------------------------------------
 // K_median: formattedMedian (aligner.cpp:247-263) by rank counting. One thread per path row;
 // the segment of column n spans rows [segrow[n-1], segrow[n]) (last column: up to T-1).
-// Ties are broken by row so ranks are a permutation.
+// Ties are broken by row so ranks are a permutation. Rank counting costs L compares per row, L^2 per
+// segment: fine for the usual dwell of ~10 rows, not for a stall (a pore that sits on one k-mer for
+// 20 000 samples would cost 4e8 compares); segments longer than MEDIAN_SHORT_MAX rows are left to
+// k_median_long.
 // ---------------------------------------------------------------------------------------------
+constexpr int MEDIAN_SHORT_MAX = 256;
+
 __global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
                          TraceBuffers tb) {
   const ReadDesc rd = descs[blockIdx.y];
@@ -1106,6 +1111,7 @@ __global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __
   const int a = (int)segrow[n - 1];
   const int b = (n < N - 1) ? (int)segrow[n] : T;
   const int L = b - a;
+  if (L > MEDIAN_SHORT_MAX) return;
   const double x = pp[t];
   int rank = 0;
   for (int u = a; u < b; ++u) {
@@ -1115,6 +1121,89 @@ __global__ void k_median(const ReadDesc* __restrict__ descs, const ReadState* __
   const int mid = L >> 1;
   if (rank == mid) tb.med_hi[rd.seg_off + n - 1] = x;
   if (!(L & 1) && rank == mid - 1) tb.med_lo[rd.seg_off + n - 1] = x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_median_long: the same two order statistics for segments longer than MEDIAN_SHORT_MAX rows, by an
+// 8-bit-per-pass radix select over the bit patterns (posteriors are non-negative doubles: value order =
+// unsigned order of the bits): 8 passes + 1 over the segment, O(L) instead of O(L^2). One 256-thread
+// block per read; reads without a long segment leave after one strided look at their segment table.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_median_long(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
+                                                     TraceBuffers tb) {
+  __shared__ uint32_t s_hist[256];
+  __shared__ unsigned long long s_prefix, s_maxless;
+  __shared__ uint32_t s_k, s_cntless;
+  const ReadDesc rd = descs[blockIdx.x];
+  if (st[rd.read].status != 0) return;
+  const int T = (int)rd.T, N = (int)rd.N;
+  const int tid = threadIdx.x;
+  const double* __restrict__ pp = tb.pp + rd.path_off;
+  const uint32_t* __restrict__ segrow = tb.segrow + rd.seg_off;
+  int any = 0;
+  for (int i = tid; i < N - 1; i += 256) {
+    const int a = (int)segrow[i], b = (i + 1 < N - 1) ? (int)segrow[i + 1] : T;
+    any |= (b - a > MEDIAN_SHORT_MAX);
+  }
+  if (!__syncthreads_or(any)) return;
+  for (int i = 0; i < N - 1; ++i) {  // block-uniform walk over the segments of this read
+    const int a = (int)segrow[i], b = (i + 1 < N - 1) ? (int)segrow[i + 1] : T;
+    const int L = b - a;
+    if (L <= MEDIAN_SHORT_MAX) continue;
+    unsigned long long prefix = 0, mask = 0;
+    uint32_t k = (uint32_t)(L >> 1);  // rank of the upper middle element
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      s_hist[tid] = 0;
+      __syncthreads();
+      for (int u = a + tid; u < b; u += 256) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(pp[u]);
+        if ((bits & mask) == prefix) atomicAdd(&s_hist[(bits >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, bin = 0;
+        for (; bin < 255; ++bin) {
+          if (k < cum + s_hist[bin]) break;
+          cum += s_hist[bin];
+        }
+        s_k = k - cum;
+        s_prefix = prefix | ((unsigned long long)bin << shift);
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      k = s_k;
+      mask |= 0xffull << shift;
+    }
+    const double hi = __longlong_as_double((long long)prefix);
+    double lo = hi;
+    if (!(L & 1)) {  // rank mid-1: another copy of hi, or the largest element below it
+      if (tid == 0) {
+        s_cntless = 0;
+        s_maxless = 0;
+      }
+      __syncthreads();
+      uint32_t cnt = 0;
+      unsigned long long mx = 0;
+      for (int u = a + tid; u < b; u += 256) {
+        const double y = pp[u];
+        if (y < hi) {
+          ++cnt;
+          mx = max(mx, (unsigned long long)__double_as_longlong(y));
+        }
+      }
+      if (cnt) {
+        atomicAdd(&s_cntless, cnt);
+        atomicMax(&s_maxless, mx);
+      }
+      __syncthreads();
+      if ((uint32_t)(L >> 1) - 1u < s_cntless) lo = __longlong_as_double((long long)s_maxless);
+      __syncthreads();
+    }
+    if (tid == 0) {
+      tb.med_hi[rd.seg_off + i] = hi;
+      tb.med_lo[rd.seg_off + i] = lo;
+    }
+  }
 }
 
 // K_final: one output row per segment (NT_aligner_api.cpp:420-430).
@@ -1291,6 +1380,7 @@ void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_
   for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {
     const int nr = std::min(MAX_GRID_Y, n_reads - r0);
     hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb);
+    hipLaunchKernelGGL(k_median_long, dim3(nr), dim3(256), 0, s, descs + r0, st, tb);
     hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb, rows, kmer_size);
   }
 }

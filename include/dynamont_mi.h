@@ -70,6 +70,7 @@ enum dyn_read_status {
 
 typedef struct dyn_aligner dyn_aligner;
 typedef struct dyn_batch dyn_batch;
+typedef struct dyn_multi dyn_multi;
 
 typedef struct dyn_info {
   int32_t abi_version;
@@ -288,6 +289,26 @@ int dyn_batch_wait(dyn_batch* ticket);
 /* Page-locked host memory for inputs/outputs of the asynchronous calls (NULL on failure). */
 void* dyn_host_alloc(uint64_t bytes);
 void dyn_host_free(void* p);
+
+/* ---- several GPUs behind one handle (reads are independent, NT_aligner_api.cpp:230-312) ----
+ *
+ * dyn_multi owns one dyn_aligner per entry of device_ids (an ordinal may appear more than once). A batch is cut
+ * into n_devices contiguous ranges of equal lattice work (sum of signal lengths); every range runs through its
+ * device's asynchronous pipeline and the results land directly in the caller's arrays, in the layout of
+ * dyn_align_batch / dyn_train_batch. No device-to-device traffic and no Python: this is how a C/C++ host shards
+ * a batch over the GPUs of a node (one PROCESS per GPU with an RCCL gather is the other form: bench.py --gpus N). */
+int dyn_multi_create(const char* model_path, int pore, const char* mode, int threads, uint64_t band,
+                     const int* device_ids, int n_devices, dyn_multi** out, char* err, uint64_t errcap);
+void dyn_multi_destroy(dyn_multi* m);
+int dyn_multi_device_count(const dyn_multi* m);
+/* the per-device handle (dyn_aligner_info, dyn_aligner_model, dyn_aligner_set_mem_budget, ...) */
+dyn_aligner* dyn_multi_handle(dyn_multi* m, int i);
+const char* dyn_multi_last_error(const dyn_multi* m);
+int dyn_multi_align_batch(dyn_multi* m, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
+                          const char* seqs, const uint64_t* seq_offsets, int calc_probabilities, dyn_align_out* out);
+/* pooled3n as in dyn_train_batch: the sum over all devices is ADDED to it */
+int dyn_multi_train_batch(dyn_multi* m, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
+                          const char* seqs, const uint64_t* seq_offsets, dyn_train_out* out, double* pooled3n);
 
 #ifdef __cplusplus
 }

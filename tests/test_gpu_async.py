@@ -124,3 +124,36 @@ def test_train_async_equals_train(models):
         assert np.array_equal(lean.Z, want.Z) and np.array_equal(lean.trans_counts, want.trans_counts)
         t.close()
     al.close()
+
+
+def test_multi_device_handle_equals_single_device(models):
+    """dyn_multi_*: one handle, several devices (here the same GPU twice and three times): the batch is cut into
+    contiguous ranges, each through its own pipeline, results written straight into one set of caller arrays --
+    bitwise what a single handle returns, failed reads included, whatever the number of ranges."""
+    from dynamont_amd import MultiAligner
+    al = Aligner(models["syn9"], "rna004", device=0)
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(4242, 37, "rna004", mean, sd, (60, 500))
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    seqs[5] = "ACGT"                                  # Sequence shorter than model kmer size: no segment rows at all
+    seqs[20] = seqs[20][:30] + "N" + seqs[20][31:]    # Invalid nucleotide
+    want = al.align_batch(sigs, seqs, True)
+    wt = al.train_batch(sigs, seqs, pooled=True)
+    for devs in ([0, 0], [0, 0, 0], [0]):
+        m = MultiAligner(models["syn9"], "rna004", devs)
+        assert m.n_devices == len(devs)
+        _same(m.align_batch(sigs, seqs, True), want)
+        z = m.align_batch(sigs, seqs, False)
+        assert np.array_equal(z.status, want.status) and int(z.n_segments.sum()) == 0
+        tr = m.train_batch(sigs, seqs, pooled=True)
+        assert np.array_equal(tr.status, wt.status) and np.array_equal(tr.Z, wt.Z)
+        assert np.array_equal(tr.transitions, wt.transitions) and np.array_equal(tr.em_count, wt.em_count)
+        assert np.array_equal(tr.em_offsets, wt.em_offsets)
+        for i in range(len(reads)):
+            a, n = int(tr.em_offsets[i]), int(tr.em_count[i])
+            assert np.array_equal(tr.em_code[a:a + n], wt.em_code[a:a + n]) and np.array_equal(tr.em_mean[a:a + n], wt.em_mean[a:a + n])
+        assert np.allclose(tr.pooled, wt.pooled, rtol=1e-13, atol=1e-13)   # summed per range, then over ranges
+        m.close()
+    with pytest.raises(ValueError, match="Unknown pore type"):
+        MultiAligner(models["syn9"], "nope", [0])
+    al.close()

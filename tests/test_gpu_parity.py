@@ -511,3 +511,44 @@ def test_many_small_reads_in_one_batch(models):
     assert none.n == 0
     one = al.align_batch([reads[7].signal], [reads[7].sequence], True)
     assert np.array_equal(one.read(0)["signal_positions"], res.read(7)["signal_positions"])
+
+
+def test_stalled_pore_long_segments(models):
+    """A pore that sits on one k-mer for 20 000 samples (polyA / adapter stalls in real RNA reads): segments beyond
+    256 rows take the radix-select median (k_median_long) instead of the quadratic rank count. Parity with the
+    oracle on such reads, odd and even segment lengths, and the per-segment kernels must not blow up in time."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    mean_c, sd_c = synth.code_order_table(mean, sd, 9, True)
+    base = synth.make_reads(321, 4, "rna004", mean, sd, (300, 400))
+    al = Aligner(models["syn9"], "rna004", device=0)
+    orc = Oracle(models["syn9"], 1)
+
+    def with_stall(r, where, length, seed):
+        # the k-mer at `where` keeps emitting for `length` more samples
+        codes = orc.kmers(r.sequence)
+        rng = np.random.default_rng(seed)
+        extra = mean_c[codes[where]] + 1.3 * sd_c[codes[where]] * rng.standard_normal(length)
+        cut = int(len(r.signal) * where / len(codes))
+        return synth.SynthRead(np.concatenate([r.signal[:cut], extra, r.signal[cut:]]), r.sequence)
+
+    stalled = [with_stall(base[0], 100, 20000, 1), with_stall(base[1], 50, 20001, 2), with_stall(base[2], 200, 257, 3),
+               with_stall(with_stall(base[3], 30, 3000, 4), 250, 5001, 5)]
+    plain = [synth.SynthRead(np.concatenate([r.signal, r.signal[-20:]]), r.sequence) for r in base]
+    times = {}
+    for tag, reads in (("plain", plain), ("stalled", stalled)):
+        with al.batch([r.signal for r in reads], [r.sequence for r in reads]) as b:
+            b.align(True)
+            res = b.fetch()
+            tm = b.timing()
+            times[tag] = tm["ms_total"] - tm["ms_dp"]      # k_median + k_median_long + k_final
+        assert (res.status == 0).all()
+        longest = 0
+        for i, r in enumerate(reads):
+            want, got = orc.align(r.signal, r.sequence, True), res.read(i)
+            assert np.array_equal(got["signal_positions"], want["signal_positions"])
+            assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+            longest = max(longest, int(np.diff(np.append(want["signal_positions"], len(r.signal))).max()))
+        assert (longest > 19000) == (tag == "stalled")
+    # 4e8 compares in one segment used to take ~100 ms here; now the stalled batch costs about what its rows cost
+    assert times["stalled"] < 2.0 * times["plain"] + 1.0, times
+    al.close()

@@ -341,6 +341,16 @@ def test_sam_and_bam_readers_round_trip(tmp_path):
             assert r.has_tag("pi") == ("pi" in tags) and r.has_tag("f5") is False
             for k, v in tags.items():
                 assert r.get_tag(k) == v, (path, k)
+    # a SAM `f` field written with more digits than a float32 holds still reads as the float32 the BAM carries
+    sam2 = str(tmp_path / "y.sam")
+    with open(sam2, "w") as w:
+        w.write("@HD\tVN:1.6\tSO:unknown\nr\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\t*\tsm:f:91.23456789012345\tsd:f:15.1\tqs:f:12\tns:i:9\tts:i:1\tfn:Z:a.pod5\n")
+    (rec,) = list(iter_basecalls(sam2))
+    assert rec.get_tag("sm") == float(np.float32(91.23456789012345)) and rec.get_tag("sd") == float(np.float32(15.1))
+    # the BAM reader streams: the first record is out before the rest of the file has been touched
+    it = bam_io.iter_bam(bam)
+    assert next(it).query_name == "read-0000"
+    it.close()
     # and the job generator consumes them exactly like the TSV container
     jobs = list(seg.generate_jobs("/data", bam, 10.0))
     assert len(jobs) == sum(t["qs"] >= 10.0 for _, _, t in recs)

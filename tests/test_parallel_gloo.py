@@ -1,4 +1,4 @@
-"""CPU, world_size 2 on gloo: the multi-GPU plumbing of SURVEY.md §8e -- shard the reads, run the
+"""CPU, world_size 2 and 8 on gloo: the multi-GPU plumbing of SURVEY.md §8e -- shard the reads, run the
 (CPU oracle as stand-in for the per-rank hot path), gather per-read segment rows to rank 0
 (config 4) and all-reduce pooled sufficient statistics (config 5); results must equal the serial
 run. The DP itself is not under test here (tests/test_gpu_parity.py)."""
@@ -48,7 +48,8 @@ def _worker(rank, world, port, model, outdir):
             rows.append(rec)
             t = orc.train(r.signal, r.sequence, dense=False)
             pooled += np.concatenate([t["weight"], t["sum"], t["sumsq"]])
-        mine = np.concatenate(rows) if rows else np.zeros(0, dtype=rows[0].dtype)
+        row_dt = np.dtype([("signal_pos", "<u4"), ("sequence_pos", "<u4"), ("probability", "<f8")])
+        mine = np.concatenate(rows) if rows else np.zeros(0, dtype=row_dt)
         got = comm.gather_rows(torch.from_numpy(np.frombuffer(mine.tobytes(), dtype=np.uint8).copy()), dst=0)
         total = comm.allreduce_sum(pooled)
         np.save(os.path.join(outdir, f"pooled_{rank}.npy"), total)
@@ -57,7 +58,7 @@ def _worker(rank, world, port, model, outdir):
         assert parallel.broadcast_str(comm, "") == ""
         assert parallel.any_rank(comm, rank == 1) and not parallel.any_rank(comm, False)
         parts = parallel.gather_bytes(comm, b"x" * (3 * rank))
-        assert parts == [b"", b"xxx"] if rank == 0 else parts is None
+        assert parts == [b"x" * (3 * r) for r in range(world)] if rank == 0 else parts is None
         if rank == 0:
             allrows = np.concatenate([parallel.rows_from_bytes(g.numpy()) for g in got])
             np.save(os.path.join(outdir, "rows.npy"), allrows)
@@ -67,18 +68,21 @@ def _worker(rank, world, port, model, outdir):
         dist.destroy_process_group()
 
 
-def test_gather_and_allreduce_world2(models, tmp_path, oracle_built):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_and_allreduce(models, tmp_path, oracle_built, world):
+    """world 2, and world 8 = the rank count of BASELINE configs 4 and 5 (7 reads over 8 ranks: one rank has
+    nothing to contribute and still takes part in every collective)."""
     from oracle.pyoracle import Oracle
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, models["syn5"], str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, models["syn5"], str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
         assert p.exitcode == 0
     # serial reference
     _, mean, sd = synth.read_model_file(models["syn5"])
@@ -94,5 +98,5 @@ def test_gather_and_allreduce_world2(models, tmp_path, oracle_built):
     rows = np.load(tmp_path / "rows.npy")
     assert np.array_equal(rows["signal_pos"], np.concatenate(sig).astype(np.uint32))
     assert np.array_equal(rows["probability"], np.concatenate(prob))
-    for r in range(2):
+    for r in range(world):
         assert np.allclose(np.load(tmp_path / f"pooled_{r}.npy"), pooled, rtol=1e-12, atol=1e-12)
