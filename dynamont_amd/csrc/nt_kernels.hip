@@ -37,10 +37,10 @@
 // Mapping: band slot s = n mod P lives in lane s / CPL, register s % CPL: a lane owns CPL CONSECUTIVE
 // slots, so the cross-lane neighbour (n-1 forward, n+1 backward) of all but one of its cells is its
 // own next register and one DPP wave rotate per exchange serves the remaining cell -- no barrier
-// anywhere in the DP loops. In HBM a row stores slot s at position row_pos(s) = (s % CPL)*64 + s / CPL,
-// i.e. register j of all lanes is one contiguous 512-byte run: every row access is CPL fully
-// coalesced operations (a 56-byte lane stride, the "natural" placement of this slot numbering, cost
-// the backward sweep 20 % in partial-line writes). The CU's LDS holds the softplus table shared by the
+// anywhere in the DP loops. In HBM a row stores the register PAIRS (0,1), (2,3), (4,5) of all lanes as three
+// contiguous 1 024-byte runs (16 bytes per lane) and register 6 as a 512-byte run (row_pos): every row access
+// is four fully coalesced operations (a 56-byte lane stride, the "natural" placement of this slot numbering,
+// cost the backward sweep 20 % in partial-line writes). The CU's LDS holds the softplus table shared by the
 // four waves (dp_math.hpp), a 4-row-deep ring per wave that the forward sweep fills straight from HBM
 // with global_load_lds_dwordx4 (see ring_dma_row), and each wave's page table.
 #include "nt_kernels.hpp"
@@ -81,8 +81,32 @@ __device__ __forceinline__ int pmod(int a) {
   return r < 0 ? r + P : r;
 }
 
-// position of band slot s inside a stored row (see "Mapping" above)
-__device__ __forceinline__ int row_pos(int s) { return (s % CPL) * 64 + s / CPL; }
+// position of band slot s = lane*CPL + j inside a stored row: registers (0,1), (2,3), (4,5) of a lane sit side by
+// side -- 16 bytes per lane, so that a row is written with three 16-byte-per-lane stores and one 8-byte one (and
+// picked up from the LDS ring with three ds_read_b128 and one ds_read_b64) instead of seven 8-byte operations.
+__device__ __forceinline__ int pos_of(int lane, int j) { return j < 6 ? (j >> 1) * 128 + lane * 2 + (j & 1) : 384 + lane; }
+__device__ __forceinline__ int row_pos(int s) { return pos_of(s / CPL, s % CPL); }
+
+typedef double dyn_d2 __attribute__((ext_vector_type(2)));
+typedef float dyn_f2 __attribute__((ext_vector_type(2)));
+typedef float dyn_f4 __attribute__((ext_vector_type(4)));
+
+// one row of 8-byte slots: (x[0],x[1]) (x[2],x[3]) (x[4],x[5]) as 16-byte stores, x[6] as an 8-byte store
+template <bool NT>
+__device__ __forceinline__ void store_row_f64(double* __restrict__ row, int lane, const double (&x)[CPL]) {
+  static_assert(CPL == 7, "three register pairs and a single");
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    dyn_d2 v;
+    v.x = x[2 * q];
+    v.y = x[2 * q + 1];
+    dyn_d2* dst = reinterpret_cast<dyn_d2*>(row + q * 128 + lane * 2);
+    if (NT) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+  }
+  if (NT) __builtin_nontemporal_store(x[6], row + 384 + lane);
+  else row[384 + lane] = x[6];
+}
 
 // size_t(t * RATIO): one IEEE fp64 multiply, then truncation (NT_aligner_api.cpp:100).
 __device__ __forceinline__ int band_mid(int t, double ratio) {
@@ -219,21 +243,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// the wave's copy of one row: cell (lane, j) sits at row_pos*8 = (j*64 + lane)*8
-__device__ __forceinline__ void ring_read_row(unsigned lds_lane_addr, double (&b)[CPL]) {
+// the wave's copy of one row: cell (lane, j) sits at pos_of(lane, j) * 8 behind the ring slot's LDS address
+__device__ __forceinline__ void ring_read_row(unsigned slot_addr, int lane, double (&b)[CPL]) {
   static_assert(CPL == 7, "ring_read_row is written for 7 cells per lane");
+  dyn_d2 p0, p1, p2;
+  double last;
   asm volatile(
-      "ds_read_b64 %0, %7\n\t"
-      "ds_read_b64 %1, %7 offset:512\n\t"
-      "ds_read_b64 %2, %7 offset:1024\n\t"
-      "ds_read_b64 %3, %7 offset:1536\n\t"
-      "ds_read_b64 %4, %7 offset:2048\n\t"
-      "ds_read_b64 %5, %7 offset:2560\n\t"
-      "ds_read_b64 %6, %7 offset:3072\n\t"
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %4 offset:1024\n\t"
+      "ds_read_b128 %2, %4 offset:2048\n\t"
+      "ds_read_b64 %3, %5 offset:3072\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6])
-      : "v"(lds_lane_addr)
+      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(last)
+      : "v"(slot_addr + lane * 16), "v"(slot_addr + lane * 8)
       : "memory");
+  b[0] = p0.x;
+  b[1] = p0.y;
+  b[2] = p1.x;
+  b[3] = p1.y;
+  b[4] = p2.x;
+  b[5] = p2.y;
+  b[6] = last;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -256,7 +286,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
   const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ out = ws + lane;
+  double* __restrict__ out = ws;
   RowCursor cur;
 
   bool bad_sample = false;
@@ -276,10 +306,10 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
       bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
       bM[j] = NEG_INF;
-      if (STORE) {
-        out[rT1 + j * 64] = bE[j];
-        out[rT + j * 64] = NEG_INF;
-      }
+    }
+    if (STORE) {
+      store_row_f64<false>(out + rT1, lane, bE);
+      store_row_f64<false>(out + rT, lane, bM);  // all -inf
     }
   }
 
@@ -346,9 +376,9 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       for (int j = 0; j < CPL; ++j) {
         bE[j] = ne[j];
         bM[j] = A[j];
-        // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
-        if (STORE) __builtin_nontemporal_store(ne[j], &out[rt + j * 64]);
       }
+      // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
+      if (STORE) store_row_f64<true>(out + rt, lane, ne);
     }
   }
   // An infinite sample gives every cell of its row the score -inf in the reference (aligner.cpp:
@@ -398,8 +428,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   // ws_rd and lp_out are separate __restrict__ parameters on purpose: with a pointer derived from
   // the load pointer hipcc orders every prefetch behind the previous row's stores (s_waitcnt vmcnt(0)
   // at the top of each row = 43 % of the wave's lifetime spent waiting).
-  const double* __restrict__ lat = ws_rd + lane;
-  float* __restrict__ lat_lp = lp_out + (INPLACE ? 2 : 1) * lane;
+  const double* __restrict__ lat = ws_rd;
+  float* __restrict__ lat_lp = lp_out;
   RowCursor cur_dma, cur_out;
 
   // Band edges without per-row masks. Lower edge: the slot of a column that leaves the band is
@@ -424,13 +454,12 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     if (POST) {
       vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
       vM[j] = NEG_INF;
-      bcur[j] = lat[r1 + j * 64];
+      bcur[j] = lat[r1 + pos_of(lane, j)];
       bnext[j] = NEG_INF;
     }
   }
   log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
-  const unsigned ring_lane = ring_base + lane * 8;
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
     for (int r = 2; r <= RING_D + 1; ++r)
@@ -455,7 +484,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
         // -inf row T, so that the same number of memory operations is in flight in every row and
         // one hand-counted s_waitcnt serves the whole loop, tail included)
         wait_vmcnt<RING_WAIT>();
-        ring_read_row(ring_lane + ((t + 1) % RING_D) * ROW_BYTES, bnext);
+        ring_read_row(ring_base + ((t + 1) % RING_D) * ROW_BYTES, lane, bnext);
         ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
       }
       from_left(fE, fEl);
@@ -522,17 +551,30 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
         const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
         const uint32_t prow = cur_out.at(w, t);
         const size_t rt = (size_t)prow * P;
+        // read again only by the traceback, one cell per row: non-temporal; same pairing as the bE rows
+        if (INPLACE) {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {  // read again only by the traceback, one cell per row: non-temporal
-          if (INPLACE) {
-            typedef float dyn_f2 __attribute__((ext_vector_type(2)));
-            dyn_f2 v2;
-            v2.x = (float)LPM[j];
-            v2.y = (float)LPE[j];
-            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * (rt + j * 64)]));
-          } else {
-            __builtin_nontemporal_store((float)LPE[j], &lat_lp[rt + j * 64]);
+          for (int q = 0; q < 3; ++q) {
+            dyn_f4 v4;
+            v4.x = (float)LPM[2 * q];
+            v4.y = (float)LPE[2 * q];
+            v4.z = (float)LPM[2 * q + 1];
+            v4.w = (float)LPE[2 * q + 1];
+            __builtin_nontemporal_store(v4, reinterpret_cast<dyn_f4*>(&lat_lp[2 * (rt + q * 128 + lane * 2)]));
           }
+          dyn_f2 v2;
+          v2.x = (float)LPM[6];
+          v2.y = (float)LPE[6];
+          __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * (rt + 384 + lane)]));
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            dyn_f2 v2;
+            v2.x = (float)LPE[2 * q];
+            v2.y = (float)LPE[2 * q + 1];
+            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[rt + q * 128 + lane * 2]));
+          }
+          __builtin_nontemporal_store((float)LPE[6], &lat_lp[rt + 384 + lane]);
         }
         if (lane < CPL) bits[(size_t)prow * CPL + lane] = mybits;
 #pragma unroll
@@ -743,7 +785,6 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
   }
   log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
   // ring prologue: rows 1 .. RING_D (row r lives in ring slot r % RING_D); rows past T repeat the -inf row T
-  const unsigned ring_lane = ring_base + lane * 8;
   const double* __restrict__ dma_src = ws + lane * 2;
   for (int r = 1; r <= RING_D; ++r)
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
@@ -760,7 +801,7 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
       const double xn = readlane_f64(xs, i);
       double fEl[CPL];
       wait_vmcnt<RING_WAIT>();
-      ring_read_row(ring_lane + (t % RING_D) * ROW_BYTES, bcur);  // bE(t, .)
+      ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, bcur);  // bE(t, .)
       ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
       from_left(fE, fEl);
       const int next_lo = band_mid(t + 1, ratio) - bw;
