@@ -87,3 +87,28 @@ def test_stub_align_and_train_on_the_gpu(stub, models, monkeypatch):
         assert np.abs(got - g7[p + "mean"]).max() <= 1e-9
     batch = al.align_batch([g["syn_signal"], np.zeros(0), g["syn_signal"]], [str(g["syn_sequence"]), "ACGTACGT", str(g["syn_sequence"])], True)
     assert batch[1] == {"error": "Signal is empty"} and np.array_equal(batch[0]["signal_positions"], batch[2]["signal_positions"])
+
+
+@pytest.fixture(scope="module")
+def c_example(tmp_path_factory, native_lib):
+    """integration/multi_gpu_example.c: a plain C consumer of the ABI (header is C, not only C++)."""
+    exe = tmp_path_factory.mktemp("cex") / "multi_gpu_example"
+    subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "integration", "multi_gpu_example.c"), "-L" + os.path.join(ROOT, "dynamont_amd"),
+                    "-ldynamont_mi", "-Wl,-rpath," + os.path.join(ROOT, "dynamont_amd"), "-lm", "-o", str(exe)], check=True)
+    return str(exe)
+
+
+def test_c_example_builds_and_fails_loudly_without_a_gpu(c_example, models):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([c_example, models["syn9"], "rna004", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU compute path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_multi_device_on_the_gpu(c_example, models):
+    r = subprocess.run([c_example, models["syn9"], "rna004", "0", "0", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "3 device handle(s): identical to the single-device result" in r.stdout

@@ -25,7 +25,7 @@ def main(argv):
             print(name, "FAILED", r.stderr[-500:], flush=True)
             continue
         j = json.loads(line[-1])
-        print(f"{name:>14s} [{flags}]: ms/step {j['ms_per_step']:.3f}  {j['kernel_ms']}  reads_ok {j['reads_ok']}", flush=True)
+        print(f"{name:>14s} [{flags}]: ms/step {j['ms_per_step']:.3f}  {j['kernel_ms_per_step']}  resident {j.get('kernel_resident_Msamp_s')}", flush=True)
 
 
 if __name__ == "__main__":
