@@ -17,6 +17,9 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using dynk::ReadState;
@@ -38,6 +41,23 @@ int hip_fail(dyn_batch* b, hipError_t e, const char* what) {
     hipError_t _e = (expr);                                   \
     if (_e != hipSuccess) return hip_fail((b), _e, #expr);    \
   } while (0)
+
+// DYN_TRACE_HOST=1: wall time of the pipeline stages of every batch on stderr
+const bool g_trace = std::getenv("DYN_TRACE_HOST") != nullptr;
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// page-locked host memory (hipHostMalloc / dyn_host_alloc): DMA can read it directly
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  std::memset(&attr, 0, sizeof attr);
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // unregistered memory reports an error on some runtimes
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
 
 int helper_threads() {
   const unsigned hc = std::thread::hardware_concurrency();
@@ -130,40 +150,59 @@ void Pipeline::back_loop() {
 // Host prepare, H2D and every kernel launch of one batch; returns without waiting for the GPU.
 int Pipeline::front_stage(dyn_batch* b) {
   const uint64_t n = b->n;
+  const double t0 = now_ms();
   int rc = host_prepare(b, a->model, true, n, b->in_sig_offsets, b->in_seqs, b->in_seq_offsets, &helpers);
+  const double t1 = now_ms();
   if (rc != DYN_OK) {
     b->error = a->last_error;
     return rc;
   }
   const uint64_t total_sig = n ? b->in_sig_offsets[n] - b->in_sig_offsets[0] : 0;
   std::lock_guard<std::mutex> lk(a->mu);
+  const double t2 = now_ms();
   rc = alloc_batch_buffers(b, total_sig);
   if (rc != DYN_OK) {
     b->error = a->last_error;
     return rc;
   }
-  for (hipEvent_t* e : {&b->ev_in, &b->ev_done, &b->ev_out})
+  const double t3 = now_ms();
+  for (hipEvent_t* e : {&b->ev_in, &b->ev_out})
     if (!*e) P_TRY(b, hipEventCreateWithFlags(e, hipEventDisableTiming));
   // H2D on the copy-in stream. Pinned caller memory (dyn_host_alloc) is a true asynchronous DMA;
   // for pageable memory the runtime stages the copy and this thread blocks for its duration, which
   // is what the thread is for -- the compute stream keeps running the previous batch meanwhile.
-  if (total_sig)
-    P_TRY(b, hipMemcpyAsync(b->d_sig.p, b->in_signals + b->in_sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->s_in));
+  if (total_sig) {
+    const double* src = b->in_signals + b->in_sig_offsets[0];
+    if (!is_pinned(src)) {
+      // Pageable caller memory is staged HERE, by the helper threads, into a pinned buffer of the batch: measured,
+      // hipMemcpyAsync from pageable memory blocks its caller for the length of the kernel that is running (~46 ms
+      // instead of 3.4), which made this thread -- not the GPU -- the pipeline's bottleneck.
+      P_TRY(b, b->h_sig.ensure(total_sig * 8));
+      double* dst = b->h_sig.as<double>();
+      const int parts = std::max(1, std::min<int>(helpers.size(), (int)(total_sig >> 18)));
+      helpers.parallel_for(parts, [&](int t) {
+        const uint64_t lo = total_sig * t / parts, hi = total_sig * (t + 1) / parts;
+        std::memcpy(dst + lo, src + lo, (hi - lo) * 8);
+      });
+      src = dst;
+    }
+    P_TRY(b, hipMemcpyAsync(b->d_sig.p, src, total_sig * 8, hipMemcpyHostToDevice, a->s_in));
+  }
   if (b->total_cols)
     P_TRY(b, hipMemcpyAsync(b->d_kmers.p, b->h_kmers.p, b->total_cols * 4, hipMemcpyHostToDevice, a->s_in));
   P_TRY(b, hipEventRecord(b->ev_in, a->s_in));
+  const double t4 = now_ms();
   P_TRY(b, hipStreamWaitEvent(a->stream, b->ev_in, 0));
   if (b->total_cols) {
     dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
     P_TRY(b, hipGetLastError());
   }
-  rc = enqueue_job(b, b->job);
+  rc = enqueue_job(b, b->job);  // records ev_done behind the batch's last kernel
   if (rc != DYN_OK) {
     b->error = a->last_error;
     (void)hipStreamSynchronize(a->stream);  // nothing of this batch may still be running when it is torn down
     return rc;
   }
-  P_TRY(b, hipEventRecord(b->ev_done, a->stream));
   P_TRY(b, hipStreamWaitEvent(a->s_out, b->ev_done, 0));
   // D2H into pinned per-batch buffers on the copy-out stream
   if (n) P_TRY(b, hipMemcpyAsync(b->h_state.p, b->d_state.p, n * sizeof(ReadState), hipMemcpyDeviceToHost, a->s_out));
@@ -186,12 +225,17 @@ int Pipeline::front_stage(dyn_batch* b) {
     if (n) P_TRY(b, hipMemcpyAsync(h + 3 * c, b->d_trans.p, n * 16, hipMemcpyDeviceToHost, a->s_out));
   }
   P_TRY(b, hipEventRecord(b->ev_out, a->s_out));
+  if (g_trace)
+    std::fprintf(stderr, "[dyn] front %p: start %.2f prepare %.2f lock %.2f alloc %.2f h2d %.2f enqueue+d2h %.2f ms\n", (void*)b,
+                 t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3, now_ms() - t4);
   return DYN_OK;
 }
 
 // Wait for the batch's last D2H, then turn the device records into the caller's arrays.
 int Pipeline::back_stage(dyn_batch* b) {
+  const double t0 = now_ms();
   P_TRY(b, hipEventSynchronize(b->ev_out));
+  const double t1 = now_ms();
   int rc = collect_timing(b);
   if (rc != DYN_OK) {
     b->error = a->last_error;
@@ -210,6 +254,7 @@ int Pipeline::back_stage(dyn_batch* b) {
                            (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
     unpack_align(b, st, want_rows ? b->h_rows.as<SegRow>() : nullptr, out, &helpers);
   }
+  if (g_trace) std::fprintf(stderr, "[dyn] back  %p: waited %.2f (until %.2f) unpack %.2f ms\n", (void*)b, t1 - t0, t1, now_ms() - t1);
   return DYN_OK;
 }
 

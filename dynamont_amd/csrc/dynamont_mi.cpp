@@ -212,7 +212,7 @@ void attach_cache(dyn_batch* b) {
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
                     &b->d_pathn})
     d->cache = c;
-  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats}) h->cache = c;
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->cache = c;
 }
 
 int need_device(dyn_aligner* a) {
@@ -650,7 +650,7 @@ void dyn_batch_destroy(dyn_batch* b) {
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
                     &b->d_pathn})
     d->release();
-  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats}) h->release();
+  for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->release();
   for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : {b->ev_in, b->ev_done, b->ev_out})
     if (e) (void)hipEventDestroy(e);
@@ -1034,15 +1034,20 @@ int enqueue_job(dyn_batch* b, DynJob job) {
                               : !calc              ? dynk::JOB_Z
                               : lpe_separate       ? dynk::JOB_ALIGN
                                                    : dynk::JOB_ALIGN_INPLACE;
+  if (!b->ev_done) HIP_TRY(a, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   dynk::launch_pool_init(pool, used_pages, (int)n_static, a->stream);
   HIP_TRY(a, hipEventRecord(ev[0], a->stream));
   dynk::launch_read_queue(qjob, q, a->n_cus, a->stream);
   HIP_TRY(a, hipEventRecord(ev[1], a->stream));
+  // the statistics leave the control words before the next batch's k_pool_init resets them (same stream)
+  HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
+  // (Running the per-segment kernels on a stream of their own, beside the next batch's read queue, was measured:
+  //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
   if (calc) dynk::launch_segments(q.descs, nr, max_T, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
   if (job == DynJob::Train)
     dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers, a->stream);
   HIP_TRY(a, hipEventRecord(ev[2], a->stream));
-  HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(a, hipEventRecord(b->ev_done, a->stream));
   HIP_TRY(a, hipGetLastError());
   tm.reads_ok = order.size();
   tm.launches = nr ? 1 : 0;

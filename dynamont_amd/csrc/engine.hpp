@@ -135,8 +135,9 @@ struct dyn_batch {
   dyneng::DevBuf d_pp, d_pathn;                // per-row path arrays (traceback -> k_median / k_final)
   dyneng::PinnedBuf h_descs, h_state, h_rows;  // h_state/h_rows: D2H targets of the asynchronous path
   dyneng::PinnedBuf h_stats;                   // wave-cycle statistics of the read-queue launch
+  dyneng::PinnedBuf h_sig;                     // staging of pageable caller signals (asynchronous path)
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels
-  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;  // ev_done: every kernel of the last job has finished
   uint32_t n_chunks = 0;                       // launches enqueued by the last job (0 or 1)
   dyn_timing timing{};
   bool aligned = false, trained = false;

@@ -552,3 +552,49 @@ def test_stalled_pore_long_segments(models):
     # 4e8 compares in one segment used to take ~100 ms here; now the stalled batch costs about what its rows cost
     assert times["stalled"] < 2.0 * times["plain"] + 1.0, times
     al.close()
+
+
+def _orc_train(job):
+    sig, seq = job
+    t = _ORC.train(sig, seq, dense=False)
+    return t["Z"], t["m1"], t["e2"], t["weight"], t["sum"], t["sumsq"]
+
+
+def test_cfg5_share_full_size_train(models, al9):
+    """BASELINE configs[4]'s per-GPU share: 1 024 RNA004 reads x ~20 k samples through train(). Size-independent
+    properties on all reads (every lattice row carries posterior mass 1, every path has exactly one M cell per
+    k-mer), full parity with the oracle on 8 reads, and the device-pooled statistics against the per-read ones."""
+    import multiprocessing as mp
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    cfg = synth.CONFIGS["cfg5"]
+    reads = synth.make_reads(cfg["seed"], 1024, cfg["pore"], mean, sd, cfg["n_bases"])
+    sig, so, sq, qo = synth.pack_reads(reads)
+    t = al9.train_async(sig, so, sq, qo, pooled=True)
+    res = t.wait()
+    tm = t.timing()
+    t.close()
+    assert (res.status == 0).all() and tm["reads_ok"] == 1024 and tm["launches"] == 1
+    K = al9.num_kmers
+    k = al9.kmer_size
+    for i, r in enumerate(reads):
+        a, n = int(res.em_offsets[i]), int(res.em_count[i])
+        # expected counts: sum over k-mers of w = S rows (one path cell per row); one E->M transition per k-mer; every
+        # E cell is entered from M (once per k-mer) or from E: E->E = (S - Kc) - Kc
+        assert abs(res.em_weight[a:a + n].sum() - len(r.signal)) <= 1e-6 * len(r.signal)
+        kc = len(r.sequence) - k + 1
+        assert abs(res.trans_counts[2 * i] - kc) <= 1e-6 * kc
+        assert abs(res.trans_counts[2 * i + 1] - (len(r.signal) - 2 * kc)) <= 1e-6 * len(r.signal)
+        assert np.all(res.em_stdev[a:a + n] > 0) and np.all(np.isfinite(res.em_mean[a:a + n]))
+    assert abs(res.pooled[:K].sum() - float(so[-1])) <= 1e-6 * float(so[-1])
+    picks = [0, 100, 333, 512, 700, 901, 1000, 1023]
+    with mp.get_context("fork").Pool(8, initializer=_orc_init, initargs=(models["syn9"], 1)) as pool:
+        want = pool.map(_orc_train, [(reads[i].signal, reads[i].sequence) for i in picks], chunksize=1)
+    for i, (Z, m1, e2, w, s1, s2) in zip(picks, want):
+        assert abs(res.Z[i] - Z) <= 1e-9 * abs(Z)
+        assert abs(res.transitions[3 * i] - m1) <= 1e-9 and abs(res.transitions[3 * i + 2] - e2) <= 1e-9
+        code, m, s = res.sparse(i)
+        touched = np.nonzero(w > 0)[0]
+        assert np.array_equal(code, touched)
+        assert np.abs(m - s1[touched] / w[touched]).max() <= 1e-9
+        a = int(res.em_offsets[i])
+        assert np.allclose(res.em_weight[a:a + len(code)], w[touched], rtol=1e-9, atol=1e-12)
