@@ -428,7 +428,7 @@ def test_train_batch_against_oracle_and_pooled_stats(models, al9):
 
 
 def test_traceback_segments_spanning_many_64_row_blocks(models):
-    """k_trace walks 64 rows at a time and jumps a segment per step: exercise dwell times from the
+    """The traceback walks 64 rows at a time and jumps a segment per step: exercise dwell times from the
     minimum (2 samples) to stalls of several hundred samples, turning points on block boundaries,
     and M cells that fall into the next block."""
     pore = "dna_r9"
@@ -486,7 +486,7 @@ def test_empty_and_all_failed_batches(al5):
 
 def test_many_small_reads_in_one_batch(models):
     """More reads than the chip has SIMDs (4 096 reads -> 1 024 workgroups per DP kernel, one block per
-    read in k_trace): dispatch order, LPT sorting and the per-read offsets must not mix reads up."""
+    read in the traceback): dispatch order, LPT sorting and the per-read offsets must not mix reads up."""
     pore = "dna_r9"
     path = model_for(models, pore)
     _, mean, sd = synth.read_model_file(path)

@@ -1,4 +1,4 @@
-// Validates the LDS-DMA ring used by k_forward: rows of 448 doubles are streamed HBM -> LDS with
+// Validates the LDS-DMA ring used by the forward sweep of k_read_queue: rows of 448 doubles are streamed HBM -> LDS with
 // global_load_lds_dwordx4 (3 full + 1 half-wave instruction per 3584-byte row), D rows deep per
 // wave, consumed with ds_read_b64 behind a hand-counted s_waitcnt vmcnt(N).
 // Build: hipcc --offload-arch=gfx950 -O3 -o lds_dma_test lds_dma_test.hip
