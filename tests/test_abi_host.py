@@ -146,3 +146,35 @@ def test_queue_planner_for_page_starved_launches(native_lib):
     a, b = plan(int(pages[:1024].sum()) + 10)          # every wave gets its lattice: longest-first stays
     assert a == b and np.array_equal(order, np.arange(4096))
     assert a / ideal < 1.03
+
+
+def test_queue_planner_properties_on_random_batches(native_lib):
+    """Whatever the length distribution and the pool size (as long as the longest read fits): the planned queue is a
+    permutation, every read gets served in the host replay (finite makespan) and the plan is never worse than
+    longest-first."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        n = int(rng.integers(1, 3000))
+        kind = trial % 4
+        if kind == 0:
+            rows = rng.integers(2000, 120000, size=n)
+        elif kind == 1:
+            rows = (rng.lognormal(10.0, 0.8, size=n)).astype(np.int64) + 50
+        elif kind == 2:
+            rows = np.full(n, int(rng.integers(100, 50000)))
+        else:
+            rows = np.concatenate([rng.integers(90000, 100000, size=n // 10 + 1), rng.integers(500, 3000, size=n)])[:n]
+        rows = np.sort(rows.astype(np.uint64))[::-1].copy()
+        pages = ((rows + 1 + 255) // 256).astype(np.uint32)
+        n_slots = int(rng.choice([4, 64, 1024]))
+        top = int(pages[:n_slots].sum())
+        pool = int(max(int(pages[0]), rng.uniform(0.15, 1.3) * top))
+        order = np.zeros(n, dtype=np.uint32)
+        lpt, planned = C.c_uint64(), C.c_uint64()
+        rc = native_lib.dyn_plan_queue(n, pages.ctypes.data_as(C.POINTER(C.c_uint32)), rows.ctypes.data_as(N.c_u64_p), n_slots,
+                                       pool, order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(lpt), C.byref(planned))
+        assert rc == N.DYN_OK
+        assert sorted(order.tolist()) == list(range(n)), trial
+        assert lpt.value != 2 ** 64 - 1 and planned.value <= lpt.value, (trial, lpt.value, planned.value)
+        assert planned.value >= int(rows[0])

@@ -598,3 +598,33 @@ def test_cfg5_share_full_size_train(models, al9):
         assert np.abs(m - s1[touched] / w[touched]).max() <= 1e-9
         a = int(res.em_offsets[i])
         assert np.allclose(res.em_weight[a:a + len(code)], w[touched], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("cus,frac", [(16, 0.5), (16, 0.12), (8, 0.3), (256, 0.2)])
+def test_page_starved_queues_equal_the_unconstrained_run(models, al9, monkeypatch, cus, frac):
+    """Few persistent workgroups (DYN_QUEUE_CUS) and a pool far too small for them: the planned queue, waves that
+    change arenas on the device, surplus pages handed to waiting waves. Whatever the schedule, every read must come
+    out exactly as in the unconstrained launch with the same posterior layout."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(9000 + cus, 260, "rna004", mean, sd, (100, 1500))
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    monkeypatch.setenv("DYN_FORCE_LAYOUT", "inplace")
+    base = al9.align_batch(sigs, seqs, True)
+    monkeypatch.setenv("DYN_QUEUE_CUS", str(cus))
+    small = Aligner(models["syn9"], "rna004", device=0)
+    monkeypatch.delenv("DYN_QUEUE_CUS")
+    n_slots = min(len(reads), 4 * cus)
+    lens = sorted((len(x) for x in sigs), reverse=True)
+    wanted = sum(lens[:n_slots]) * (448 * 8 + 56)                      # in-place lattices of the reads in flight
+    small.set_mem_budget(int(max(frac * wanted, 1.3 * lens[0] * (448 * 8 + 56))))
+    with small.batch(sigs, seqs) as b:
+        b.align(True)
+        got = b.fetch()
+        tm = b.timing()
+    assert tm["launches"] == 1 and tm["lp_inplace"] == 1 and tm["n_waves"] == min(4 * cus, (len(reads) + 3) // 4 * 4)
+    assert (got.status == 0).all() and (base.status == 0).all()
+    for i in range(len(reads)):
+        a, c = base.read(i), got.read(i)
+        assert np.array_equal(a["signal_positions"], c["signal_positions"]) and a["Z"] == c["Z"]
+        assert np.array_equal(a["probabilities"], c["probabilities"])
+    small.close()
