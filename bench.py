@@ -320,6 +320,12 @@ def main():
             # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
             "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
                                 "waiting_for_pages": round(kern["wave_wait_share"] / steps, 4)},
+            # the two sweeps apart: their algorithmic bytes over their share of the launch (they overlap in time only
+            # when waves are out of phase, i.e. in batches of more reads than waves)
+            "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(ms_dp * share("ms_backward"), 3),
+                                          "frac": round(cells_per_launch * KBWD_BYTES_PER_CELL / (ms_dp * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
+                       "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(ms_dp * share("ms_forward"), 3),
+                                         "frac": round(cells_per_launch * bpc_f / (ms_dp * share("ms_forward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_forward") else None}},
             "wave_occupancy": round(kern["wave_occupancy"] / steps, 4),
             "page_pool": {"pages": launches["pool_pages"], "rows_per_page": launches["page_rows"],
                           "reads_with_reserved_pages": launches["n_static"], "waves": launches["n_waves"]},

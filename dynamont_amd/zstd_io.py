@@ -74,8 +74,11 @@ class ZstdWriter:
             rc = L.ZSTD_CCtx_setParameter(self._ctx, _ZSTD_c_nbWorkers, int(workers))
             if L.ZSTD_isError(rc):
                 workers = 0
-        self._cap = int(L.ZSTD_CStreamOutSize())
+        # a large output buffer: one ZSTD_compressStream2 call (GIL released) then consumes megabytes of input
+        # instead of returning to Python every 128 KB (that loop alone held the CLI at 24 Msamp/s)
+        self._cap = max(int(L.ZSTD_CStreamOutSize()), 8 << 20)
         self._out = C.create_string_buffer(self._cap)
+        self._view = memoryview(self._out)
 
     def _check(self, rc):
         if self._L.ZSTD_isError(rc):
@@ -89,7 +92,7 @@ class ZstdWriter:
             remaining = self._L.ZSTD_compressStream2(self._ctx, C.byref(ob), C.byref(ib), mode)
             self._check(remaining)
             if ob.pos:
-                self._raw.write(self._out.raw[:ob.pos])
+                self._raw.write(self._view[:ob.pos])
             done = (ib.pos == ib.size) if mode == _ZSTD_e_continue else (remaining == 0)
             if done:
                 break

@@ -8,6 +8,7 @@ from dynamont_amd import synth
 from dynamont_amd.segmentation import segment as seg
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+extra = sys.argv[2:]  # e.g. --parallel-zstd-frames
 d = tempfile.mkdtemp(prefix="dyn_e2e_")
 model = synth.write_model(os.path.join(d, "m9.model"), 9)
 _, mean, sd = synth.read_model_file(model)
@@ -21,8 +22,8 @@ pr = cProfile.Profile()
 t0 = time.time()
 pr.enable()
 seg.main(["-r", os.path.join(d, "in"), "-b", bam, "-o", os.path.join(d, "out.csv"), "--mode", "basic", "-p", "rna004",
-          "--model_path", model, "--batch-reads", "1024"])
+          "--model_path", model, "--batch-reads", "1024"] + extra)
 pr.disable()
 dt = time.time() - t0
-print(f"end to end: {dt:.2f} s -> {samples/dt/1e6:.1f} Msamp/s, {n/dt:.0f} reads/s, output {os.path.getsize(os.path.join(d,'out.csv.zst'))/1e6:.1f} MB")
+print(f"flags {extra}: end to end: {dt:.2f} s -> {samples/dt/1e6:.1f} Msamp/s, {n/dt:.0f} reads/s, output {os.path.getsize(os.path.join(d,'out.csv.zst'))/1e6:.1f} MB")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
