@@ -53,8 +53,9 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
     p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same bytes)")
     p.add_argument("--parallel-zstd-frames", action="store_true",
-                   help="compress the CSV on several threads as consecutive zstd frames (faster; readers must read across frames, "
-                        "python-zstandard's defaults stop after the first frame). Default: one frame, like the reference")
+                   help="write the CSV as consecutive independent zstd frames (readers must read across frames: "
+                        "python-zstandard's defaults stop after the first). Default: one frame, like the reference, "
+                        "compressed on several threads either way")
     return p.parse_args(argv)
 
 

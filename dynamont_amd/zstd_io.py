@@ -1,8 +1,8 @@
 """zstd level-3 writers for the CSV output (reference: ``zstd.ZstdCompressor(level=3)
-.stream_writer``, segment.py:74-79): :class:`ZstdWriter` (ONE frame, like the reference -- what the
-CLIs write by default; the ``zstandard`` package when it is installed, the system ``libzstd.so.1``
-through ctypes otherwise) and :class:`ParallelZstdWriter` (opt-in: chunks compressed concurrently and
-written as consecutive independent frames).
+.stream_writer``, segment.py:74-79): :class:`ParallelZstdWriter` -- chunks compressed concurrently and
+written either as ONE frame (default of the CLIs: the job scheme of zstd's own multi-threaded mode, over
+the system ``libzstd.so.1`` through ctypes) or, opt-in, as consecutive independent frames -- and
+:class:`ZstdWriter` (one frame, one thread; the ``zstandard`` package when it is installed).
 
 Why one frame is the default: python-zstandard's default readers (``stream_reader``, ``zstd.open``,
 ``decompressobj()``, one-shot ``decompress``) stop at the end of the FIRST frame, so a consumer such as
@@ -134,9 +134,19 @@ class ParallelZstdWriter:
     and :func:`decompress` return the concatenation. One level-3 thread manages ~400 MB/s of CSV,
     which made the writer the slowest stage of ``dynamont-resquiggle`` on an MI355X."""
 
-    def __init__(self, raw, level: int = 3, threads: int = 4, chunk_bytes: int = 4 << 20):
+    def __init__(self, raw, level: int = 3, threads: int = 4, chunk_bytes: int = 4 << 20, single_frame: bool = False):
+        """``single_frame=True``: the chunks become the jobs of ONE zstd frame, the way zstd's own multi-threaded
+        mode (zstdmt, not compiled into the image's libzstd 1.4.8) builds it: every job is compressed by a context
+        of its own with the same parameters; job 0 keeps its frame header, every later job flushes its header into
+        the void (``ZSTD_compressContinue`` with 0 bytes) and calls ``ZSTD_invalidateRepCodes`` so that its first
+        block does not lean on repeat offsets the decoder will not have at that point (a fresh context has no
+        previous entropy tables either); the frame is closed by an empty last block. Any zstd decoder sees one
+        ordinary frame."""
         from concurrent.futures import ThreadPoolExecutor
         self._raw = raw
+        self._single = bool(single_frame)
+        import threading
+        self._tls, self._ctxs, self._ctx_lock = threading.local(), [], threading.Lock()
         self._level = int(level)
         self._chunk = int(chunk_bytes)
         self._threads = max(1, int(threads))
@@ -150,9 +160,45 @@ class ParallelZstdWriter:
         L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         L.ZSTD_compressBound.restype = C.c_size_t
         L.ZSTD_compressBound.argtypes = [C.c_size_t]
+        if self._single:
+            for name in ("ZSTD_compressBegin", "ZSTD_compressContinue", "ZSTD_compressEnd", "ZSTD_invalidateRepCodes"):
+                if not hasattr(L, name):
+                    raise OSError(f"libzstd lacks {name}")
+            L.ZSTD_compressBegin.restype = C.c_size_t
+            L.ZSTD_compressBegin.argtypes = [C.c_void_p, C.c_int]
+            for fn in (L.ZSTD_compressContinue, L.ZSTD_compressEnd):
+                fn.restype = C.c_size_t
+                fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.ZSTD_invalidateRepCodes.restype = None
+            L.ZSTD_invalidateRepCodes.argtypes = [C.c_void_p]
 
-    def _compress(self, owner, addr: int, n: int) -> bytes:
+    def _err(self, rc):
+        if self._L.ZSTD_isError(rc):
+            raise OSError("zstd: " + self._L.ZSTD_getErrorName(rc).decode())
+        return rc
+
+    def _job(self, owner, addr: int, n: int, first: bool, last: bool) -> bytes:
+        """One job of the single frame (see __init__). `last`: the terminating job (no data, closes the frame)."""
+        L = self._L
+        ctx = getattr(self._tls, "ctx", None)  # one context per worker thread, reset by ZSTD_compressBegin
+        if ctx is None:
+            ctx = self._tls.ctx = L.ZSTD_createCCtx()
+            with self._ctx_lock:
+                self._ctxs.append(ctx)
+        self._err(L.ZSTD_compressBegin(ctx, self._level))
+        cap = int(L.ZSTD_compressBound(n)) + 64
+        dst = C.create_string_buffer(cap)
+        if not first:
+            self._err(L.ZSTD_compressContinue(ctx, dst, cap, None, 0))  # this context's frame header: dropped
+            L.ZSTD_invalidateRepCodes(ctx)
+        fn = L.ZSTD_compressEnd if last else L.ZSTD_compressContinue
+        rc = self._err(fn(ctx, dst, cap, addr if n else None, n))
+        return dst.raw[:rc]
+
+    def _compress(self, owner, addr: int, n: int, first: bool = True) -> bytes:
         # `owner` keeps the source bytes alive while the worker reads [addr, addr + n)
+        if self._single:
+            return self._job(owner, addr, n, first, False)
         L = self._L
         cap = int(L.ZSTD_compressBound(n))
         dst = C.create_string_buffer(cap)
@@ -163,7 +209,7 @@ class ParallelZstdWriter:
 
     def _submit(self, data: bytes, off: int, n: int):
         base = C.cast(C.c_char_p(data), C.c_void_p).value or 0
-        self._pending.append(self._pool.submit(self._compress, data, base + off, n))
+        self._pending.append(self._pool.submit(self._compress, data, base + off, n, self._frames == 0))
         self._frames += 1
         while len(self._pending) > 2 * self._threads:  # back-pressure: bounded memory
             self._raw.write(self._pending.pop(0).result())
@@ -199,10 +245,15 @@ class ParallelZstdWriter:
         if self._pool is None:
             return
         self.flush()
-        if self._frames == 0:  # an empty stream is still one (empty) frame
+        if self._single:  # the empty last block that closes the frame (with the header, if nothing was written)
+            self._raw.write(self._job(b"", 0, 0, self._frames == 0, True))
+        elif self._frames == 0:  # an empty stream is still one (empty) frame
             self._raw.write(self._compress(b"", 0, 0))
         self._pool.shutdown()
         self._pool = None
+        for ctx in self._ctxs:
+            self._L.ZSTD_freeCCtx(ctx)
+        self._ctxs = []
 
     def __enter__(self):
         return self
@@ -212,21 +263,19 @@ class ParallelZstdWriter:
 
 
 def open_writer(raw, level: int = 3, threads: int = 0, parallel_frames: bool = False):
-    """The CSV writer of the CLIs. Default: ONE zstd frame, as the reference writes it (compressed by
-    ``threads`` libzstd workers where the library was built with them, by the calling thread
-    otherwise -- the ctypes call releases the GIL, so it overlaps with the rest of the pipeline).
-    ``parallel_frames=True`` (``--parallel-zstd-frames``): chunks compressed on up to 8 threads and written
-    as consecutive frames -- 2-3x the writer throughput, but only for consumers that read across
-    frames (``zstd -d``, ``zstandard`` with ``read_across_frames=True``, :func:`decompress`)."""
+    """The CSV writer of the CLIs. Default: ONE zstd frame, as the reference writes it, its 4 MB jobs compressed
+    on up to 8 threads (:class:`ParallelZstdWriter` with ``single_frame=True``; the one-thread :class:`ZstdWriter`
+    if the library lacks the block-level entry points). ``parallel_frames=True`` (``--parallel-zstd-frames``):
+    the same chunks written as consecutive independent frames -- for consumers that read across frames
+    (``zstd -d``, ``zstandard`` with ``read_across_frames=True``, :func:`decompress`); no faster than the default
+    any more, kept for files whose chunks are to be decompressed independently."""
     import os
     if threads <= 0:
         threads = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    if parallel_frames:
-        try:
-            return ParallelZstdWriter(raw, level, threads)
-        except OSError:
-            pass
-    return ZstdWriter(raw, level, threads)
+    try:
+        return ParallelZstdWriter(raw, level, threads, single_frame=not parallel_frames)
+    except OSError:
+        return ZstdWriter(raw, level, threads)
 
 
 def count_frames(data: bytes) -> int:

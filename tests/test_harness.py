@@ -185,6 +185,46 @@ def test_zstd_parallel_frames_roundtrip(threads, chunk):
     assert empty.getvalue()[:4] == b"\x28\xb5\x2f\xfd" and zstd_io.decompress(empty.getvalue()) == b""
 
 
+def _one_shot_decompress(data: bytes, size: int) -> bytes:
+    """libzstd's single-call decoder (a different code path from the streaming one zstd_io.decompress uses); it
+    decodes exactly ONE frame and fails on anything malformed in it."""
+    import ctypes as C
+    L = zstd_io._libzstd()
+    L.ZSTD_decompress.restype = C.c_size_t
+    L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    dst = C.create_string_buffer(max(size, 1))
+    rc = L.ZSTD_decompress(dst, size, data, len(data))
+    assert not L.ZSTD_isError(rc), L.ZSTD_getErrorName(rc)
+    return dst.raw[:rc]
+
+
+@pytest.mark.parametrize("kind", ["csv", "repeats", "constant", "random", "tiny", "empty"])
+@pytest.mark.parametrize("threads,chunk", [(1, 4 << 20), (4, 70001), (8, 1 << 17)])
+def test_zstd_single_frame_jobs(kind, threads, chunk):
+    """The default CLI writer: jobs compressed concurrently by contexts of their own and stitched into ONE frame
+    (job 0's header, rep-codes invalidated at every later job's start, an empty last block). Payloads chosen so that
+    the stitched blocks are compressed (with and without repeat offsets crossing a job boundary), RLE and raw."""
+    rng = np.random.default_rng(3)
+    payload = {
+        "csv": lambda: b"".join(b"r%d,%d,%f\n" % (i, i * 7, x) for i, x in enumerate(rng.standard_normal(40000))),
+        "repeats": lambda: (b"read-0001,12345,12399,77,M,0.999871\n" * 7 + b"read-0001,12399,12405,78,M,0.5\n") * 6000,
+        "constant": lambda: b"\0" * 900000,
+        "random": lambda: rng.integers(0, 256, 700000, dtype=np.uint8).tobytes(),
+        "tiny": lambda: b"x",
+        "empty": lambda: b"",
+    }[kind]()
+    buf = io.BytesIO()
+    with zstd_io.ParallelZstdWriter(buf, level=3, threads=threads, chunk_bytes=chunk, single_frame=True) as w:
+        for i in range(0, len(payload), 99991):
+            w.write(payload[i:i + 99991])
+    out = buf.getvalue()
+    assert zstd_io.count_frames(out) == 1
+    assert zstd_io.decompress(out) == payload
+    assert _one_shot_decompress(out, len(payload)) == payload
+    if kind in ("csv", "repeats", "constant"):
+        assert len(out) < len(payload) // 2
+
+
 def test_cli_writer_is_one_frame_by_default(tmp_path):
     """python-zstandard's default readers stop after the first frame, so the CLI must write ONE frame
     like the reference (segment.py:74-79) unless the user opts into parallel frames."""
