@@ -876,7 +876,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   while (((uint64_t)max_T + 1 + ((1ull << log_r) - 1)) >> log_r > (uint64_t)dynk::PT_MAX) ++log_r;
   const uint64_t page_rows = 1ull << log_r;
   auto pages_of = [&](uint64_t S) { return (uint32_t)((S + 2 + page_rows - 1) >> log_r); };  // rows 0 .. T = S+1
-  const size_t n_slots = std::min<size_t>(order.size(), (size_t)a->n_cus * 4);
+  const size_t n_slots = std::min<size_t>(order.size(), (size_t)a->n_cus * dynk::WAVES_PER_CU);
   uint64_t wanted = 0;  // pages that keep every wave slot busy: the n_slots longest reads at once
   for (size_t k = 0; k < n_slots; ++k) wanted += pages_of(b->reads[order[k]].S);
 
@@ -1055,7 +1055,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   tm.pool_pages = pool.n_pages;
   tm.page_rows = (uint32_t)page_rows;
   tm.n_static = n_static;
-  tm.n_waves = (uint32_t)std::min<size_t>((order.size() + 3) / 4 * 4, (size_t)a->n_cus * 4);
+  tm.n_waves = (uint32_t)std::min<size_t>((order.size() + dynk::WAVES_PER_CU - 1) / dynk::WAVES_PER_CU * dynk::WAVES_PER_CU,
+                                         (size_t)a->n_cus * dynk::WAVES_PER_CU);
   b->timing = tm;
   b->n_chunks = nr ? 1 : 0;
   b->aligned = job != DynJob::Train;

@@ -53,12 +53,13 @@
 // streams with 7-way ILP that saturate a SIMD on their own, so they are compiled for exactly one
 // wave per SIMD: the dispatcher must then spread the waves over all 1 024 SIMDs, and the whole
 // 512-entry register file is available to keep the interleaved chains out of AGPR spills.
-#define DYN_ONE_WAVE_PER_SIMD __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define DYN_ONE_WAVE_PER_SIMD \
+  __launch_bounds__(256 * DYN_WAVES_PER_SIMD) __attribute__((amdgpu_waves_per_eu(DYN_WAVES_PER_SIMD, DYN_WAVES_PER_SIMD)))
 
 // FOUR waves per 256-thread workgroup (one per SIMD of a CU): they never synchronise after the
 // prologue, they only share the 82 KB softplus table that the workgroup stages into the CU's LDS once
 // (dp_math.hpp, softplus_table_vec).
-#define DYN_WAVES_PER_GROUP 4
+#define DYN_WAVES_PER_GROUP (4 * DYN_WAVES_PER_SIMD)
 
 namespace dynk {
 
@@ -213,7 +214,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // AGPRs mid-row). The rows now go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, 3 full +
 // 1 half-wave instruction per 3584-byte row), RING_D rows ahead, and are picked up with ds_read_b64
 // behind a hand-counted s_waitcnt. Validated in isolation by tools/ubench/lds_dma_test.hip.
-constexpr int RING_D = 4;  // 2..5 rows deep measure the same: the sweep is bandwidth-, not latency-bound
+constexpr int RING_D = DYN_WAVES_PER_SIMD == 1 ? 4 : 2;  // 2..5 rows deep measure the same: the sweep is bandwidth-, not latency-bound
 constexpr int ROW_BYTES = P * 8;
 // vmcnt(N) lets the N youngest vector-memory operations stay in flight. Only the DMA instructions
 // themselves are counted (4 per row, RING_D-1 younger rows => 12): loads retire in issue order, so
@@ -1018,7 +1019,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
   __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
   __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
-  for (int i = threadIdx.x; i < SP_NODES; i += 256) s_tab[i] = sp_tab[i];
+  for (int i = threadIdx.x; i < SP_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
   __syncthreads();
   // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
   // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /
@@ -1407,7 +1408,7 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
 void launch_read_queue(QueueJob job, const QueueArgs& q, int n_cus, hipStream_t s) {
   if (q.n_reads <= 0) return;
   const int groups = std::min((q.n_reads + DYN_WAVES_PER_GROUP - 1) / DYN_WAVES_PER_GROUP, std::max(1, n_cus));
-  const dim3 grid(groups), block(256);
+  const dim3 grid(groups), block(64 * DYN_WAVES_PER_GROUP);
   switch (job) {
     case JOB_Z: hipLaunchKernelGGL(k_read_queue<JOB_Z>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
     case JOB_ALIGN: hipLaunchKernelGGL(k_read_queue<JOB_ALIGN>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;

@@ -26,6 +26,11 @@ constexpr int MAX_HALF_BAND = (P - 2) / 2;   // 2*bw+1 <= P-1  ->  bw <= 223 (ba
 // backward sweep until its traceback is done. A wave keeps the page numbers of its current read in
 // LDS (PT_MAX entries), so rows_per_page is chosen per launch such that the longest read fits.
 constexpr int PT_MAX = 512;
+// Waves per SIMD of the read queue (an experiment switch: 2 = eight waves per CU, a 2-deep row ring)
+#ifndef DYN_WAVES_PER_SIMD
+#define DYN_WAVES_PER_SIMD 1
+#endif
+constexpr int WAVES_PER_CU = 4 * DYN_WAVES_PER_SIMD;
 constexpr uint32_t NO_PAGE = 0xffffffffu;
 
 struct ReadDesc {
