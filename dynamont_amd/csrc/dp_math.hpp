@@ -114,9 +114,9 @@ DYN_HD double log_plus(double x, double y) {
 // Per-k-mer emission constants kept with each band slot.
 struct Emis {
   double mean;
-  double inv_stdev;  // 1/stdev rounded to nearest
-  double log_norm;   // -log(stdev) - 0.5*log(2*pi); std::log evaluated on the host by the libm the reference calls
-  double stdev;      // only for log_normal_pdf_exact (host tests)
+  double inv_stdev;      // 1/stdev rounded to nearest
+  double neg_log_stdev;  // -log(stdev); std::log evaluated on the host by the libm the reference calls
+  double stdev;          // only for log_normal_pdf_exact (host tests)
 };
 
 constexpr double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;  // 0.5*log(2*pi) = 0.91893853320467274178
@@ -137,20 +137,29 @@ DYN_HD double log_normal_pdf_exact(double x, double mean, double stdev, double l
   return t - HALF_LOG_2PI;
 }
 
-// The kernels' emission: z = diff * (1/stdev), e = fma(-0.5*z, z, log_norm): 4 fp64 operations per
-// cell instead of 8. Differs from the expression above by a few ulp of |z^2/2| + |log_norm| (the
-// quotient is not corrected and the two constants are pre-added); the chip is power-limited on fp64
-// operations, and the differences are 1e-16-level, like those of the softplus.
+// The kernels' emission, 5 fp64 operations instead of 8:
+//   z = diff * (1/stdev);  t = z*z;  e = fma(t, -0.5, -log(stdev)) - 0.5*log(2*pi)
+// The tail rounds exactly like the reference's (-0.5*z*z - log(stdev)) - 0.5*log(2*pi): halving is exact,
+// so fma(t, -0.5, c) = RN(RN(-0.5 z z) + c). Only the quotient is not corrected (z differs from diff/stdev
+// in its last bit in a fraction of the cases). Why not fewer: rounds 1-2 pre-added the two constants and
+// fused them into one FMA (4 operations; a 3-operation form with 1/(stdev sqrt 2) was tried too). Where two
+// neighbouring columns carry the same k-mer the traceback's comparison is a tie in exact arithmetic and
+// the reference's choice rests on the last bits of exactly these sums: replaying the
+// oracle's control flow with each candidate arithmetic on 1 000 short reads (tests/tie_parity.py), the
+// 3-, 4- and 5-operation forms give 17, 11 and 3 reads whose borders differ from the reference's -- 3 is
+// also what the fully corrected 8-operation form gives (the rest is the <= 1 ulp of the logPlus).
 DYN_HD double log_normal_pdf(double x, const Emis& p) {
   const double z = (x - p.mean) * p.inv_stdev;
-  return fma_(-0.5 * z, z, p.log_norm);
+  const double t = z * z;
+  return fma_(t, -0.5, p.neg_log_stdev) - HALF_LOG_2PI;
 }
 
-DYN_HD Emis make_emis(double mean, double stdev, double log_stdev) {
+// Host only (model load).
+inline Emis make_emis(double mean, double stdev, double log_stdev) {
   Emis e;
   e.mean = mean;
   e.inv_stdev = 1.0 / stdev;
-  e.log_norm = -log_stdev - HALF_LOG_2PI;
+  e.neg_log_stdev = -log_stdev;
   e.stdev = stdev;
   return e;
 }
@@ -167,9 +176,15 @@ DYN_HD Emis make_emis(double mean, double stdev, double log_stdev) {
 // higher derivative is a polynomial in s:  with u = s(1-s), w = 1-2s
 //   g2 = u,  g3 = u w,  g4 = u (1-6u),  g5 = u w (1-12u),  |g6| <= 1/4      (gk = k-th derivative)
 // A table of (g, s) at the nodes d_i = -i/128, i = 0..5120 (81 936 bytes, one copy in the LDS of
-// each CU) plus the degree-5 Taylor polynomial about the NEAREST node (|r| <= 1/256) gives
-// |error| <= 1/4 (1/256)^6 / 720 = 1.2e-18 + the rounding of g_i and of the last FMA, i.e. the
-// same <= ~1 ulp class as the polynomial form above at 24 instead of 45 fp64 instructions.
+// each CU) plus the degree-5 Taylor polynomial about the NEAREST node (|r| <= 1/256), written with the
+// common factor u r pulled out of the upper terms,
+//   g(d_i + r) = g_i + r ( s + (u r) ( 1/2 + r ( w/6 + r ( (1-6u)/24 + r w (1-12u)/120 ) ) ) ),
+// costs 13 fp64 operations after the lookup (the plain Horner form of rounds 1-2 took 16).
+// |error| <= 1/4 (1/256)^6 / 720 = 1.2e-18 + the rounding of g_i and of the last FMA, i.e. the same
+// <= ~1 ulp class as glibc's log1p(exp(d)). That class is not a luxury: where two neighbouring columns
+// carry the same k-mer the traceback's comparison is a tie in exact arithmetic and the reference's
+// choice rests on the last bits of its logPlus; a degree-4 polynomial (1.0e-15,
+// 4 operations fewer, +6.6 % throughput) was measured and flipped such a decision in the fuzz tests.
 // d <= -40 (incl. -inf and NaN, clamped) maps to the last node, which holds (0, 0): g = 0 exactly.
 // ---------------------------------------------------------------------------------------------
 struct SoftplusNode {
@@ -178,6 +193,9 @@ struct SoftplusNode {
 constexpr int SP_STEPS = 128;                   // nodes per unit of d
 constexpr int SP_RANGE = 40;                    // table covers d in [-40, 0]
 constexpr int SP_NODES = SP_STEPS * SP_RANGE + 1;
+// 1.5 * 2^52: adding it to a value in [0, 2^31) rounds that value to the nearest integer (ties to
+// even, like rint) and leaves the integer in the low 32 bits of the sum's bit pattern.
+constexpr double SP_MAGIC = 0x1.8p52;
 
 // Host-side generator (long double arithmetic, rounded once to double).
 inline void softplus_build_table(SoftplusNode* t) {
@@ -189,47 +207,14 @@ inline void softplus_build_table(SoftplusNode* t) {
   }
 }
 
-template <int M>
-DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNode* __restrict__ tab) {
-  double kf[M], r[M], g0[M], s[M], u[M], w[M], uw[M], p[M], q[M];
-#pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -(double)SP_RANGE);  // also NaN -> -40
-#pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * -(double)SP_STEPS);
-#pragma unroll
-  for (int j = 0; j < M; ++j) r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);          // exact
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-    const SoftplusNode nd = tab[(int)kf[j]];
-    g0[j] = nd.g;
-    s[j] = nd.s;
-  }
-#pragma unroll
-  for (int j = 0; j < M; ++j) w[j] = 1.0 - s[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) u[j] = s[j] * w[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) w[j] = w[j] - s[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], q[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], uw[j] * (1.0 / 6.0));
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], u[j] * 0.5);
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], r[j], s[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) g[j] = fma_(p[j], r[j], g0[j]);
+DYN_HD int low_word(double m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __double2loint(m);
+#else
+  unsigned long long b;
+  __builtin_memcpy(&b, &m, 8);
+  return (int)(unsigned)(b & 0xffffffffull);
+#endif
 }
 
 // Two-phase form of the table-driven logPlus so that independent work (the next row's emission)
@@ -240,23 +225,35 @@ struct SoftplusLookup {
   double hi[M], r[M], g0[M], s[M];
 };
 
+// d = lo - hi = -|x - y| (a correctly rounded difference has the same magnitude either way round);
+// node index k = rint(-128 d) by the magic-number addition, r = d + k/128 exactly. 5 fp64 operations
+// + the max for hi (the reference form min, sub, clamp, mul, rndne, cvt, fma took 8).
 template <int M>
 DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusLookup<M>& L,
                            const SoftplusNode* __restrict__ tab) {
-  double d[M], kf[M];
+  double d[M], m[M], kf[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) L.hi[j] = __builtin_fmax(x[j], y[j]);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Pins the max HERE, next to the additions that produced x and y. Left alone, hipcc sinks it to its use in
+  // log_plus_finish; where a branch lies in between (backward sweep) it no longer knows the operands to be
+  // canonical there and quiets both with a v_max_f64 v, v, v first: two extra fp64 instructions per cell.
 #pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmin(x[j], y[j]) - L.hi[j];
+  for (int j = 0; j < M; ++j) asm volatile("" : "+v"(L.hi[j]));
+#endif
 #pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -(double)SP_RANGE);  // also NaN -> -40
+  for (int j = 0; j < M; ++j) d[j] = x[j] - y[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = __builtin_rint(d[j] * -(double)SP_STEPS);
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(-__builtin_fabs(d[j]), -(double)SP_RANGE);  // also NaN -> -40
 #pragma unroll
-  for (int j = 0; j < M; ++j) L.r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);  // exact
+  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], -(double)SP_STEPS, SP_MAGIC);
+#pragma unroll
+  for (int j = 0; j < M; ++j) kf[j] = m[j] - SP_MAGIC;                       // exact
+#pragma unroll
+  for (int j = 0; j < M; ++j) L.r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);    // exact
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    const SoftplusNode nd = tab[(int)kf[j]];
+    const SoftplusNode nd = tab[low_word(m[j])];
     L.g0[j] = nd.g;
     L.s[j] = nd.s;
   }
@@ -264,44 +261,54 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
 
 template <int M>
 DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
-  double u[M], w[M], uw[M], p[M], q[M];
+  double u[M], w[M], p[M], q[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
 #pragma unroll
   for (int j = 0; j < M; ++j) u[j] = L.s[j] * w[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
+  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];                          // w = 1 - 2s (exact)
 #pragma unroll
   for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
+  for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];                             // g5/(5! u)
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
+  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], -0.25, 1.0 / 24.0);           // (1 - 6u)/24 = g4/(4! u)
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
+  for (int j = 0; j < M; ++j) p[j] = fma_(q[j], L.r[j], p[j]);
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], q[j]);
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], w[j] * (1.0 / 6.0));
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], uw[j] * (1.0 / 6.0));
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], 0.5);
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], u[j] * 0.5);
+  for (int j = 0; j < M; ++j) u[j] = u[j] * L.r[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.s[j]);
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], u[j], L.s[j]);
 #pragma unroll
   for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
 }
 
+// softplus alone (tests): the same lookup and polynomial for d <= 0.
+template <int M>
+DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNode* __restrict__ tab) {
+  double zero[M];
+  SoftplusLookup<M> L;
+#pragma unroll
+  for (int j = 0; j < M; ++j) zero[j] = 0.0;
+  log_plus_issue<M>(zero, d, L, tab);  // hi = 0 for d <= 0
+  log_plus_finish<M>(L, g);
+}
+
 // log_plus_finish plus the logistic value sigma(d) = e^d / (1 + e^d) at the SAME argument d = lo - hi:
-// sigma is the first derivative of the softplus, so it is the derivative of the same Taylor polynomial
-// about the same node (4 more FMAs; truncation <= |g6|/120 * (1/256)^5 = 1.9e-15 * u, relative to a
-// value in (0, 1/2]). exp(lo - logPlus(x, y)) = sigma and exp(hi - logPlus(x, y)) = 1 - sigma: the
-// shares of the two operands in the sum, which is what the training pass needs (nt_kernels.hip,
-// forward_train_sweep) -- without an exponential. d <= -40 (and -inf, NaN) gives sigma = 0 exactly.
+// sigma is the first derivative of the softplus, so it is the derivative of the same polynomial,
+//   sigma(d_i + r) = s + (u r) ( 1 + r ( w/2 + r ( (1-6u)/6 + r w (1-12u)/24 ) ) )
+// (5 more operations; truncation <= |g6|/120 (1/256)^5 = 1.9e-15 u, relative to a value in (0, 1/2]).
+// exp(lo - logPlus(x, y)) = sigma and exp(hi - logPlus(x, y)) = 1 - sigma: the shares of the two
+// operands in the sum, which is what the training pass needs (nt_kernels.hip, forward_train_sweep) --
+// without an exponential. d <= -40 (and -inf, NaN) gives sigma = 0 exactly.
 template <int M>
 DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
-  double u[M], w[M], uw[M], p[M], q[M], dp[M];
+  double u[M], w[M], p[M], q[M], dp[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
 #pragma unroll
@@ -309,31 +316,29 @@ DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], 
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) uw[j] = u[j] * w[j];
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
+  for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = uw[j] * q[j];                              // g5/5!
+  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], -0.25, 1.0 / 24.0);
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -6.0 / 24.0, 1.0 / 24.0);      // (1 - 6u)/24
+  for (int j = 0; j < M; ++j) dp[j] = fma_(q[j] * 5.0, L.r[j], p[j] * 4.0);   // (1-6u)/6 + r w (1-12u)/24
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = u[j] * q[j];                               // g4/4!
+  for (int j = 0; j < M; ++j) p[j] = fma_(q[j], L.r[j], p[j]);
 #pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(p[j] * 5.0, L.r[j], q[j] * 4.0);     // derivative: 5 c5 r + 4 c4
+  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], w[j] * 0.5);
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], q[j]);
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], w[j] * (1.0 / 6.0));
 #pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], uw[j] * 0.5);         // + 3 c3
+  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], 1.0);
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], uw[j] * (1.0 / 6.0));
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], 0.5);
 #pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], u[j]);                // + 2 c2
+  for (int j = 0; j < M; ++j) u[j] = u[j] * L.r[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], u[j] * 0.5);
+  for (int j = 0; j < M; ++j) sig[j] = fma_(dp[j], u[j], L.s[j]);
 #pragma unroll
-  for (int j = 0; j < M; ++j) sig[j] = fma_(dp[j], L.r[j], L.s[j]);             // + c1
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.s[j]);
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], u[j], L.s[j]);
 #pragma unroll
   for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
 }
@@ -381,25 +386,27 @@ DYN_HD void exp_vec(double (&d)[M], double (&out)[M]) {
 // Structure-of-arrays emission constants of the M cells of a lane.
 template <int M>
 struct EmisV {
-  double mean[M], inv_stdev[M], log_norm[M];
+  double mean[M], inv_stdev[M], neg_log_stdev[M];
   DYN_HD void set(int j, const Emis& e) {
     mean[j] = e.mean;
     inv_stdev[j] = e.inv_stdev;
-    log_norm[j] = e.log_norm;
+    neg_log_stdev[j] = e.neg_log_stdev;
   }
 };
 
 template <int M>
 DYN_HD void log_normal_pdf_vec(double x, const EmisV<M>& p, double (&out)[M]) {
-  double diff[M], z[M], h[M];
+  double z[M];
 #pragma unroll
-  for (int j = 0; j < M; ++j) diff[j] = x - p.mean[j];
+  for (int j = 0; j < M; ++j) z[j] = x - p.mean[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) z[j] = diff[j] * p.inv_stdev[j];
+  for (int j = 0; j < M; ++j) z[j] = z[j] * p.inv_stdev[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) h[j] = -0.5 * z[j];
+  for (int j = 0; j < M; ++j) z[j] = z[j] * z[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = fma_(h[j], z[j], p.log_norm[j]);
+  for (int j = 0; j < M; ++j) z[j] = fma_(z[j], -0.5, p.neg_log_stdev[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = z[j] - HALF_LOG_2PI;
 }
 
 }  // namespace dynmath

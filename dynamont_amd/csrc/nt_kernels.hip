@@ -165,7 +165,7 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   } else {  // column without a k-mer (n <= 0 or n >= N): log-density -inf (log_norm = -inf)
     e.mean = 0.0;
     e.inv_stdev = 1.0;
-    e.log_norm = NEG_INF;
+    e.neg_log_stdev = NEG_INF;
     e.stdev = 1.0;
   }
   return e;
@@ -407,6 +407,14 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 // Returns Zf = forwardE[T*B - bandwidth - 2] = fE(T-1, mid(T-1))  (NT_aligner_api.cpp:285).
 // ---------------------------------------------------------------------------------------------
 // INPLACE (only with POST): see the comment at lat_lp below
+// max of two values the compiler cannot prove canonical (loop-carried): fmax() makes hipcc quiet each operand with
+// a v_max_f64 v, v, v first -- three fp64 instructions instead of one. vM and vE are sums or -inf, never signalling.
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <bool POST, bool INPLACE>
 __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                 const double* __restrict__ sig, const Emis* __restrict__ par,
@@ -528,7 +536,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
 #pragma unroll
         for (int j = 0; j < CPL; ++j) vMn[j] = vEl[j] + LPM[j];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) vEn[j] = fmax(vM[j], vE[j]) + LPE[j];
+        for (int j = 0; j < CPL; ++j) vEn[j] = max_f64(vM[j], vE[j]) + LPE[j];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
 #pragma unroll

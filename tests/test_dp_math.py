@@ -139,8 +139,8 @@ def test_log_normal_pdf_bit_identical(mathlib, oracle_built):
 
 
 def test_kernel_emission_within_a_few_ulp_of_the_reference_expression(mathlib):
-    """The kernels run the 4-operation emission (uncorrected quotient, pre-added constants); it must
-    stay within a few ulp of the terms it adds, and handle the 'no k-mer' and non-finite cases."""
+    """The kernels run the 5-operation emission (uncorrected quotient, the reference's rounding sequence after
+    it); it must stay within a few ulp of the terms it adds and be bit-identical most of the time."""
     rng = np.random.default_rng(3)
     n = 49 * 1000
     x = rng.standard_normal(n) * 3
@@ -156,7 +156,7 @@ def test_kernel_emission_within_a_few_ulp_of_the_reference_expression(mathlib):
     z2 = 0.5 * ((x - mean) / sd) ** 2
     scale = np.spacing(z2 + np.abs(np.log(sd)) + 0.92)
     err = np.abs(fast - exact) / scale
-    assert err.max() <= 4.0 and np.mean(fast == exact) > 0.3, (err.max(), np.mean(fast == exact))
+    assert err.max() <= 4.0 and np.mean(fast == exact) > 0.6, (err.max(), np.mean(fast == exact))
 
 
 def _grid7(rng):
