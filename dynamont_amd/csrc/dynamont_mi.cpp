@@ -381,8 +381,9 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
                      hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy(model)");
   {
-    std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES);
+    std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES + dynmath::EXP_TAB_NODES);
     dynmath::softplus_build_table(tab.data());
+    dynmath::exp_build_table(reinterpret_cast<double*>(tab.data() + dynmath::SP_NODES));  // 2^(i/64), training pass
     if ((e = a->d_sptab.ensure(sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess) return fail(e, "hipMalloc(softplus table)");
     if ((e = hipMemcpy(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
       return fail(e, "hipMemcpy(softplus table)");

@@ -848,13 +848,13 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
       dynmath::log_plus_finish_sigma<CPL>(L, fEn, sgm);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) aE[j] = (fEn[j] + bcur[j]) - Z;
-      dynmath::exp_vec<CPL>(aE, gE);
+      dynmath::exp_vec<CPL>(aE, gE, reinterpret_cast<const double*>(s_tab + SP_NODES));
       const double xt2 = xt * xt, xp2 = xp * xp;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         const double shareE = (op2[j] >= x1[j]) ? 1.0 - sgm[j] : sgm[j];  // share of the arrival from E
         const double gT = gE[j] * shareE;             // E(t-1,n) -> E(t,n)
-        const double gMp = gE[j] * (1.0 - shareE);    // = exp(LPM(t-1,n))
+        const double gMp = gE[j] - gT;                // = exp(LPM(t-1,n)): the rest of the cell's mass
         aw[j] = (aw[j] + gE[j]) + gMp;
         a1[j] = dynmath::fma_(gMp, xp, dynmath::fma_(gE[j], xt, a1[j]));
         a2[j] = dynmath::fma_(gMp, xp2, dynmath::fma_(gE[j], xt2, a2[j]));
@@ -1024,10 +1024,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
                                                    const double* __restrict__ sig, const Emis* __restrict__ par,
                                                    const SoftplusNode* __restrict__ sp_tab) {
   constexpr bool LATTICE = JOB != JOB_Z;
-  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES];
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES + dynmath::EXP_TAB_NODES];  // + 2^(i/64) (exp_vec)
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
   __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
-  for (int i = threadIdx.x; i < SP_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
+  for (int i = threadIdx.x; i < SP_NODES + dynmath::EXP_TAB_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
   __syncthreads();
   // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
   // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /

@@ -53,7 +53,9 @@ void eval_exp_vec(const double* d, double* out, long n) {
   for (long i = 0; i + 7 <= n; i += 7) {
     double a[7], g[7];
     for (int j = 0; j < 7; ++j) a[j] = d[i + j];
-    dynmath::exp_vec<7>(a, g);
+    static double ET[dynmath::EXP_TAB_SIZE]; static bool init = false;
+    if (!init) { dynmath::exp_build_table(ET); init = true; }
+    dynmath::exp_vec<7>(a, g, ET);
     for (int j = 0; j < 7; ++j) out[i + j] = g[j];
   }
 }
