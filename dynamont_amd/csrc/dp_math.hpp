@@ -207,6 +207,27 @@ inline void softplus_build_table(SoftplusNode* t) {
   }
 }
 
+// A constant the compiler must keep in ONE vector register pair. gfx9 VALU instructions read at most one
+// scalar/literal operand, so fma(x, c1, c2) with two non-inline constants gets c2 through the accumulator of a
+// v_fmac_f64 -- which hipcc re-materialises for EVERY cell (v_mov_b32 x 2 per cell and FMA: 14-28 extra
+// instructions per row and lookup). Hidden behind an empty asm it is loaded once and used as the third
+// operand of a v_fma_f64.
+DYN_HD double vreg_const(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(c));
+#endif
+  return c;
+}
+
+// The multiplier of such an FMA, kept in a scalar register pair: left as a literal it forces the VOP2 encoding
+// (v_fmac_f64 with its destructive accumulator, hence a copy of the addend per cell); VOP3 has no literals on gfx9.
+DYN_HD double sreg_const(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(c));
+#endif
+  return c;
+}
+
 DYN_HD int low_word(double m) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __double2loint(m);
@@ -232,6 +253,7 @@ template <int M>
 DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusLookup<M>& L,
                            const SoftplusNode* __restrict__ tab) {
   double d[M], m[M], kf[M];
+  const double magic = vreg_const(SP_MAGIC), neg_steps = sreg_const(-(double)SP_STEPS);
 #pragma unroll
   for (int j = 0; j < M; ++j) L.hi[j] = __builtin_fmax(x[j], y[j]);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -246,9 +268,9 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
 #pragma unroll
   for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(-__builtin_fabs(d[j]), -(double)SP_RANGE);  // also NaN -> -40
 #pragma unroll
-  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], -(double)SP_STEPS, SP_MAGIC);
+  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], neg_steps, magic);
 #pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = m[j] - SP_MAGIC;                       // exact
+  for (int j = 0; j < M; ++j) kf[j] = m[j] - magic;                          // exact
 #pragma unroll
   for (int j = 0; j < M; ++j) L.r[j] = fma_(kf[j], 1.0 / SP_STEPS, d[j]);    // exact
 #pragma unroll
@@ -262,6 +284,8 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
 template <int M>
 DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
   double u[M], w[M], p[M], q[M];
+  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
+  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
 #pragma unroll
@@ -269,11 +293,11 @@ DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];                          // w = 1 - 2s (exact)
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);  // (1 - 12u)/120
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], m10, c120);                   // (1 - 12u)/120
 #pragma unroll
   for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];                             // g5/(5! u)
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], -0.25, 1.0 / 24.0);           // (1 - 6u)/24 = g4/(4! u)
+  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], m4, c24);                     // (1 - 6u)/24 = g4/(4! u)
 #pragma unroll
   for (int j = 0; j < M; ++j) p[j] = fma_(q[j], L.r[j], p[j]);
 #pragma unroll
@@ -309,6 +333,8 @@ DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNod
 template <int M>
 DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
   double u[M], w[M], p[M], q[M], dp[M];
+  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
+  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
 #pragma unroll
@@ -316,11 +342,11 @@ DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], 
 #pragma unroll
   for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], -12.0 / 120.0, 1.0 / 120.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], m10, c120);
 #pragma unroll
   for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], -0.25, 1.0 / 24.0);
+  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], m4, c24);
 #pragma unroll
   for (int j = 0; j < M; ++j) dp[j] = fma_(q[j] * 5.0, L.r[j], p[j] * 4.0);   // (1-6u)/6 + r w (1-12u)/24
 #pragma unroll
@@ -365,12 +391,14 @@ DYN_HD void exp_vec(double (&d)[M], double (&out)[M], const double* __restrict__
   const double LN2_64_LO = 0x1.a39ef35793c76p-39;
   double m[M], kf[M], r[M], q[M], T[M];
   int k[M];
+  const double magic = vreg_const(SP_MAGIC), c24 = vreg_const(1.0 / 24.0);
+  const double inv = sreg_const(INV), c120 = sreg_const(1.0 / 120.0);
 #pragma unroll
   for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -1000.0);
 #pragma unroll
-  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], INV, SP_MAGIC);
+  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], inv, magic);
 #pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = m[j] - SP_MAGIC;
+  for (int j = 0; j < M; ++j) kf[j] = m[j] - magic;
 #pragma unroll
   for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_64_HI, d[j]);
 #pragma unroll
@@ -380,7 +408,7 @@ DYN_HD void exp_vec(double (&d)[M], double (&out)[M], const double* __restrict__
 #pragma unroll
   for (int j = 0; j < M; ++j) T[j] = tab[k[j] & (EXP_TAB_SIZE - 1)];
 #pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], 1.0 / 120.0, 1.0 / 24.0);
+  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], c120, c24);
 #pragma unroll
   for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], 1.0 / 6.0);
 #pragma unroll
