@@ -11,7 +11,9 @@ from this module's C++ shim, which calls dp_math.hpp compiled for the host.
 
 Modes of the shim: 0 = libm (must reproduce the oracle exactly), 1 = the product (dp_math.hpp as it stands),
 2 = the 4-operation emission of rounds 1-2 (constants pre-added, one FMA), 3 = a 3-operation emission
-(1/(stdev sqrt 2) folded into the constant), 4 = the product's logPlus with the reference's emission.
+(1/(stdev sqrt 2) folded into the constant), 4 = the product's logPlus with the reference's emission,
+5 = the product's emission with the difference folded into an FMA (z = fma(x, 1/stdev, -mean/stdev), one operation
+fewer). Measured on 1 000 reads: 0 / 3 / 11 / 17 / 3 / 14 reads differ.
 """
 from __future__ import annotations
 
@@ -50,6 +52,8 @@ extern "C" double nto_hook_pdf(double x, double mean, double sd) {
     case 2: { const double z = (x - mean) * (1.0 / sd); return dynmath::fma_(-0.5 * z, z, -std::log(sd) - dynmath::HALF_LOG_2PI); }
     case 3: { const double k = (double)(1.0L / ((long double)sd * 1.41421356237309504880168872420969808L));
               const double y = (x - mean) * k; return dynmath::fma_(-y, y, -std::log(sd) - dynmath::HALF_LOG_2PI); }
+    case 5: { const double inv = 1.0 / sd; const double z = dynmath::fma_(x, inv, -(mean * inv)); const double t = z * z;
+              return dynmath::fma_(t, -0.5, -std::log(sd)) - dynmath::HALF_LOG_2PI; }
     default: return dynmath::log_normal_pdf(x, dynmath::make_emis(mean, sd, std::log(sd)));
   }
 }
@@ -143,7 +147,7 @@ if __name__ == "__main__":
     rp = Replay(build_replay(d), path, synth.PORES[pore][0], 400)
     for mode, name in ((0, "libm primitives (sanity: the oracle itself)"), (1, "product arithmetic (dp_math.hpp)"),
                        (4, "reference emission + product logPlus"), (2, "4-operation emission of rounds 1-2 + product logPlus"),
-                       (3, "3-operation emission + product logPlus")):
+                       (3, "3-operation emission + product logPlus"), (5, "z = fma(x, 1/sd, -mean/sd), reference tail + product logPlus")):
         rp.set_mode(mode)
         bad = differing_reads(rp, reads, want)
         print(f"{name:55s}: {len(bad):3d} of {sum(w is not None for w in want)} reads with borders differing from the reference")
