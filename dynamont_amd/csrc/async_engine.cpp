@@ -115,6 +115,12 @@ void Pipeline::front_loop() {
       q_front.pop_front();
     }
     const int rc = front_stage(b);
+    if (rc != DYN_OK && !a->host_only) {
+      // whatever part of the batch was already enqueued must have left the GPU before the caller may tear it down
+      for (hipStream_t st : {a->s_in, a->stream, a->s_out})
+        if (st) (void)hipStreamSynchronize(st);
+      (void)hipGetLastError();
+    }
     {
       std::lock_guard<std::mutex> lk(m);
       b->rc = rc;
@@ -200,8 +206,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   rc = enqueue_job(b, b->job);  // records ev_done behind the batch's last kernel
   if (rc != DYN_OK) {
     b->error = a->last_error;
-    (void)hipStreamSynchronize(a->stream);  // nothing of this batch may still be running when it is torn down
-    return rc;
+    return rc;  // front_loop drains the streams of a failed batch
   }
   P_TRY(b, hipStreamWaitEvent(a->s_out, b->ev_done, 0));
   // D2H into pinned per-batch buffers on the copy-out stream

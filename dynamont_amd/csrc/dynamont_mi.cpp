@@ -645,7 +645,7 @@ int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count) {
 
 void dyn_batch_destroy(dyn_batch* b) {
   if (!b) return;
-  if (b->async && !b->done && b->a && b->a->pipe) (void)b->a->pipe->wait(b);
+  if (b->async && b->a && b->a->pipe) (void)b->a->pipe->wait(b);  // returns at once when the batch is done
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
