@@ -365,10 +365,12 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(x1, x2, L, s_tab);
       // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
-      // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: that one
-      //  emission is computed after the block switch below)
-      if (i > 0) {
-        const double xnext = readlane_f64(xs, i - 1);
+      // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: the value computed
+      //  here is thrown away and that one emission is computed after the block switch above. Unconditional on
+      //  purpose: behind an `if (i > 0)` the seven results are merged with the old ones by a register move each,
+      //  in every row)
+      {
+        const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
         log_normal_pdf_vec<CPL>(xnext, p, e);
       }
       log_plus_finish<CPL>(L, ne);
