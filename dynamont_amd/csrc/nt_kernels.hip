@@ -294,7 +294,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
   int lo = band_mid(T - 1, ratio) - bw;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
   int n[CPL];
-  double bE[CPL], bM[CPL], e[CPL];
+  double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], e[CPL];
   EmisV<CPL> p;
   {
     // one row past the lattice, all -inf: bM(T-1, .) = bE(T, .) + e has no successor. It lets the
@@ -321,18 +321,19 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
     log_normal_pdf_vec<CPL>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
-#pragma unroll 1
-    for (int i = 63; i >= ilo; --i) {
+    // one lattice row: reads (bE_in, bM_in) = row t+1, writes (bE_out, bM_out) = row t; the loop is unrolled by two and
+    // ping-pongs between the two pairs (see forward_sweep: no register moves at the loop's back edge)
+    auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
       const int t = base + i;
       // e[] = e(t+1, n) was computed during the previous row's table lookups (software pipeline)
-      double Y[CPL], A[CPL], Yr[CPL], x1[CPL], x2[CPL], ne[CPL];
+      double Y[CPL], Yr[CPL], x1[CPL], x2[CPL];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) Y[j] = bM[j] + e[j];
+      for (int j = 0; j < CPL; ++j) Y[j] = bM_in[j] + e[j];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) A[j] = bE[j] + e[j];
+      for (int j = 0; j < CPL; ++j) bM_out[j] = bE_in[j] + e[j];  // bM(t, n) ("A" below)
       from_right(Y, Yr);
       const int new_lo = band_mid(t, ratio) - bw;
-      if (new_lo != lo) {  // wave-uniform: the window moved down by one column
+      if (__builtin_expect(new_lo != lo, 0)) {  // wave-uniform: the window moved down by one column
         const int leaving = lo + P - 1;
         const int top = lo + W - 1;  // last band column of row t+1: above the band of row t
         // uniform address, outside the per-lane branch: a scalar load (lgkmcnt). A vector load here
@@ -352,7 +353,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
           // ring neighbour, band column lo, in every row (the slot ring wraps) and is emptied by
           // e = -inf before anything reads it.
           if (n[j] == top) {
-            A[j] = NEG_INF;
+            bM_out[j] = NEG_INF;
             p.set(j, none);
           }
         }
@@ -361,7 +362,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) x2[j] = A[j] + e2;
+      for (int j = 0; j < CPL; ++j) x2[j] = bM_out[j] + e2;
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(x1, x2, L, s_tab);
       // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
@@ -373,15 +374,24 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
         log_normal_pdf_vec<CPL>(xnext, p, e);
       }
-      log_plus_finish<CPL>(L, ne);
+      log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
+      // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
+      if (STORE) store_row_f64<true>(out + rt, lane, bE_out);
+    };
+    int i = 63;
+#pragma unroll 1
+    for (; i - 1 >= ilo; i -= 2) {
+      row(i, bE, bM, bE2, bM2);
+      row(i - 1, bE2, bM2, bE, bM);
+    }
+    if (i >= ilo) {  // odd number of rows (first block of a read only)
+      row(i, bE, bM, bE2, bM2);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        bE[j] = ne[j];
-        bM[j] = A[j];
+        bE[j] = bE2[j];
+        bM[j] = bM2[j];
       }
-      // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
-      if (STORE) store_row_f64<true>(out + rt, lane, ne);
     }
   }
   // An infinite sample gives every cell of its row the score -inf in the reference (aligner.cpp:
@@ -450,8 +460,14 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   // no select in the row loop. Both hand-overs happen in the rare block that looks one row ahead.
   int lo = band_mid(1, ratio) - bw;  // band of row 1 (column 0 of row 0 is inside: band_mid(1) <= 1 <= bw)
   int n[CPL];
-  double fM[CPL], fE[CPL], e[CPL];
-  double vM[CPL], vE[CPL], bcur[CPL], bnext[CPL];
+  // The loop-carried values of a row. The row loop is unrolled by two and ping-pongs between two of these:
+  // with one set, "new" values are computed while the "old" ones are still live and hipcc closes every
+  // iteration with a register move per value and cell (19 v_mov_b64 per row in this sweep, 5 % of its VALU
+  // instructions -- and the chip's power limit charges per instruction).
+  struct RowState {
+    double fM[CPL], fE[CPL], e[CPL], vM[CPL], vE[CPL], b[CPL];  // b = bE of the row that is about to be computed
+  };
+  RowState sa, sb;
   EmisV<CPL> p;
   const double x0 = sg[0];
   const size_t r1 = POST ? (size_t)cur_out.at(w, 1) * P : 0;
@@ -460,16 +476,13 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
     p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
-    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
-    fM[j] = NEG_INF;
-    if (POST) {
-      vE[j] = fE[j];                      // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
-      vM[j] = NEG_INF;
-      bcur[j] = lat[r1 + pos_of(lane, j)];
-      bnext[j] = NEG_INF;
-    }
+    sa.fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
+    sa.fM[j] = NEG_INF;
+    sa.vE[j] = sa.fE[j];                     // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
+    sa.vM[j] = NEG_INF;
+    sa.b[j] = POST ? lat[r1 + pos_of(lane, j)] : NEG_INF;
   }
-  log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
+  log_normal_pdf_vec<CPL>(x0, p, sa.e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
@@ -477,31 +490,22 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
       ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
   }
 
-  for (int tb = 1; tb < T; tb += 64) {
-    const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
-    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
-    // The block's samples must have ARRIVED before the row loop starts: hipcc otherwise places the
-    // s_waitcnt vmcnt(0) for this load in front of its first use INSIDE the loop, where it drains the
-    // DMA ring in every row (+7 % on the sweep). A use here pins the wait to once per 64 rows.
-    asm volatile("" ::"v"(xs));
-    const int iend = min(64, T - tb);
-#pragma unroll 1
-    for (int i = 0; i < iend; ++i) {
-      const int t = tb + i;
-      const double xn = readlane_f64(xs, i);
-      double fEl[CPL], vEl[CPL];
-      if (POST) {
-        // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D (clamped to the
-        // -inf row T, so that the same number of memory operations is in flight in every row and
-        // one hand-counted s_waitcnt serves the whole loop, tail included)
-        wait_vmcnt<RING_WAIT>();
-        ring_read_row(ring_base + ((t + 1) % RING_D) * ROW_BYTES, lane, bnext);
-        ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
-      }
-      from_left(fE, fEl);
-      if (POST) from_left(vE, vEl);
+  // one lattice row: reads the state `in` (row t-1), writes `out` (row t)
+  auto row = [&](auto check_move, int t, double xn, const RowState& in, RowState& out) {
+    double fEl[CPL], vEl[CPL];
+    if (POST) {
+      // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D (clamped to the
+      // -inf row T, so that the same number of memory operations is in flight in every row and
+      // one hand-counted s_waitcnt serves the whole loop, tail included)
+      wait_vmcnt<RING_WAIT>();
+      ring_read_row(ring_base + ((t + 1) % RING_D) * ROW_BYTES, lane, out.b);
+      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
+    }
+    from_left(in.fE, fEl);
+    if (POST) from_left(in.vE, vEl);
+    if constexpr (decltype(check_move)::value) {
       const int next_lo = band_mid(t + 1, ratio) - bw;
-      if (next_lo != lo) {  // wave-uniform: the window moves up by one column between rows t and t+1
+      if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
         // uniform addresses -> scalar loads (see backward_sweep)
         const Emis none = load_emis(pr, 0, 0);
         const Emis entering = load_emis(pr, lo + W, N);
@@ -517,92 +521,101 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
         }
         lo = next_lo;
       }
-      double a1[CPL], a2[CPL], fMn[CPL], fEn[CPL], en[CPL];
+    }
+    double a1[CPL], a2[CPL];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
+    for (int j = 0; j < CPL; ++j) out.fM[j] = (fEl[j] + in.e[j]) + m1;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) a1[j] = fM[j] + e[j];
+    for (int j = 0; j < CPL; ++j) a1[j] = in.fM[j] + in.e[j];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) a2[j] = (fE[j] + e[j]) + e2;
-      SoftplusLookup<CPL> L;
-      log_plus_issue<CPL>(a1, a2, L, s_tab);
-      log_normal_pdf_vec<CPL>(xn, p, en);  // e(t+1, n): independent work under the LDS latency
-      log_plus_finish<CPL>(L, fEn);
-      if (POST) {
-        double LPM[CPL], LPE[CPL], vMn[CPL], vEn[CPL], alt[CPL];
-        uint64_t bj[CPL];
+    for (int j = 0; j < CPL; ++j) a2[j] = (in.fE[j] + in.e[j]) + e2;
+    SoftplusLookup<CPL> L;
+    log_plus_issue<CPL>(a1, a2, L, s_tab);
+    log_normal_pdf_vec<CPL>(xn, p, out.e);  // e(t+1, n): independent work under the LDS latency
+    log_plus_finish<CPL>(L, out.fE);
+    if (POST) {
+      double LPM[CPL], LPE[CPL], alt[CPL];
+      uint64_t bj[CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) LPM[j] = (fMn[j] + (bnext[j] + en[j])) - Z;  // bM(t,n) = bE(t+1,n) + e(t+1,n)
+      for (int j = 0; j < CPL; ++j) LPM[j] = (out.fM[j] + (out.b[j] + out.e[j])) - Z;  // bM(t,n) = bE(t+1,n) + e(t+1,n)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) LPE[j] = (fEn[j] + bcur[j]) - Z;
+      for (int j = 0; j < CPL; ++j) LPE[j] = (out.fE[j] + in.b[j]) - Z;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) vMn[j] = vEl[j] + LPM[j];
+      for (int j = 0; j < CPL; ++j) out.vM[j] = vEl[j] + LPM[j];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) vEn[j] = max_f64(vM[j], vE[j]) + LPE[j];
+      for (int j = 0; j < CPL; ++j) out.vE[j] = max_f64(in.vM[j], in.vE[j]) + LPE[j];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) alt[j] = vM[j] + LPE[j];
+      for (int j = 0; j < CPL; ++j) alt[j] = in.vM[j] + LPE[j];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) bj[j] = __ballot(vEn[j] == alt[j]);
-        // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much). All 14
-        // sit in ONE asm block behind an s_nop: the ballots are SGPR pairs written by v_cmp (VALU), and
-        // a v_writelane that reads such an SGPR too soon after the v_cmp picks up stale data -- the
-        // compiler's hazard recogniser does not look inside inline asm (observed: a build that happened
-        // to schedule v_cmp two instructions ahead of the v_writelane produced garbage decision bits).
-        unsigned wlo, whi;
-        static_assert(CPL == 7, "one v_writelane pair per cell register");
+      for (int j = 0; j < CPL; ++j) bj[j] = __ballot(out.vE[j] == alt[j]);
+      // lane j keeps ballot j: two v_writelane per word (a select chain costs twice as much). All 14
+      // sit in ONE asm block behind an s_nop: the ballots are SGPR pairs written by v_cmp (VALU), and
+      // a v_writelane that reads such an SGPR too soon after the v_cmp picks up stale data -- the
+      // compiler's hazard recogniser does not look inside inline asm (observed: a build that happened
+      // to schedule v_cmp two instructions ahead of the v_writelane produced garbage decision bits).
+      unsigned wlo, whi;
+      static_assert(CPL == 7, "one v_writelane pair per cell register");
 #define DYN_WL(J, LO, HI) "v_writelane_b32 %0, %" #LO ", " #J "\n\tv_writelane_b32 %1, %" #HI ", " #J "\n\t"
-        asm("s_nop 4\n\t"
-            DYN_WL(0, 2, 3) DYN_WL(1, 4, 5) DYN_WL(2, 6, 7) DYN_WL(3, 8, 9) DYN_WL(4, 10, 11) DYN_WL(5, 12, 13) DYN_WL(6, 14, 15)
-            : "=&v"(wlo), "=&v"(whi)
-            : "s"((unsigned)bj[0]), "s"((unsigned)(bj[0] >> 32)), "s"((unsigned)bj[1]), "s"((unsigned)(bj[1] >> 32)),
-              "s"((unsigned)bj[2]), "s"((unsigned)(bj[2] >> 32)), "s"((unsigned)bj[3]), "s"((unsigned)(bj[3] >> 32)),
-              "s"((unsigned)bj[4]), "s"((unsigned)(bj[4] >> 32)), "s"((unsigned)bj[5]), "s"((unsigned)(bj[5] >> 32)),
-              "s"((unsigned)bj[6]), "s"((unsigned)(bj[6] >> 32)));
+      asm("s_nop 4\n\t"
+          DYN_WL(0, 2, 3) DYN_WL(1, 4, 5) DYN_WL(2, 6, 7) DYN_WL(3, 8, 9) DYN_WL(4, 10, 11) DYN_WL(5, 12, 13) DYN_WL(6, 14, 15)
+          : "=&v"(wlo), "=&v"(whi)
+          : "s"((unsigned)bj[0]), "s"((unsigned)(bj[0] >> 32)), "s"((unsigned)bj[1]), "s"((unsigned)(bj[1] >> 32)),
+            "s"((unsigned)bj[2]), "s"((unsigned)(bj[2] >> 32)), "s"((unsigned)bj[3]), "s"((unsigned)(bj[3] >> 32)),
+            "s"((unsigned)bj[4]), "s"((unsigned)(bj[4] >> 32)), "s"((unsigned)bj[5]), "s"((unsigned)(bj[5] >> 32)),
+            "s"((unsigned)bj[6]), "s"((unsigned)(bj[6] >> 32)));
 #undef DYN_WL
-        const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
-        const uint32_t prow = cur_out.at(w, t);
-        const size_t rt = (size_t)prow * P;
-        // read again only by the traceback, one cell per row: non-temporal; same pairing as the bE rows
-        if (INPLACE) {
+      const uint64_t mybits = ((uint64_t)whi << 32) | wlo;
+      const uint32_t prow = cur_out.at(w, t);
+      const size_t rt = (size_t)prow * P;
+      // read again only by the traceback, one cell per row: non-temporal; same pairing as the bE rows
+      if (INPLACE) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            dyn_f4 v4;
-            v4.x = (float)LPM[2 * q];
-            v4.y = (float)LPE[2 * q];
-            v4.z = (float)LPM[2 * q + 1];
-            v4.w = (float)LPE[2 * q + 1];
-            __builtin_nontemporal_store(v4, reinterpret_cast<dyn_f4*>(&lat_lp[2 * (rt + q * 128 + lane * 2)]));
-          }
+        for (int q = 0; q < 3; ++q) {
+          dyn_f4 v4;
+          v4.x = (float)LPM[2 * q];
+          v4.y = (float)LPE[2 * q];
+          v4.z = (float)LPM[2 * q + 1];
+          v4.w = (float)LPE[2 * q + 1];
+          __builtin_nontemporal_store(v4, reinterpret_cast<dyn_f4*>(&lat_lp[2 * (rt + q * 128 + lane * 2)]));
+        }
+        dyn_f2 v2;
+        v2.x = (float)LPM[6];
+        v2.y = (float)LPE[6];
+        __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * (rt + 384 + lane)]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
           dyn_f2 v2;
-          v2.x = (float)LPM[6];
-          v2.y = (float)LPE[6];
-          __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[2 * (rt + 384 + lane)]));
-        } else {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            dyn_f2 v2;
-            v2.x = (float)LPE[2 * q];
-            v2.y = (float)LPE[2 * q + 1];
-            __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[rt + q * 128 + lane * 2]));
-          }
-          __builtin_nontemporal_store((float)LPE[6], &lat_lp[rt + 384 + lane]);
+          v2.x = (float)LPE[2 * q];
+          v2.y = (float)LPE[2 * q + 1];
+          __builtin_nontemporal_store(v2, reinterpret_cast<dyn_f2*>(&lat_lp[rt + q * 128 + lane * 2]));
         }
-        if (lane < CPL) bits[(size_t)prow * CPL + lane] = mybits;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          vM[j] = vMn[j];
-          vE[j] = vEn[j];
-          bcur[j] = bnext[j];
-        }
+        __builtin_nontemporal_store((float)LPE[6], &lat_lp[rt + 384 + lane]);
       }
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        fM[j] = fMn[j];
-        fE[j] = fEn[j];
-        e[j] = en[j];
-      }
+      if (lane < CPL) bits[(size_t)prow * CPL + lane] = mybits;
+    }
+  };
+
+  for (int tb = 1; tb < T; tb += 64) {
+    const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
+    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    // The block's samples must have ARRIVED before the row loop starts: hipcc otherwise places the
+    // s_waitcnt vmcnt(0) for this load in front of its first use INSIDE the loop, where it drains the
+    // DMA ring in every row (+7 % on the sweep). A use here pins the wait to once per 64 rows.
+    asm volatile("" ::"v"(xs));
+    const int iend = min(64, T - tb);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 1 < iend; i += 2) {
+      row(std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+      row(std::true_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
+    }
+    if (i < iend) {  // odd tail (last block of a read only): one more row, then the roles are swapped back
+      row(std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+      sa = sb;
     }
   }
+  const double (&fE)[CPL] = sa.fE;
   if (POST) wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);
@@ -816,7 +829,7 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
       ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
       from_left(fE, fEl);
       const int next_lo = band_mid(t + 1, ratio) - bw;
-      if (next_lo != lo) {  // wave-uniform: the window moves up by one column between rows t and t+1
+      if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
         const Emis none = load_emis(pr, 0, 0);
         const Emis entering = load_emis(pr, lo + W, N);
 #pragma unroll
