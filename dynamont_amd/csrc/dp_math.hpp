@@ -124,7 +124,7 @@ constexpr double HALF_LOG_2PI = 0x1.d67f1c864beb4p-1;  // 0.5*log(2*pi) = 0.9189
 // aligner.cpp:287-292 with the reference's evaluation order: z = diff/stdev formed as diff*inv + one
 // FMA residual correction (= the correctly rounded quotient, Markstein), then
 // (-0.5*z*z - log(stdev)) - 0.5*log(2*pi). Bit-identical to the CPU expression (tests/test_dp_math.py);
-// 8 fp64 operations. Kept as the yardstick for the 4-operation form the kernels run.
+// 8 fp64 operations. Kept as the yardstick for the 5-operation form the kernels run.
 DYN_HD double log_normal_pdf_exact(double x, double mean, double stdev, double log_stdev) {
   const double inv = 1.0 / stdev;
   const double diff = x - mean;
