@@ -393,6 +393,66 @@ def test_g7_train_against_reference_golden(models):
         assert len(dense["emission_model"]) == al.num_kmers and dense["transition_params"]["e1"] == 1.0
 
 
+def _read_with_exactly(rng, S, kc, k, mean_code, sd_code, rna):
+    """A synthetic read with exactly S samples and kc k-mers (kc + k - 1 bases); dwell split as evenly as S allows."""
+    digits = rng.integers(0, 4, size=kc + k - 1)
+    if rna:
+        digits[:min(9, len(digits))] = 0
+    codes = synth._seq_codes(digits, k)
+    dw = np.full(kc, S // kc)
+    dw[: S - dw.sum()] += 1
+    idx = np.repeat(codes, dw)
+    sig = mean_code[idx] + 1.2 * sd_code[idx] * rng.standard_normal(len(idx))
+    return synth.SynthRead(np.ascontiguousarray(sig, dtype=np.float64), "".join(synth.BASES[d] for d in digits))
+
+
+@pytest.mark.parametrize("pore", ["rna002", "dna_r10_400bps"])
+def test_row_loop_tails_at_block_and_parity_edges(models, pore):
+    """The row loops run in blocks of 64 rows and two rows per iteration (ping-pong state): every combination of an
+    odd / even number of rows and of a last block of 1, 2, 63, 64 rows, for align (both posterior layouts share the
+    loop) and train, against the oracle."""
+    path = model_for(models, pore)
+    pid, rna, k = synth.PORES[pore]
+    mf, sf = synth.read_model_file(path)[1:]
+    mean_code, sd_code = synth.code_order_table(mf, sf, k, rna)
+    rng = np.random.default_rng(64)
+    reads = []
+    for S in (2, 3, 4, 5, 62, 63, 64, 65, 66, 67, 126, 127, 128, 129, 130, 191, 192, 193, 194, 255, 256, 257, 258, 320, 321):
+        for kc in sorted({1, max(1, S // 7), max(1, S // 2)}):
+            reads.append(_read_with_exactly(rng, S, kc, k, mean_code, sd_code, rna))
+    al = Aligner(path, pore, device=0)
+    orc = Oracle(path, pid)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    tr = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
+    checked = 0
+    for i, r in enumerate(reads):
+        try:
+            want = orc.align(r.signal, r.sequence, True)
+        except RuntimeError as e:
+            assert res.error(i) == str(e), (i, len(r.signal), len(r.sequence))
+            continue
+        got = res.read(i)
+        tag = (i, len(r.signal), len(r.sequence))
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), tag
+        assert np.array_equal(got["signal_positions"], want["signal_positions"]), tag
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT, tag
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"])), tag
+        try:
+            wt = orc.train(r.signal, r.sequence)
+        except RuntimeError as e:
+            assert tr.error(i) == str(e), tag
+            continue
+        assert tr.status[i] == 0, (tag, tr.error(i))
+        assert abs(tr.Z[i] - wt["Z"]) <= 1e-9 * max(1.0, abs(wt["Z"])), tag
+        assert abs(tr.transitions[3 * i] - wt["m1"]) <= 1e-9 and abs(tr.transitions[3 * i + 2] - wt["e2"]) <= 1e-9, tag
+        code, m, sdev = tr.sparse(i)
+        touched = np.nonzero(wt["weight"] > 0)[0]
+        assert np.array_equal(code, touched), tag
+        assert np.abs(m - wt["mean"][touched]).max() <= 1e-9 and np.abs(sdev - wt["stdev"][touched]).max() <= 1e-7, tag
+        checked += 1
+    assert checked >= 60
+
+
 def test_train_batch_against_oracle_and_pooled_stats(models, al9):
     _, mean, sd = synth.read_model_file(models["syn9"])
     reads = synth.make_reads(5, 6, "rna004", mean, sd, (120, 500))
