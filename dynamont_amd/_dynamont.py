@@ -441,6 +441,16 @@ class Aligner:
     def set_mem_budget(self, nbytes: int) -> None:
         self._L.dyn_aligner_set_mem_budget(self._h, int(nbytes))
 
+    STRICT_MODES = {"off": 0, "start": 1, "all": 2}
+
+    def set_strict(self, mode) -> None:
+        """dyn_aligner_set_strict: 0/"off" default arithmetic; 1/"start" reads whose first two k-mers are equal go
+        through the kernels that reproduce the reference's libm bit for bit; 2/"all" every read."""
+        m = self.STRICT_MODES[mode] if isinstance(mode, str) else int(mode)
+        rc = self._L.dyn_aligner_set_strict(self._h, m)
+        if rc != N.DYN_OK:
+            raise ValueError("strict mode must be 0 (off), 1 (start) or 2 (all)")
+
     def model_table(self):
         """(mean, stdev) in k-mer-code order."""
         if self._model is None:

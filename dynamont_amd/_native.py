@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
 SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "nt_kernels.hip"]
-HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", os.path.join("..", "..", "include", "dynamont_mi.h")]
+HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
 DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)
@@ -49,7 +49,8 @@ class DynTiming(C.Structure):
                 ("ms_trace", C.c_double), ("wave_wait_share", C.c_double), ("wave_occupancy", C.c_double),
                 ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
                 ("launches", C.c_uint32), ("lp_inplace", C.c_uint32), ("pool_pages", C.c_uint32),
-                ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32)]
+                ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32),
+                ("reads_strict", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
     "dyn_aligner_last_error": (C.c_char_p, [C.c_void_p]),
     "dyn_read_strerror": (C.c_int, [C.c_int, C.c_char, C.c_char_p, C.c_uint64]),
     "dyn_segment_capacity": (C.c_uint64, [C.c_void_p, C.c_uint64, c_u64_p]),

@@ -47,6 +47,8 @@
 
 #include <algorithm>
 
+#include "dp_math_strict.hpp"
+
 // Placement: the SPI packs single-wave workgroups onto one SIMD for as long as its registers
 // allow (measured: a 184-VGPR build of the backward sweep ran 1 024 reads as 2 waves on each of 512
 // SIMDs and took 2x the time of 512 reads; tools/ubench + DESIGN.md). The DP waves are pure fp64 issue
@@ -171,6 +173,24 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   return e;
 }
 
+// STRICT (dp_math_strict.hpp): the reference's expressions operation by operation, glibc's exp / log1p bit for bit.
+// The slot that normally carries 1/stdev then carries stdev itself (true IEEE division).
+template <bool STRICT>
+__device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
+  p.set(j, e);
+  if (STRICT) p.inv_stdev[j] = e.stdev;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, double (&out)[CPL]) {
+  if constexpr (STRICT) dynmath::log_normal_pdf_strict_vec<CPL>(x, p, out);
+  else log_normal_pdf_vec<CPL>(x, p, out);
+}
+
+__device__ __forceinline__ const uint64_t* strict_tab(const SoftplusNode* s_tab) {
+  return reinterpret_cast<const uint64_t*>(s_tab + SP_NODES + dynmath::EXP_TAB_NODES);
+}
+
 // ---- paged lattice rows --------------------------------------------------------------------------
 // Lattice row t of the wave's current read is row (pt[t >> log_r] << log_r) + (t mod 2^log_r) of the
 // pool arrays. The sweeps keep the page base in a scalar register and look the table (LDS) up only
@@ -277,7 +297,7 @@ __device__ __forceinline__ void ring_read_row(unsigned slot_addr, int lane, doub
 // n+1 < N guards arithmetically; the upper band edge is handled in the window-move block.
 // Returns Zb = bE(0,0) (-inf when the signal holds a non-finite sample).
 // ---------------------------------------------------------------------------------------------
-template <bool STORE>
+template <bool STORE, bool STRICT>
 __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par, double* __restrict__ ws,
@@ -304,7 +324,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     for (int j = 0; j < CPL; ++j) {
       const int slot = lane * CPL + j;
       n[j] = lo + pmod(slot - lo);
-      p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
+      set_emis<STRICT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
       bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
       bM[j] = NEG_INF;
     }
@@ -320,7 +340,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
     bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
-    log_normal_pdf_vec<CPL>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
+    emission_vec<STRICT>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
     // one lattice row: reads (bE_in, bM_in) = row t+1, writes (bE_out, bM_out) = row t; the loop is unrolled by two and
     // ping-pongs between the two pairs (see forward_sweep: no register moves at the loop's back edge)
     auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
@@ -344,7 +364,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
-            p.set(j, fresh);
+            set_emis<STRICT>(p, j, fresh);
           }
           // Upper band edge: bM(t, top) = A must not see the in-band cell (t+1, top); Y keeps it for
           // the diagonal into (t, top-1). From row t on the slot carries the "no k-mer" parameters, so
@@ -354,7 +374,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
           // e = -inf before anything reads it.
           if (n[j] == top) {
             bM_out[j] = NEG_INF;
-            p.set(j, none);
+            set_emis<STRICT>(p, j, none);
           }
         }
         lo = new_lo;
@@ -364,7 +384,8 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x2[j] = bM_out[j] + e2;
       SoftplusLookup<CPL> L;
-      log_plus_issue<CPL>(x1, x2, L, s_tab);
+      if constexpr (STRICT) dynmath::log_plus_strict_vec<CPL>(x1, x2, bE_out, strict_tab(s_tab));
+      else log_plus_issue<CPL>(x1, x2, L, s_tab);
       // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
       // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: the value computed
       //  here is thrown away and that one emission is computed after the block switch above. Unconditional on
@@ -372,9 +393,9 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       //  in every row)
       {
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
-        log_normal_pdf_vec<CPL>(xnext, p, e);
+        emission_vec<STRICT>(xnext, p, e);
       }
-      log_plus_finish<CPL>(L, bE_out);
+      if constexpr (!STRICT) log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
       // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
       if (STORE) store_row_f64<true>(out + rt, lane, bE_out);
@@ -427,7 +448,7 @@ __device__ __forceinline__ double max_f64(double a, double b) {
   return r;
 }
 
-template <bool POST, bool INPLACE>
+template <bool POST, bool INPLACE, bool STRICT>
 __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                 const double* __restrict__ sig, const Emis* __restrict__ par,
                                                 const double* __restrict__ ws_rd, float* __restrict__ lp_out,
@@ -475,14 +496,14 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+    set_emis<STRICT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
     sa.fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     sa.fM[j] = NEG_INF;
     sa.vE[j] = sa.fE[j];                     // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
     sa.vM[j] = NEG_INF;
     sa.b[j] = POST ? lat[r1 + pos_of(lane, j)] : NEG_INF;
   }
-  log_normal_pdf_vec<CPL>(x0, p, sa.e);  // e(1, n)
+  emission_vec<STRICT>(x0, p, sa.e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
@@ -516,8 +537,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
           // and fE/vE(t-1, lo) stay where this row and the right neighbour (fEl/vEl) still read them.
           const bool leaves = n[j] == lo;
           n[j] = leaves ? lo + P : n[j];
-          if (leaves) p.set(j, none);
-          if (n[j] == lo + W) p.set(j, entering);  // first band row of this column is t+1
+          if (leaves) set_emis<STRICT>(p, j, none);
+          if (n[j] == lo + W) set_emis<STRICT>(p, j, entering);  // first band row of this column is t+1
         }
         lo = next_lo;
       }
@@ -529,10 +550,15 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     for (int j = 0; j < CPL; ++j) a1[j] = in.fM[j] + in.e[j];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) a2[j] = (in.fE[j] + in.e[j]) + e2;
-    SoftplusLookup<CPL> L;
-    log_plus_issue<CPL>(a1, a2, L, s_tab);
-    log_normal_pdf_vec<CPL>(xn, p, out.e);  // e(t+1, n): independent work under the LDS latency
-    log_plus_finish<CPL>(L, out.fE);
+    if constexpr (STRICT) {
+      dynmath::log_plus_strict_vec<CPL>(a1, a2, out.fE, strict_tab(s_tab));
+      emission_vec<STRICT>(xn, p, out.e);
+    } else {
+      SoftplusLookup<CPL> L;
+      log_plus_issue<CPL>(a1, a2, L, s_tab);
+      log_normal_pdf_vec<CPL>(xn, p, out.e);  // e(t+1, n): independent work under the LDS latency
+      log_plus_finish<CPL>(L, out.fE);
+    }
     if (POST) {
       double LPM[CPL], LPE[CPL], alt[CPL];
       uint64_t bj[CPL];
@@ -1034,15 +1060,17 @@ __global__ void k_pool_init(PagePool pool, uint32_t first_free, uint32_t n_stati
 // by-value argument struct they carry no no-alias information, and hipcc then turns the wave-uniform
 // loads from them (emission parameters in the window-move blocks, read descriptors) into VECTOR loads
 // guarded by s_waitcnt vmcnt(0) -- which drains the forward sweep's DMA ring every ~13 rows.
-template <int JOB>
+template <int JOB, bool STRICT>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const ReadDesc* __restrict__ descs,
                                                    const double* __restrict__ sig, const Emis* __restrict__ par,
                                                    const SoftplusNode* __restrict__ sp_tab) {
   constexpr bool LATTICE = JOB != JOB_Z;
-  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[SP_NODES + dynmath::EXP_TAB_NODES];  // + 2^(i/64) (exp_vec)
+  // + 2^(i/64) (exp_vec) + the 2^(k/128) table of the strict exp (dp_math_strict.hpp)
+  constexpr int TAB_NODES = SP_NODES + dynmath::EXP_TAB_NODES + dynmath::STRICT_EXP_WORDS / 2;
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[TAB_NODES];
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
   __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
-  for (int i = threadIdx.x; i < SP_NODES + dynmath::EXP_TAB_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
+  for (int i = threadIdx.x; i < TAB_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
   __syncthreads();
   // readfirstlane: the wave index is uniform, and the compiler must know it -- otherwise the read
   // descriptor, every pointer and loop bound derived from it live in VGPRs and every table /
@@ -1096,18 +1124,18 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     cyc_w += t1 - t0;
 
-    const double Zb = backward_sweep<LATTICE>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+    const double Zb = backward_sweep<LATTICE, STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
     const uint64_t t2 = __builtin_amdgcn_s_memtime();
     cyc_b += t2 - t1;
     double Zf;
     if (JOB == JOB_TRAIN) {
       Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
     } else if (JOB == JOB_ALIGN) {
-      Zf = forward_sweep<true, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+      Zf = forward_sweep<true, false, STRICT>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
     } else if (JOB == JOB_ALIGN_INPLACE) {
-      Zf = forward_sweep<true, true>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+      Zf = forward_sweep<true, true, STRICT>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
     } else {
-      Zf = forward_sweep<false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+      Zf = forward_sweep<false, false, STRICT>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
     }
     const uint64_t t3 = __builtin_amdgcn_s_memtime();
     cyc_f += t3 - t2;
@@ -1428,15 +1456,20 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
   hipLaunchKernelGGL(k_pool_init, dim3((n + 255) / 256), dim3(256), 0, s, pool, first_free, (uint32_t)n_static);
 }
 
-void launch_read_queue(QueueJob job, const QueueArgs& q, int n_cus, hipStream_t s) {
+void launch_read_queue(QueueJob job, bool strict, const QueueArgs& q, int n_cus, hipStream_t s) {
   if (q.n_reads <= 0) return;
   const int groups = std::min((q.n_reads + DYN_WAVES_PER_GROUP - 1) / DYN_WAVES_PER_GROUP, std::max(1, n_cus));
   const dim3 grid(groups), block(64 * DYN_WAVES_PER_GROUP);
+  if (strict) {  // only jobs with integer outputs have a strict form
+    if (job == JOB_ALIGN) hipLaunchKernelGGL((k_read_queue<JOB_ALIGN, true>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab);
+    else hipLaunchKernelGGL((k_read_queue<JOB_ALIGN_INPLACE, true>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab);
+    return;
+  }
   switch (job) {
-    case JOB_Z: hipLaunchKernelGGL(k_read_queue<JOB_Z>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
-    case JOB_ALIGN: hipLaunchKernelGGL(k_read_queue<JOB_ALIGN>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
-    case JOB_ALIGN_INPLACE: hipLaunchKernelGGL(k_read_queue<JOB_ALIGN_INPLACE>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
-    case JOB_TRAIN: hipLaunchKernelGGL(k_read_queue<JOB_TRAIN>, grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_Z: hipLaunchKernelGGL((k_read_queue<JOB_Z, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_ALIGN: hipLaunchKernelGGL((k_read_queue<JOB_ALIGN, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_ALIGN_INPLACE: hipLaunchKernelGGL((k_read_queue<JOB_ALIGN_INPLACE, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_TRAIN: hipLaunchKernelGGL((k_read_queue<JOB_TRAIN, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
   }
 }
 

@@ -125,7 +125,8 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
 // reads off the queue until it is empty; per read backward -> forward (+ posterior, Viterbi fill,
 // decision bits | training statistics) -> Z check -> traceback -> segment-start posteriors.
 // n_cus: compute units of the device (one 4-wave workgroup per CU).
-void launch_read_queue(QueueJob job, const QueueArgs& q, int n_cus, hipStream_t s);
+// strict: the bit-for-bit arithmetic of dp_math_strict.hpp (JOB_ALIGN / JOB_ALIGN_INPLACE only)
+void launch_read_queue(QueueJob job, bool strict, const QueueArgs& q, int n_cus, hipStream_t s);
 // per-segment median posterior + output rows for all reads of descs (after launch_read_queue)
 void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
                      TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s);

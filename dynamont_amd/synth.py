@@ -120,6 +120,12 @@ def make_read(rng: np.random.Generator, mean_code: np.ndarray, sd_code: np.ndarr
     digits = rng.integers(0, 4, size=n_bases)
     if rna:
         digits[:9] = 0  # aligner-orientation RNA reads start with the polyA pad (segment.py:155-158)
+    return read_from_digits(rng, digits, mean_code, sd_code, k, dwell)
+
+
+def read_from_digits(rng: np.random.Generator, digits: np.ndarray, mean_code: np.ndarray, sd_code: np.ndarray, k: int,
+                     dwell: float) -> SynthRead:
+    """The signal half of make_read for a prescribed base sequence (0..3 = ACGT, aligner orientation)."""
     codes = _seq_codes(digits, k)
     dw = np.maximum(2, rng.poisson(dwell, size=len(codes)))
     c = rng.uniform(0.8, 2.0)

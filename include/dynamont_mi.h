@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 2
+#define DYN_ABI_VERSION 3
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -146,13 +146,15 @@ typedef struct dyn_timing {
   uint64_t cells;        /* in-band lattice cells processed: sum over ok reads of T*min(2bw+1,N) */
   uint64_t samples;      /* sum of signal lengths over ok reads */
   uint64_t reads_ok;
-  uint32_t launches;     /* read-queue launches (1; 0 for a batch without an ok read) */
+  uint32_t launches;     /* read-queue launches (1; 0 for a batch without an ok read; 2 when strict and default reads mix) */
   uint32_t lp_inplace;   /* 1: the page pool could not hold a separate-layout lattice (12 B per band slot) for every
                             wave, the posteriors overwrote the backward rows in place (8 B per slot, slower sweep) */
   uint32_t pool_pages;   /* pages in the lattice pool */
   uint32_t page_rows;    /* lattice rows per page */
   uint32_t n_static;     /* reads whose pages were reserved by the host (first round) */
   uint32_t n_waves;      /* persistent waves launched */
+  uint32_t reads_strict; /* reads that went through the strict kernels (dyn_aligner_set_strict) */
+  uint32_t reserved;
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
@@ -171,6 +173,16 @@ int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
 int dyn_aligner_model(const dyn_aligner* a, double* out2n);
 /* Upper limit on HBM used for lattice workspaces (bytes; 0 = 90 % of free memory). */
 int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
+/* Strict mode (opt-in; affects align with calc_probabilities only). The reference's traceback takes exact fp64
+ * comparisons (NT_aligner_api.cpp:445-448); where the first two lattice columns carry the same k-mer (every RNA read
+ * that starts with the polyA pad + A, any read starting with a homopolymer of k+1 bases) such a comparison is a tie in
+ * exact arithmetic and the reference's choice rests on the last bits of glibc's exp/log1p inside logPlus
+ * (aligner.cpp:276-285). The default kernels use a table softplus that is <= 1 ulp away from those and reproduce
+ * 997 of 1 000 such reads (tests/golden/g10_ties.npz lists the three); the strict kernels restate glibc 2.35's
+ * x86-64 exp (FMA variant) and fdlibm log1p and the reference's emission expression bit for bit (Z becomes
+ * bit-identical too), at ~1/3 of the default speed for the reads they run.
+ *   mode 0: off (default)   mode 1: reads whose first two k-mers are equal   mode 2: every read */
+int dyn_aligner_set_strict(dyn_aligner* a, int mode);
 /* Message of the last failing call on this handle (thread-unsafe like the handle itself). */
 const char* dyn_aligner_last_error(const dyn_aligner* a);
 /* Reference exception text for a per-read status (bad_char fills "Invalid nucleotide: X"). */

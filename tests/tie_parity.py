@@ -13,7 +13,8 @@ Modes of the shim: 0 = libm (must reproduce the oracle exactly), 1 = the product
 2 = the 4-operation emission of rounds 1-2 (constants pre-added, one FMA), 3 = a 3-operation emission
 (1/(stdev sqrt 2) folded into the constant), 4 = the product's logPlus with the reference's emission,
 5 = the product's emission with the difference folded into an FMA (z = fma(x, 1/stdev, -mean/stdev), one operation
-fewer). Measured on 1 000 reads: 0 / 3 / 11 / 17 / 3 / 14 reads differ.
+fewer), 6 = the STRICT arithmetic (dp_math_strict.hpp: glibc's exp and log1p restated bit for bit, the reference's
+emission expression). Measured on 1 000 reads: 0 / 3 / 11 / 17 / 3 / 14 / 0 reads differ.
 """
 from __future__ import annotations
 
@@ -34,6 +35,7 @@ from oracle import pyoracle  # noqa: E402
 
 SHIM = r'''
 #include "%(root)s/dynamont_amd/csrc/dp_math.hpp"
+#include "%(root)s/dynamont_amd/csrc/dp_math_strict.hpp"
 #include <cmath>
 #include <vector>
 static std::vector<dynmath::SoftplusNode> TAB;
@@ -49,6 +51,7 @@ static double libm_pdf(double x, double mean, double sd) {
 extern "C" double nto_hook_pdf(double x, double mean, double sd) {
   switch (g_mode) {
     case 0: case 4: return libm_pdf(x, mean, sd);
+    case 6: return dynmath::log_normal_pdf_strict(x, dynmath::make_emis(mean, sd, std::log(sd)));
     case 2: { const double z = (x - mean) * (1.0 / sd); return dynmath::fma_(-0.5 * z, z, -std::log(sd) - dynmath::HALF_LOG_2PI); }
     case 3: { const double k = (double)(1.0L / ((long double)sd * 1.41421356237309504880168872420969808L));
               const double y = (x - mean) * k; return dynmath::fma_(-y, y, -std::log(sd) - dynmath::HALF_LOG_2PI); }
@@ -64,6 +67,7 @@ extern "C" double nto_hook_log_plus(double x, double y) {
     if (x < y) { const double t = x; x = y; y = t; }
     return x + std::log1p(std::exp(y - x));
   }
+  if (g_mode == 6) return dynmath::log_plus_strict(x, y, dynmath::strict_exp_table());
   double a[1] = {x}, b[1] = {y}, o[1];
   dynmath::SoftplusLookup<1> L;
   dynmath::log_plus_issue<1>(a, b, L, TAB.data());
@@ -111,6 +115,65 @@ def tie_reads(n: int, mean, sd, pore: str = "rna002", seed: int = 5000):
                              dwell=float(rng.choice([2.0, 3.5, 10.0])))[0] for i in range(n)]
 
 
+def start_tie_reads(n: int, mean, sd, pore: str, seed: int):
+    """Short reads (k+2 .. 70 bases) that START with a homopolymer of k+1 .. k+4 bases: columns 1 and 2 (and more) carry
+    the same k-mer, the symmetric read-start tie, for any pore (DNA reads have no pad; RNA 9-mer reads need pad + A)."""
+    _, rna, k = synth.PORES[pore]
+    mean_c, sd_c = synth.code_order_table(mean, sd, k, rna)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nb = int(rng.integers(k + 2, 71))
+        digits = rng.integers(0, 4, size=nb)
+        run = int(rng.integers(k + 1, min(nb, k + 5)))
+        digits[:run] = 0 if rna else int(rng.integers(0, 4))
+        if rna:
+            digits[:9] = 0
+        out.append(synth.read_from_digits(rng, digits, mean_c, sd_c, k, float(rng.choice([2.0, 3.5, 10.0]))))
+    return out
+
+
+def internal_homopolymer_reads(n: int, mean, sd, pore: str, seed: int):
+    """Reads of 150 .. 400 bases with ONE internal homopolymer run of 20 .. 120 bases (>= k+1: a stretch of identical
+    k-mers away from the read start, where the history on both sides of a tie is no longer symmetric)."""
+    _, rna, k = synth.PORES[pore]
+    mean_c, sd_c = synth.code_order_table(mean, sd, k, rna)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nb = int(rng.integers(150, 401))
+        digits = rng.integers(0, 4, size=nb)
+        if rna:
+            digits[:9] = 0
+            digits[9] = int(rng.integers(1, 4))  # no read-start tie in this family
+        run = int(rng.integers(20, min(121, nb - 40)))
+        at = int(rng.integers(20, nb - run - 10))
+        digits[at:at + run] = int(rng.integers(0, 4))
+        out.append(synth.read_from_digits(rng, digits, mean_c, sd_c, k, 10.0 if rna else 12.5))
+    return out
+
+
+# Fixture G10 (tests/golden/make_golden_g10.py): family -> (pore, model, generator). Models: the synthetic ones of
+# conftest ("syn5": 5-mer, stdev 0.25; "syn9": 9-mer, stdev 0.15) and "syn5_sd015", the 5-mer model with stdev 0.15 that
+# `python tests/tie_parity.py` uses -- the configuration in which the default arithmetic is known to deviate.
+G10_MODELS = {"syn5": (5, 0.25), "syn9": (9, 0.15), "syn5_sd015": (5, 0.15)}
+G10_FAMILIES = {
+    "rna002_start": ("rna002", "syn5", lambda m, s: tie_reads(1000, m, s, "rna002")),
+    "rna002_start_sd015": ("rna002", "syn5_sd015", lambda m, s: tie_reads(1000, m, s, "rna002")),
+    "rna004_start": ("rna004", "syn9", lambda m, s: start_tie_reads(300, m, s, "rna004", 6100)),
+    "dna_r10_400_start": ("dna_r10_400bps", "syn9", lambda m, s: start_tie_reads(300, m, s, "dna_r10_400bps", 6200)),
+    "dna_r9_start": ("dna_r9", "syn5", lambda m, s: start_tie_reads(200, m, s, "dna_r9", 6300)),
+    "dna_r9_start_sd015": ("dna_r9", "syn5_sd015", lambda m, s: start_tie_reads(300, m, s, "dna_r9", 6350)),
+    "rna002_internal": ("rna002", "syn5", lambda m, s: internal_homopolymer_reads(100, m, s, "rna002", 6400)),
+    "rna004_internal": ("rna004", "syn9", lambda m, s: internal_homopolymer_reads(100, m, s, "rna004", 6500)),
+    "dna_r10_400_internal": ("dna_r10_400bps", "syn9", lambda m, s: internal_homopolymer_reads(100, m, s, "dna_r10_400bps", 6600)),
+}
+
+
+def g10_model_paths(outdir: str) -> dict:
+    return {name: synth.write_model(os.path.join(outdir, name + ".model"), k, seed=7, stdev=sd) for name, (k, sd) in G10_MODELS.items()}
+
+
 def borders_equal(a: dict, b: dict) -> bool:
     return (np.array_equal(a["signal_positions"], b["signal_positions"])
             and np.array_equal(a["sequence_positions"], b["sequence_positions"]))
@@ -147,7 +210,8 @@ if __name__ == "__main__":
     rp = Replay(build_replay(d), path, synth.PORES[pore][0], 400)
     for mode, name in ((0, "libm primitives (sanity: the oracle itself)"), (1, "product arithmetic (dp_math.hpp)"),
                        (4, "reference emission + product logPlus"), (2, "4-operation emission of rounds 1-2 + product logPlus"),
-                       (3, "3-operation emission + product logPlus"), (5, "z = fma(x, 1/sd, -mean/sd), reference tail + product logPlus")):
+                       (3, "3-operation emission + product logPlus"), (5, "z = fma(x, 1/sd, -mean/sd), reference tail + product logPlus"),
+                       (6, "strict arithmetic (dp_math_strict.hpp)")):
         rp.set_mode(mode)
         bad = differing_reads(rp, reads, want)
         print(f"{name:55s}: {len(bad):3d} of {sum(w is not None for w in want)} reads with borders differing from the reference")
