@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU sample (0 = 4 per core)")
     ap.add_argument("--reads", type=int, default=0, help="experiment only: override reads per batch (not a bench line)")
+    ap.add_argument("--strict", default="off", choices=["off", "start", "all"],
+                    help="experiment only: dyn_aligner_set_strict (cost of the bit-for-bit libm kernels; not a bench line)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
                     help="align = the headline metric; train = Baum-Welch statistics pass (config 5 shape, secondary)")
     return ap.parse_args()
@@ -166,6 +168,7 @@ def main():
     samples_of = [int(b[1][-1]) for b in batches]
 
     al = Aligner(model_path, pore, mode="basic", band=400, device=local_rank)
+    al.set_strict(args.strict)
     depth = max(1, args.depth)
     free_results: list = []  # result objects are reused: fresh 50 MB arrays per batch would be page-faulted in every time
 
@@ -226,7 +229,7 @@ def main():
             tm = t.timing()
             for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy"):
                 kern[key] += tm[key]
-            for key in ("launches", "cells", "lp_inplace"):
+            for key in ("launches", "cells", "lp_inplace", "reads_strict"):
                 launches[key] += tm[key]
             launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
             launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
@@ -343,6 +346,7 @@ def main():
                        "parallelism": f"reads sharded x{n_gpus}" + ((", RCCL gather of segment rows to rank 0" if args.mode == "align" else ", RCCL all-reduce of pooled statistics") if use_dist else "")},
             "reads_per_s": round(total_reads / elapsed, 1),
             "reads_ok_last_batch": ok,
+            **({"strict_mode": args.strict, "strict_reads_per_step": launches["reads_strict"] / steps} if args.strict != "off" else {}),
             "kernel_ms_per_step": {k_: round(v / steps, 3) for k_, v in kern.items() if k_.startswith("ms_")},
             "kernel_resident_Msamp_s": round(resident["samples"] / resident["ms_total"] / 1e3, 3) if resident and resident["ms_total"] else None,
             "pipeline_efficiency": round((total_samples / n_gpus / elapsed / 1e6) / (resident["samples"] / resident["ms_total"] / 1e3), 4) if resident and resident["ms_total"] else None,

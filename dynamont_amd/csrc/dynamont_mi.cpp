@@ -849,21 +849,25 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   const PoreModel& m = a->model;
   const int z_fail = job == DynJob::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
 
-  // Launch groups. Group 0: the default arithmetic. Group 1 (align(calc=true) only, opt-in through
-  // dyn_aligner_set_strict): reads that go through the strict kernels, which reproduce the reference's libm bit for
-  // bit (dp_math_strict.hpp) -- mode 1: reads whose first two k-mers are equal (the symmetric read-start tie,
-  // NT_aligner_api.cpp:445-448), mode 2: every read. Within a group: longest reads first, so that the tail of the
-  // launch is made of the shortest reads.
+  // Strict reads (align(calc=true) only, opt-in through dyn_aligner_set_strict) take the sweeps that reproduce the
+  // reference's libm bit for bit (dp_math_strict.hpp) -- mode 1: reads whose first two k-mers are equal (the symmetric
+  // read-start tie, NT_aligner_api.cpp:445-448), mode 2: every read. They run in the SAME launch as the others (a
+  // per-read flag, kernel variant k_read_queue<JOB, true>), ~3.4x as long per lattice row.
+  // Queue order: most expensive reads first, so that the tail of the launch is made of the cheapest ones.
+  constexpr uint64_t STRICT_COST_NUM = 17, STRICT_COST_DEN = 5;  // measured: 137 vs 40 ms per cfg2 launch
   const int32_t* km = b->kmers();
-  std::vector<uint32_t> orders[2];
+  std::vector<uint8_t> is_strict(b->n, 0);
+  std::vector<uint32_t> order;
+  uint64_t n_strict = 0;
   for (uint64_t i = 0; i < b->n; ++i) {
     const HostRead& r = b->reads[i];
     if (r.status != DYN_READ_OK) continue;
-    const bool strict = calc && (a->strict_mode == 2 || (a->strict_mode == 1 && r.kc >= 2 && km[r.flat_off] == km[r.flat_off + 1]));
-    orders[strict ? 1 : 0].push_back((uint32_t)i);
+    is_strict[i] = calc && (a->strict_mode == 2 || (a->strict_mode == 1 && r.kc >= 2 && km[r.flat_off] == km[r.flat_off + 1]));
+    n_strict += is_strict[i];
+    order.push_back((uint32_t)i);
   }
-  for (auto& order : orders)
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->reads[x].S > b->reads[y].S; });
+  auto cost_rows = [&](uint32_t i) { return is_strict[i] ? (b->reads[i].S + 1) * STRICT_COST_NUM / STRICT_COST_DEN : b->reads[i].S + 1; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost_rows(x) > cost_rows(y); });
 
   if (calc) {
     HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
@@ -891,22 +895,22 @@ int enqueue_job(dyn_batch* b, DynJob job) {
 
   // rows per page: the longest read must fit the waves' PT_MAX-entry page tables
   uint32_t max_T = 0;
-  for (const auto& order : orders)
-    for (uint32_t i : order) max_T = std::max<uint32_t>(max_T, (uint32_t)(b->reads[i].S + 1));
+  for (uint32_t i : order) max_T = std::max<uint32_t>(max_T, (uint32_t)(b->reads[i].S + 1));
   int log_r = 8;
   while (((uint64_t)max_T + 1 + ((1ull << log_r) - 1)) >> log_r > (uint64_t)dynk::PT_MAX) ++log_r;
   const uint64_t page_rows = 1ull << log_r;
   auto pages_of = [&](uint64_t S) { return (uint32_t)((S + 2 + page_rows - 1) >> log_r); };  // rows 0 .. T = S+1
-  const size_t max_slots = (size_t)a->n_cus * dynk::WAVES_PER_CU;
-  // pages that keep every wave slot busy: the n_slots longest reads of a group at once (the groups run one after the other)
+  const size_t n_slots = std::min<size_t>(order.size(), (size_t)a->n_cus * dynk::WAVES_PER_CU);
+  // pages that keep every wave slot busy: the largest lattices at once (with strict reads in the batch the queue is
+  // not in length order, hence the explicit selection)
   auto pages_wanted = [&]() {
-    uint64_t wanted = 0;
-    for (const auto& order : orders) {
-      uint64_t w = 0;
-      for (size_t k = 0; k < std::min(max_slots, order.size()); ++k) w += pages_of(b->reads[order[k]].S);
-      wanted = std::max(wanted, w);
-    }
-    return wanted;
+    std::vector<uint32_t> pg(order.size());
+    for (size_t k = 0; k < order.size(); ++k) pg[k] = pages_of(b->reads[order[k]].S);
+    const size_t top = std::min(n_slots, pg.size());
+    std::partial_sort(pg.begin(), pg.begin() + top, pg.end(), std::greater<uint32_t>());
+    uint64_t w = 0;
+    for (size_t k = 0; k < top; ++k) w += pg[k];
+    return w;
   };
   uint64_t wanted = pages_wanted();
 
@@ -936,20 +940,18 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     st[i].n_segments = 0;
   }
   if (lattice) {
-    bool dropped = false;
-    for (auto& order : orders) {
-      size_t wr = 0;
-      for (uint32_t i : order) {
-        if ((uint64_t)pages_of(b->reads[i].S) * page_bytes > budget) st[i].status = DYN_READ_TOO_LARGE;
-        else order[wr++] = i;
-      }
-      dropped |= wr != order.size();
-      order.resize(wr);
+    size_t wr = 0;
+    for (uint32_t i : order) {
+      if ((uint64_t)pages_of(b->reads[i].S) * page_bytes > budget) st[i].status = DYN_READ_TOO_LARGE;
+      else order[wr++] = i;
     }
-    if (dropped) wanted = pages_wanted();
+    if (wr != order.size()) {
+      order.resize(wr);
+      wanted = pages_wanted();
+    }
   }
   if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st, b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
-  const size_t n_ok = orders[0].size() + orders[1].size();
+  const size_t n_ok = order.size();
 
   // the pool: grow-only, shared by every batch of the handle (stream order serialises them)
   dynk::PagePool pool{};
@@ -984,59 +986,52 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));
   pool.ctl = a->ctl.as<uint32_t>();
 
-  // read descriptors in processing order, group after group; pages of each launch's first round reserved here
+  // Page-starved launches: the queue order is planned (plan_queue above); `rows` is each read's duration.
+  if (lattice && order.size() > n_slots && !std::getenv("DYN_NO_BRIDGE")) {
+    std::vector<uint32_t> need(order.size());
+    std::vector<uint64_t> rows(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+      need[k] = pages_of(b->reads[order[k]].S);
+      rows[k] = cost_rows(order[k]);
+    }
+    if (!n_strict) plan_queue(order, need, rows, n_slots, pool.n_pages);  // the planner assumes pages ~ duration
+  }
+
+  // read descriptors in processing order; pages of the first round reserved here
   HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
   ReadDesc* descs = b->h_descs.as<ReadDesc>();
   dyn_timing tm{};
   uint64_t rows_total = 0;
-  uint32_t max_N = 0;
-  struct Group { size_t first = 0, n = 0; uint32_t used_pages = 0, n_static = 0; };
-  Group grp[2];
-  size_t kd = 0;
-  for (int g = 0; g < 2; ++g) {
-    std::vector<uint32_t>& order = orders[g];
-    const size_t n_slots = std::min<size_t>(order.size(), max_slots);
-    // Page-starved launches: the queue order is planned (plan_queue above).
-    if (lattice && order.size() > n_slots && !std::getenv("DYN_NO_BRIDGE")) {
-      std::vector<uint32_t> need(order.size());
-      std::vector<uint64_t> rows(order.size());
-      for (size_t k = 0; k < order.size(); ++k) {
-        need[k] = pages_of(b->reads[order[k]].S);
-        rows[k] = b->reads[order[k]].S + 1;
-      }
-      plan_queue(order, need, rows, n_slots, pool.n_pages);
+  uint32_t used_pages = 0, n_static = 0, max_N = 0;
+  bool reserving = true;
+  for (size_t k = 0; k < order.size(); ++k) {
+    const uint32_t i = order[k];
+    const HostRead& r = b->reads[i];
+    ReadDesc d{};
+    d.T = (uint32_t)(r.S + 1);
+    d.N = (uint32_t)(r.kc + 1);
+    d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
+    d.read = i;
+    d.ratio = (double)d.N / (double)d.T;
+    d.sig_off = r.sig_off;
+    d.par_off = r.flat_off;
+    d.seg_off = r.seg_off;
+    d.path_off = rows_total;
+    d.n_pages = lattice ? pages_of(r.S) : 0;
+    d.first_page = dynk::NO_PAGE;
+    d.flags = is_strict[i] ? dynk::READ_STRICT : 0u;
+    if (reserving && k < n_slots && (!lattice || (uint64_t)used_pages + d.n_pages <= pool.n_pages)) {
+      d.first_page = lattice ? used_pages : 0;
+      used_pages += d.n_pages;
+      n_static = (uint32_t)(k + 1);
+    } else {
+      reserving = false;  // later reads get their pages on the device
     }
-    grp[g].first = kd;
-    grp[g].n = order.size();
-    bool reserving = true;
-    for (size_t k = 0; k < order.size(); ++k, ++kd) {
-      const uint32_t i = order[k];
-      const HostRead& r = b->reads[i];
-      ReadDesc d{};
-      d.T = (uint32_t)(r.S + 1);
-      d.N = (uint32_t)(r.kc + 1);
-      d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
-      d.read = i;
-      d.ratio = (double)d.N / (double)d.T;
-      d.sig_off = r.sig_off;
-      d.par_off = r.flat_off;
-      d.seg_off = r.seg_off;
-      d.path_off = rows_total;
-      d.n_pages = lattice ? pages_of(r.S) : 0;
-      d.first_page = dynk::NO_PAGE;
-      if (reserving && k < n_slots && (!lattice || (uint64_t)grp[g].used_pages + d.n_pages <= pool.n_pages)) {
-        d.first_page = lattice ? grp[g].used_pages : 0;
-        grp[g].used_pages += d.n_pages;
-        grp[g].n_static = (uint32_t)(k + 1);
-      } else {
-        reserving = false;  // later reads get their pages on the device
-      }
-      rows_total += d.T;
-      max_N = std::max(max_N, d.N);
-      descs[kd] = d;
-      tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
-      tm.samples += r.S;
-    }
+    rows_total += d.T;
+    max_N = std::max(max_N, d.N);
+    descs[k] = d;
+    tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
+    tm.samples += r.S;
   }
   if (calc) {
     HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
@@ -1045,8 +1040,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
   if (n_ok)
     HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, n_ok * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
-  HIP_TRY(a, b->h_stats.ensure(2 * dynk::QUEUE_CTL_WORDS * 4));
-  std::memset(b->h_stats.p, 0, 2 * dynk::QUEUE_CTL_WORDS * 4);
+  HIP_TRY(a, b->h_stats.ensure(dynk::QUEUE_CTL_WORDS * 4));
+  std::memset(b->h_stats.p, 0, dynk::QUEUE_CTL_WORDS * 4);
 
   while (b->events.size() < 3) {
     hipEvent_t e = nullptr;
@@ -1058,6 +1053,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   dynk::QueueArgs q{};
   q.descs = b->d_descs.as<ReadDesc>();
   q.n_reads = nr;
+  q.n_static = (int)n_static;
   q.sig = b->d_sig.as<double>();
   q.par = b->d_par.as<Emis>();
   q.pool = pool;
@@ -1074,24 +1070,12 @@ int enqueue_job(dyn_batch* b, DynJob job) {
                               : lpe_separate       ? dynk::JOB_ALIGN
                                                    : dynk::JOB_ALIGN_INPLACE;
   if (!b->ev_done) HIP_TRY(a, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+  dynk::launch_pool_init(pool, used_pages, (int)n_static, a->stream);
   HIP_TRY(a, hipEventRecord(ev[0], a->stream));
-  uint32_t launches = 0;
-  for (int g = 0; g < 2; ++g) {
-    b->group_waves[g] = 0;
-    if (!grp[g].n) continue;
-    dynk::QueueArgs qg = q;
-    qg.descs = q.descs + grp[g].first;
-    qg.n_reads = (int)grp[g].n;
-    qg.n_static = (int)grp[g].n_static;
-    dynk::launch_pool_init(pool, grp[g].used_pages, (int)grp[g].n_static, a->stream);
-    dynk::launch_read_queue(qjob, g == 1, qg, a->n_cus, a->stream);
-    // the statistics leave the control words before the next k_pool_init resets them (same stream)
-    HIP_TRY(a, hipMemcpyAsync(b->h_stats.as<uint32_t>() + g * dynk::QUEUE_CTL_WORDS, pool.ctl, dynk::QUEUE_CTL_WORDS * 4,
-                              hipMemcpyDeviceToHost, a->stream));
-    b->group_waves[g] = (uint32_t)std::min<size_t>((grp[g].n + dynk::WAVES_PER_CU - 1) / dynk::WAVES_PER_CU * dynk::WAVES_PER_CU, max_slots);
-    ++launches;
-  }
+  dynk::launch_read_queue(qjob, n_strict != 0, q, a->n_cus, a->stream);
   HIP_TRY(a, hipEventRecord(ev[1], a->stream));
+  // the statistics leave the control words before the next batch's k_pool_init resets them (same stream)
+  HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
   // (Running the per-segment kernels on a stream of their own, beside the next batch's read queue, was measured:
   //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
   if (calc) dynk::launch_segments(q.descs, nr, max_T, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
@@ -1101,15 +1085,16 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, hipEventRecord(b->ev_done, a->stream));
   HIP_TRY(a, hipGetLastError());
   tm.reads_ok = n_ok;
-  tm.reads_strict = grp[1].n;
-  tm.launches = launches;
+  tm.reads_strict = (uint32_t)n_strict;
+  tm.launches = nr ? 1 : 0;
   tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
   tm.pool_pages = pool.n_pages;
   tm.page_rows = (uint32_t)page_rows;
-  tm.n_static = grp[0].n ? grp[0].n_static : grp[1].n_static;
-  tm.n_waves = std::max(b->group_waves[0], b->group_waves[1]);
+  tm.n_static = n_static;
+  tm.n_waves = (uint32_t)std::min<size_t>((order.size() + dynk::WAVES_PER_CU - 1) / dynk::WAVES_PER_CU * dynk::WAVES_PER_CU,
+                                         (size_t)a->n_cus * dynk::WAVES_PER_CU);
   b->timing = tm;
-  b->n_chunks = launches;
+  b->n_chunks = nr ? 1 : 0;
   b->aligned = job != DynJob::Train;
   b->trained = job == DynJob::Train;
   b->last_calc = calc ? 1 : 0;
@@ -1129,19 +1114,12 @@ int collect_timing(dyn_batch* b) {
   HIP_TRY(a, hipEventElapsedTime(&ms12, ev[1], ev[2]));
   // wave-cycles per phase, summed over all waves of the launch: backward, forward, traceback (+ state
   // write-back and page release), waiting for a read / for pages, lifetime; [5] = longest lifetime
-  double sums[5] = {0, 0, 0, 0, 0}, slot_time = 0.0;  // slot_time: waves x longest lifetime, per launch
-  for (int g = 0; g < 2; ++g) {
-    const uint32_t* words = b->h_stats.as<uint32_t>() + g * dynk::QUEUE_CTL_WORDS;
-    if (words[3] != 0) {
-      a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
-      return DYN_ERR_DEVICE;
-    }
-    const uint64_t* sg = reinterpret_cast<const uint64_t*>(words + dynk::QUEUE_STATS);
-    for (int k = 0; k < 5; ++k) sums[k] += (double)sg[k];
-    slot_time += (double)sg[5] * b->group_waves[g];
+  if (b->h_stats.as<uint32_t>()[3] != 0) {
+    a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
+    return DYN_ERR_DEVICE;
   }
-  const double* s = sums;
-  const double life = sums[4];
+  const uint64_t* s = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::QUEUE_STATS);
+  const double life = (double)s[4];
   tm.ms_dp = ms01;
   tm.ms_total = ms01 + ms12;
   if (life > 0) {
@@ -1149,7 +1127,7 @@ int collect_timing(dyn_batch* b) {
     tm.ms_forward = ms01 * (double)s[1] / life;
     tm.ms_trace = ms01 * (double)s[2] / life + ms12;
     tm.wave_wait_share = (double)s[3] / life;
-    if (slot_time > 0) tm.wave_occupancy = life / slot_time;
+    if (s[5] && tm.n_waves) tm.wave_occupancy = life / ((double)s[5] * tm.n_waves);
   } else {
     tm.ms_trace = ms12;
   }

@@ -139,8 +139,7 @@ struct dyn_batch {
   dyneng::PinnedBuf h_sig;                     // staging of pageable caller signals (asynchronous path)
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;  // ev_done: every kernel of the last job has finished
-  uint32_t n_chunks = 0;                       // read-queue launches enqueued by the last job (0, 1, or 2 with strict reads)
-  uint32_t group_waves[2] = {0, 0};            // persistent waves of the default / strict launch
+  uint32_t n_chunks = 0;                       // launches enqueued by the last job (0 or 1)
   dyn_timing timing{};
   bool aligned = false, trained = false;
   int last_calc = 0;

@@ -1060,7 +1060,9 @@ __global__ void k_pool_init(PagePool pool, uint32_t first_free, uint32_t n_stati
 // by-value argument struct they carry no no-alias information, and hipcc then turns the wave-uniform
 // loads from them (emission parameters in the window-move blocks, read descriptors) into VECTOR loads
 // guarded by s_waitcnt vmcnt(0) -- which drains the forward sweep's DMA ring every ~13 rows.
-template <int JOB, bool STRICT>
+// MIXED: the launch holds reads flagged READ_STRICT; such a read takes the sweeps instantiated with the bit-for-bit
+// arithmetic (dp_math_strict.hpp). The default launches (MIXED = false) do not contain that code at all.
+template <int JOB, bool MIXED>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const ReadDesc* __restrict__ descs,
                                                    const double* __restrict__ sig, const Emis* __restrict__ par,
                                                    const SoftplusNode* __restrict__ sp_tab) {
@@ -1124,19 +1126,33 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     cyc_w += t1 - t0;
 
-    const double Zb = backward_sweep<LATTICE, STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
-    const uint64_t t2 = __builtin_amdgcn_s_memtime();
-    cyc_b += t2 - t1;
-    double Zf;
-    if (JOB == JOB_TRAIN) {
-      Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
-    } else if (JOB == JOB_ALIGN) {
-      Zf = forward_sweep<true, false, STRICT>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
-    } else if (JOB == JOB_ALIGN_INPLACE) {
-      Zf = forward_sweep<true, true, STRICT>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
-    } else {
-      Zf = forward_sweep<false, false, STRICT>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+    const bool strict = MIXED && (rd.flags & READ_STRICT) != 0;  // wave-uniform
+    double Zb, Zf;
+    uint64_t t2;
+    if constexpr (MIXED) {
+      static_assert(JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE, "strict reads exist for align(calc=true) only");
     }
+    if (MIXED && strict) {
+      Zb = backward_sweep<LATTICE, MIXED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+      t2 = __builtin_amdgcn_s_memtime();
+      if (JOB == JOB_ALIGN_INPLACE)
+        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+      else
+        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+    } else {
+      Zb = backward_sweep<LATTICE, false>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+      t2 = __builtin_amdgcn_s_memtime();
+      if (JOB == JOB_TRAIN) {
+        Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
+      } else if (JOB == JOB_ALIGN) {
+        Zf = forward_sweep<true, false, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+      } else if (JOB == JOB_ALIGN_INPLACE) {
+        Zf = forward_sweep<true, true, false>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+      } else {
+        Zf = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+      }
+    }
+    cyc_b += t2 - t1;
     const uint64_t t3 = __builtin_amdgcn_s_memtime();
     cyc_f += t3 - t2;
 
@@ -1456,11 +1472,11 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
   hipLaunchKernelGGL(k_pool_init, dim3((n + 255) / 256), dim3(256), 0, s, pool, first_free, (uint32_t)n_static);
 }
 
-void launch_read_queue(QueueJob job, bool strict, const QueueArgs& q, int n_cus, hipStream_t s) {
+void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n_cus, hipStream_t s) {
   if (q.n_reads <= 0) return;
   const int groups = std::min((q.n_reads + DYN_WAVES_PER_GROUP - 1) / DYN_WAVES_PER_GROUP, std::max(1, n_cus));
   const dim3 grid(groups), block(64 * DYN_WAVES_PER_GROUP);
-  if (strict) {  // only jobs with integer outputs have a strict form
+  if (with_strict) {  // only jobs with integer outputs have strict reads
     if (job == JOB_ALIGN) hipLaunchKernelGGL((k_read_queue<JOB_ALIGN, true>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab);
     else hipLaunchKernelGGL((k_read_queue<JOB_ALIGN_INPLACE, true>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab);
     return;

@@ -46,7 +46,10 @@ struct ReadDesc {
   uint32_t first_page;  // pages first_page .. first_page+n_pages-1 were reserved by the host (first round of a
                         // launch), or NO_PAGE: the wave takes n_pages from the pool's free list
   uint32_t n_pages;     // lattice rows 0..T in pages; 0 for jobs without a stored lattice
+  uint32_t flags;       // READ_STRICT: this read takes the bit-for-bit sweeps (dp_math_strict.hpp)
+  uint32_t reserved;
 };
+constexpr uint32_t READ_STRICT = 1u;
 
 struct ReadState {
   double Zb;          // backwardE(0,0)          (NT_aligner_api.cpp:286)
@@ -125,8 +128,9 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
 // reads off the queue until it is empty; per read backward -> forward (+ posterior, Viterbi fill,
 // decision bits | training statistics) -> Z check -> traceback -> segment-start posteriors.
 // n_cus: compute units of the device (one 4-wave workgroup per CU).
-// strict: the bit-for-bit arithmetic of dp_math_strict.hpp (JOB_ALIGN / JOB_ALIGN_INPLACE only)
-void launch_read_queue(QueueJob job, bool strict, const QueueArgs& q, int n_cus, hipStream_t s);
+// with_strict: the launch holds reads flagged READ_STRICT (JOB_ALIGN / JOB_ALIGN_INPLACE only): the kernel variant
+// that carries both arithmetic flavours and branches per read
+void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n_cus, hipStream_t s);
 // per-segment median posterior + output rows for all reads of descs (after launch_read_queue)
 void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
                      TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s);
