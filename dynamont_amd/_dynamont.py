@@ -129,13 +129,18 @@ class AlignBatchResult:
 
 def format_csv(aligner: "Aligner", res: AlignBatchResult, sequences: Sequence[str], readids: Sequence[str],
                signalids: Sequence[str], sig_offsets: Sequence[int], last_index: Sequence[int],
-               threads: int = 8):
+               threads: int = 8, compact: bool = False, seqs_packed=None):
     """Native segmentation_to_string for a batch (dyn_format_csv). Returns (buffer, begin[n], end[n]):
-    read i's CSV rows are ``buffer[begin[i]:end[i]]`` (empty for failed reads)."""
+    read i's CSV rows are ``buffer[begin[i]:end[i]]`` (empty for failed reads). ``compact=True`` closes the gaps
+    between the reads' ranges (dyn_csv_compact): ``buffer[:end[-1]]`` is then the whole batch in read order.
+    ``seqs_packed`` = (bytes, uint64 offsets) of the sequences if the caller already holds them packed."""
     n = res.n
-    seq_off = np.zeros(n + 1, dtype=np.uint64)
-    seq_off[1:] = np.cumsum(np.array([len(s) for s in sequences], dtype=np.uint64))
-    seqs = "".join(sequences).encode("latin-1")
+    if seqs_packed is not None:
+        seqs, seq_off = seqs_packed
+    else:
+        seq_off = np.zeros(n + 1, dtype=np.uint64)
+        seq_off[1:] = np.cumsum(np.array([len(s) for s in sequences], dtype=np.uint64))
+        seqs = "".join(sequences).encode("latin-1")
     rid = (C.c_char_p * n)(*[str(x).encode() for x in readids])
     sid = (C.c_char_p * n)(*[str(x).encode() for x in signalids])
     so = np.ascontiguousarray(sig_offsets, dtype=np.int64)
@@ -154,6 +159,8 @@ def format_csv(aligner: "Aligner", res: AlignBatchResult, sequences: Sequence[st
                           int(threads), buf.ctypes.data, cap, _ptr(begin, N.c_u64_p), _ptr(end, N.c_u64_p))
     if rc != N.DYN_OK:
         _raise(rc, "dyn_format_csv failed")
+    if compact:
+        L.dyn_csv_compact(buf.ctypes.data, n, _ptr(begin, N.c_u64_p), _ptr(end, N.c_u64_p))
     return buf, begin, end
 
 
@@ -391,6 +398,14 @@ def pinned_empty(n: int, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dt, count=int(n))
 
 
+class _Scattered:
+    """A batch's raw slices as a pointer table (DYN_RAW_SCATTERED); keeps the slices alive."""
+
+    def __init__(self, table: np.ndarray, slices, dtype):
+        self.table, self.slices, self.dtype = table, slices, np.dtype(dtype)
+        self.ctypes = table.ctypes  # .ctypes.data -> the table
+
+
 class Aligner:
     """Mirror of ``_dynamont.Aligner`` (aligner_bindings.cpp:191-216).
 
@@ -526,6 +541,76 @@ class Aligner:
         if rc != N.DYN_OK:
             _raise(rc, self.last_error())
         return AsyncBatch(self, h, out, (sig, sig_off, seqs, seq_off))
+
+    def _raw_args(self, raw, shift, scale, calibration=None):
+        scattered = isinstance(raw, (list, tuple))
+        if scattered:  # one array per read: the library gathers them (DYN_RAW_SCATTERED), no concatenation here
+            slices = [np.ascontiguousarray(x) for x in raw]
+            dt = slices[0].dtype if slices else np.dtype(np.int16)
+            if any(x.dtype != dt for x in slices):
+                raise ValueError("raw slices of one batch must share a dtype")
+            table = np.fromiter((x.ctypes.data for x in slices), dtype=np.uint64, count=len(slices))
+            raw = _Scattered(table, slices, dt)
+        else:
+            raw = np.ascontiguousarray(raw)
+        code = {np.dtype(np.float32): 0, np.dtype(np.int16): 1, np.dtype(np.float64): 2}.get(raw.dtype)
+        if code is None:
+            raise ValueError(f"raw signal dtype {raw.dtype} is not float32, int16 or float64")
+        if scattered:
+            code |= 0x100
+        cal = (None, None)
+        if calibration is not None:  # int16 ADC + pod5 calibration: picoampere formed on the device
+            if code & 0xff != 1:
+                raise ValueError("calibration arrays go with int16 ADC samples")
+            code = 3 | (code & 0x100)
+            cal = (np.ascontiguousarray(calibration[0], dtype=np.float32), np.ascontiguousarray(calibration[1], dtype=np.float32))
+        return raw, code, np.ascontiguousarray(shift, dtype=np.float64), np.ascontiguousarray(scale, dtype=np.float64), cal
+
+    def align_raw_async(self, raw, raw_offsets, shift, scale, seqs: bytes, seq_offsets, window: int = 3,
+                        n_sigmas: float = 3.0, f32: bool = False, calc_probabilities: bool = True,
+                        out: AlignBatchResult | None = None, calibration=None) -> AsyncBatch:
+        """dyn_batch_align_raw_async: ``raw`` = the concatenated RAW [start:end) slices of the batch (float32 pA,
+        int16 ADC or float64), or a LIST of per-read arrays (gathered by the library's helper threads, no copy here); normalisation + Hampel filter (segment.py:146-153) run on the device as the first
+        stage of the asynchronous pipeline. ``calibration`` = (offset[n], scale[n]) with int16 ``raw``: the samples are
+        ADC counts and picoampere = (float32(adc) + offset) * scale is formed on the device too (what pod5's
+        ``signal_pa`` computes on the host). Returns at once."""
+        raw, code, shift, scale, cal = self._raw_args(raw, shift, scale, calibration)
+        raw_off = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(raw_off) - 1
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        if out is None or out.n != n or out.cap < cap:
+            out = AlignBatchResult(n, cap + cap // 8)
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_align_raw_async(self._h, n, raw.ctypes.data, code, _ptr(raw_off, N.c_u64_p),
+                                               _ptr(cal[0], N.c_float_p) if code & 0xff == 3 else None,
+                                               _ptr(cal[1], N.c_float_p) if code & 0xff == 3 else None, _ptr(shift, N.c_double_p), _ptr(scale, N.c_double_p), int(window),
+                                               float(n_sigmas), int(bool(f32)), seqs, _ptr(seq_off, N.c_u64_p),
+                                               int(bool(calc_probabilities)), C.byref(out._c), C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return AsyncBatch(self, h, out, (raw, raw_off, shift, scale, seqs, seq_off, cal))
+
+    def train_raw_async(self, raw, raw_offsets, shift, scale, seqs: bytes, seq_offsets, window: int = 7,
+                        n_sigmas: float = 5.0, f32: bool = True, pooled: bool = False,
+                        emissions: bool = True, calibration=None) -> AsyncBatch:
+        """dyn_batch_train_raw_async (train.py:163-170: float32 arithmetic, Hampel(7, 5 sigma) by default)."""
+        raw, code, shift, scale, cal = self._raw_args(raw, shift, scale, calibration)
+        raw_off = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(raw_off) - 1
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        out = TrainBatchResult(n, cap, self.num_kmers, pooled, emissions)
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_train_raw_async(self._h, n, raw.ctypes.data, code, _ptr(raw_off, N.c_u64_p),
+                                               _ptr(cal[0], N.c_float_p) if code & 0xff == 3 else None,
+                                               _ptr(cal[1], N.c_float_p) if code & 0xff == 3 else None, _ptr(shift, N.c_double_p), _ptr(scale, N.c_double_p), int(window),
+                                               float(n_sigmas), int(bool(f32)), seqs, _ptr(seq_off, N.c_u64_p),
+                                               C.byref(out._c), _ptr(out.pooled, N.c_double_p) if pooled else None,
+                                               C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return AsyncBatch(self, h, out, (raw, raw_off, shift, scale, seqs, seq_off, cal))
 
     def segment_capacity(self, seq_offsets) -> int:
         """dyn_segment_capacity: rows to allocate for a batch with these sequence offsets."""

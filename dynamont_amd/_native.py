@@ -12,13 +12,14 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "nt_kernels.hip"]
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "nt_kernels.hip"]
 HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
 DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)
 
 c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
 c_u64_p = C.POINTER(C.c_uint64)
 c_i32_p = C.POINTER(C.c_int32)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -77,6 +78,13 @@ SIGNATURES = {
     "dyn_format_csv": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(DynAlignOut), C.c_char_p, c_u64_p,
                                  C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_uint64, c_u64_p, c_u64_p]),
+    "dyn_csv_compact": (C.c_uint64, [C.c_void_p, C.c_uint64, c_u64_p, c_u64_p]),
+    "dyn_csv_sink_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
+    "dyn_csv_sink_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DynAlignOut), C.c_uint64, C.c_char_p, c_u64_p,
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_u64_p]),
+    "dyn_csv_sink_error_line": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "dyn_csv_sink_completed": (C.c_uint64, [C.c_void_p]),
+    "dyn_csv_sink_close": (C.c_int, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, C.c_char_p, C.c_uint64]),
     "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                    C.POINTER(C.c_void_p)]),
     "dyn_batch_create_raw": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_double_p, c_double_p,
@@ -96,6 +104,12 @@ SIGNATURES = {
                                         C.POINTER(DynAlignOut), C.POINTER(C.c_void_p)]),
     "dyn_batch_train_async": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                         C.POINTER(DynTrainOut), c_double_p, C.POINTER(C.c_void_p)]),
+    "dyn_batch_align_raw_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_float_p, c_float_p, c_double_p, c_double_p,
+                                            C.c_int, C.c_double, C.c_int, C.c_char_p, c_u64_p, C.c_int,
+                                            C.POINTER(DynAlignOut), C.POINTER(C.c_void_p)]),
+    "dyn_batch_train_raw_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_float_p, c_float_p, c_double_p, c_double_p,
+                                            C.c_int, C.c_double, C.c_int, C.c_char_p, c_u64_p,
+                                            C.POINTER(DynTrainOut), c_double_p, C.POINTER(C.c_void_p)]),
     "dyn_batch_wait": (C.c_int, [C.c_void_p]),
     "dyn_host_alloc": (C.c_void_p, [C.c_uint64]),
     "dyn_host_free": (None, [C.c_void_p]),
@@ -132,7 +146,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-o", LIB_PATH + ".tmp"]
+           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-ldl", "-o", LIB_PATH + ".tmp"]
     cmd += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -177,7 +177,48 @@ int Pipeline::front_stage(dyn_batch* b) {
   // H2D on the copy-in stream. Pinned caller memory (dyn_host_alloc) is a true asynchronous DMA;
   // for pageable memory the runtime stages the copy and this thread blocks for its duration, which
   // is what the thread is for -- the compute stream keeps running the previous batch meanwhile.
-  if (total_sig) {
+  uint64_t raw_max_len = 0;
+  if (total_sig && b->has_raw) {
+    // RAW slices (segment.py:146-153 runs on the device): [offsets | shift | scale | samples] are gathered into ONE
+    // pinned staging buffer by the helper threads and go up with one DMA; k_normalise / k_hampel then run on the
+    // compute stream in front of the batch's read queue.
+    const RawSource& rs = b->raw_src;
+    const size_t esz = rs.elem_size();
+    const uint64_t meta = (4 * n + 1) * 8;  // offsets, shift, scale, (cal_offset, cal_scale); 8-byte aligned
+    P_TRY(b, b->h_sig.ensure(meta + total_sig * esz));
+    uint64_t* h_offs = b->h_sig.as<uint64_t>();
+    double* h_shift = reinterpret_cast<double*>(h_offs + n + 1);
+    double* h_scale = h_shift + n;
+    float* h_cal = reinterpret_cast<float*>(h_scale + n);  // [n] offsets, [n] scales
+    char* h_raw = reinterpret_cast<char*>(h_cal + 2 * n);
+    if (rs.dtype == 3) {
+      std::memcpy(h_cal, rs.cal_offset, n * 4);
+      std::memcpy(h_cal + n, rs.cal_scale, n * 4);
+    }
+    for (uint64_t i = 0; i <= n; ++i) h_offs[i] = b->in_sig_offsets[i] - b->in_sig_offsets[0];
+    for (uint64_t i = 0; i < n; ++i) raw_max_len = std::max(raw_max_len, h_offs[i + 1] - h_offs[i]);
+    std::memcpy(h_shift, rs.shift, n * 8);
+    std::memcpy(h_scale, rs.scale, n * 8);
+    const uint64_t bytes = total_sig * esz;
+    if (rs.scattered) {  // one pointer per read: the gather into the staging buffer IS the only host copy
+      const void* const* slices = static_cast<const void* const*>(rs.raw);
+      const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 8)));
+      helpers.parallel_for(parts, [&](int t) {
+        for (uint64_t i = n * t / parts; i < n * (t + 1) / parts; ++i)
+          std::memcpy(h_raw + h_offs[i] * esz, slices[i], (h_offs[i + 1] - h_offs[i]) * esz);
+      });
+    } else {
+      const char* src = static_cast<const char*>(rs.raw) + b->in_sig_offsets[0] * esz;
+      const int parts = std::max(1, std::min<int>(helpers.size(), (int)(bytes >> 21)));
+      helpers.parallel_for(parts, [&](int t) {
+        const uint64_t lo = bytes * t / parts, hi = bytes * (t + 1) / parts;
+        std::memcpy(h_raw + lo, src + lo, hi - lo);
+      });
+    }
+    P_TRY(b, b->d_meta.ensure(meta + total_sig * esz));
+    P_TRY(b, b->d_norm.ensure(total_sig * (rs.compute_f32 ? 4 : 8)));
+    P_TRY(b, hipMemcpyAsync(b->d_meta.p, b->h_sig.p, meta + bytes, hipMemcpyHostToDevice, a->s_in));
+  } else if (total_sig) {
     const double* src = b->in_signals + b->in_sig_offsets[0];
     if (!is_pinned(src)) {
       // Pageable caller memory is staged HERE, by the helper threads, into a pinned buffer of the batch: measured,
@@ -199,6 +240,15 @@ int Pipeline::front_stage(dyn_batch* b) {
   P_TRY(b, hipEventRecord(b->ev_in, a->s_in));
   const double t4 = now_ms();
   P_TRY(b, hipStreamWaitEvent(a->stream, b->ev_in, 0));
+  if (total_sig && b->has_raw) {
+    const RawSource& rs = b->raw_src;
+    const uint64_t* d_offs = b->d_meta.as<uint64_t>();
+    const double* d_shift = reinterpret_cast<const double*>(d_offs + n + 1);
+    const float* d_cal = reinterpret_cast<const float*>(d_shift + 2 * n);
+    dynk::launch_preprocess(reinterpret_cast<const char*>(d_cal + 2 * n), rs.dtype, rs.compute_f32, d_offs, d_shift, d_shift + n,
+                            d_cal, d_cal + n, b->d_norm.p, b->d_sig.as<double>(), (int)n, raw_max_len, rs.window, rs.n_sigmas, a->stream);
+    P_TRY(b, hipGetLastError());
+  }
   if (b->total_cols) {
     dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
     P_TRY(b, hipGetLastError());
@@ -271,8 +321,20 @@ namespace {
 
 int submit_common(dyn_aligner* a, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
                   const char* seqs, const uint64_t* seq_offsets, DynJob job, dyn_align_out* oa,
-                  dyn_train_out* ot, double* pooled, dyn_batch** ticket) {
-  if (!a || !ticket || !sig_offsets || !seq_offsets || (n_reads && (!signals || !seqs))) return DYN_ERR_INVALID_ARGUMENT;
+                  dyn_train_out* ot, double* pooled, dyn_batch** ticket, const RawSource* rs = nullptr) {
+  if (!a || !ticket || !sig_offsets || !seq_offsets || (n_reads && ((!signals && !rs) || !seqs))) return DYN_ERR_INVALID_ARGUMENT;
+  RawSource rs_local;
+  if (rs) {  // DYN_RAW_SCATTERED: `raw` is a table of n_reads pointers
+    rs_local = *rs;
+    rs_local.scattered = (rs->dtype & DYN_RAW_SCATTERED) != 0;
+    rs_local.dtype = rs->dtype & ~DYN_RAW_SCATTERED;
+    rs = &rs_local;
+  }
+  if (rs && (rs->dtype < 0 || rs->dtype > 3 || rs->window < 1 || rs->window > 16 || (n_reads && (!rs->raw || !rs->shift || !rs->scale)) ||
+             (rs->dtype == 3 && n_reads && (!rs->cal_offset || !rs->cal_scale)))) {
+    a->last_error = "raw batches: raw_dtype must be 0 (f32), 1 (i16), 2 (f64) or 3 (i16 + calibration arrays) and 1 <= window <= 16";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
   *ticket = nullptr;
   {
     std::lock_guard<std::mutex> lk(a->mu);
@@ -303,6 +365,10 @@ int submit_common(dyn_aligner* a, uint64_t n_reads, const double* signals, const
   b->async = true;
   b->job = job;
   b->in_signals = signals;
+  if (rs) {
+    b->has_raw = true;
+    b->raw_src = *rs;
+  }
   b->in_sig_offsets = sig_offsets;
   b->in_seqs = seqs;
   b->in_seq_offsets = seq_offsets;
@@ -331,6 +397,45 @@ int dyn_batch_train_async(dyn_aligner* a, uint64_t n_reads, const double* signal
                           dyn_train_out* out, double* pooled3n, dyn_batch** ticket) {
   if (!out) return DYN_ERR_INVALID_ARGUMENT;
   return submit_common(a, n_reads, signals, sig_offsets, seqs, seq_offsets, DynJob::Train, nullptr, out, pooled3n, ticket);
+}
+
+int dyn_batch_align_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale, int hampel_window,
+                              double hampel_n_sigmas, int compute_f32, const char* seqs, const uint64_t* seq_offsets,
+                              int calc_probabilities, dyn_align_out* out, dyn_batch** ticket) {
+  if (!out) return DYN_ERR_INVALID_ARGUMENT;
+  RawSource rs;
+  rs.raw = raw;
+  rs.dtype = raw_dtype;
+  rs.cal_offset = cal_offset;
+  rs.cal_scale = cal_scale;
+  rs.shift = shift;
+  rs.scale = scale;
+  rs.window = hampel_window;
+  rs.n_sigmas = hampel_n_sigmas;
+  rs.compute_f32 = compute_f32;
+  return submit_common(a, n_reads, nullptr, raw_offsets, seqs, seq_offsets, calc_probabilities ? DynJob::AlignFull : DynJob::AlignZ,
+                       out, nullptr, nullptr, ticket, &rs);
+}
+
+int dyn_batch_train_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale, int hampel_window,
+                              double hampel_n_sigmas, int compute_f32, const char* seqs, const uint64_t* seq_offsets,
+                              dyn_train_out* out, double* pooled3n, dyn_batch** ticket) {
+  if (!out) return DYN_ERR_INVALID_ARGUMENT;
+  RawSource rs;
+  rs.raw = raw;
+  rs.dtype = raw_dtype;
+  rs.cal_offset = cal_offset;
+  rs.cal_scale = cal_scale;
+  rs.shift = shift;
+  rs.scale = scale;
+  rs.window = hampel_window;
+  rs.n_sigmas = hampel_n_sigmas;
+  rs.compute_f32 = compute_f32;
+  return submit_common(a, n_reads, nullptr, raw_offsets, seqs, seq_offsets, DynJob::Train, nullptr, out, pooled3n, ticket, &rs);
 }
 
 int dyn_batch_wait(dyn_batch* b) {

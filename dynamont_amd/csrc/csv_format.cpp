@@ -176,3 +176,19 @@ extern "C" int dyn_format_csv(const dyn_aligner* a, uint64_t n_reads, const dyn_
   }
   return DYN_OK;
 }
+
+// Close the gaps between the per-read slots dyn_format_csv wrote: the rows of all reads become ONE contiguous
+// run at the front of `out`, in read order (what the writer thread hands to the compressor as a single blob).
+// row_begin/row_end are updated; returns the total number of bytes.
+extern "C" uint64_t dyn_csv_compact(char* out, uint64_t n_reads, uint64_t* row_begin, uint64_t* row_end) {
+  if (!out || !row_begin || !row_end) return 0;
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    const uint64_t len = row_end[i] - row_begin[i];
+    if (len && row_begin[i] != pos) std::memmove(out + pos, out + row_begin[i], len);
+    row_begin[i] = pos;
+    pos += len;
+    row_end[i] = pos;
+  }
+  return pos;
+}

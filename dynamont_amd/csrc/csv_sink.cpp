@@ -1,0 +1,395 @@
+// csv_sink.cpp -- the output half of dynamont-resquiggle as native threads: wait for a batch of the asynchronous
+// engine, format its rows, compress them into ONE zstd frame, write the file; `.errors` lines for failed reads.
+//
+// Reference being replaced: the listener process of src/dynamont/segmentation/segment.py:69-107 (a zstd level-3
+// stream writer fed through a multiprocessing queue) and the per-read formatting of utils.py:193-232
+// (csv_format.cpp). One GPU produces ~1 GB of CSV per second; a Python thread per stage loses most of that to the
+// interpreter lock while the producer thread parses the next reads, so the whole back half lives here:
+//
+//   sink thread      dyn_batch_wait(ticket) -> dyn_format_csv (its own threads) -> dyn_csv_compact -> cut into jobs
+//   compress threads one zstd context each; job k of the frame (see below)
+//   writer thread    jobs in order -> fwrite
+//
+// One frame from independent jobs (what zstd's own multi-threaded mode does; the image's libzstd 1.4.8 is built
+// without it, and ships no header -- the few entry points used are bound with dlopen): every job is compressed by
+// a context of its own with the same parameters. Job 0 keeps its frame header; every later job flushes its header
+// into the void (ZSTD_compressContinue with no input) and calls ZSTD_invalidateRepCodes so that its first block
+// does not lean on repeat offsets the decoder will not have at that point; an empty last block closes the frame.
+// Any zstd decoder sees one ordinary frame (tests/test_harness.py, tests/test_gpu_harness.py).
+#include "../../include/dynamont_mi.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Zstd {
+  void* lib = nullptr;
+  void* (*createCCtx)() = nullptr;
+  size_t (*freeCCtx)(void*) = nullptr;
+  size_t (*compressBegin)(void*, int) = nullptr;
+  size_t (*compressContinue)(void*, void*, size_t, const void*, size_t) = nullptr;
+  size_t (*compressEnd)(void*, void*, size_t, const void*, size_t) = nullptr;
+  void (*invalidateRepCodes)(void*) = nullptr;
+  size_t (*compressBound)(size_t) = nullptr;
+  unsigned (*isError)(size_t) = nullptr;
+  const char* (*getErrorName)(size_t) = nullptr;
+
+  bool load(std::string& err) {
+    for (const char* name : {"libzstd.so.1", "libzstd.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = "libzstd.so.1 not found";
+      return false;
+    }
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+#define DYN_Z(field, name)                                        \
+  field = reinterpret_cast<decltype(field)>(sym(name));           \
+  if (!field) {                                                   \
+    err = std::string("libzstd lacks ") + name;                   \
+    return false;                                                 \
+  }
+    DYN_Z(createCCtx, "ZSTD_createCCtx");
+    DYN_Z(freeCCtx, "ZSTD_freeCCtx");
+    DYN_Z(compressBegin, "ZSTD_compressBegin");
+    DYN_Z(compressContinue, "ZSTD_compressContinue");
+    DYN_Z(compressEnd, "ZSTD_compressEnd");
+    DYN_Z(invalidateRepCodes, "ZSTD_invalidateRepCodes");
+    DYN_Z(compressBound, "ZSTD_compressBound");
+    DYN_Z(isError, "ZSTD_isError");
+    DYN_Z(getErrorName, "ZSTD_getErrorName");
+#undef DYN_Z
+    return true;
+  }
+};
+
+constexpr size_t kJobBytes = 4u << 20;
+const char kHeader[] = "readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n";  // segment.py:80
+
+struct Blob {  // the formatted rows of one batch; freed when its last job has been compressed
+  std::unique_ptr<char[]> data;
+  size_t cap = 0;
+};
+
+struct Job {
+  uint64_t index = 0;
+  std::shared_ptr<Blob> blob;  // keeps the source alive
+  const char* src = nullptr;
+  size_t len = 0;
+  bool last = false;  // the terminating job: no data, closes the frame
+  std::vector<char> out;
+  bool done = false;
+};
+
+struct Item {
+  dyn_aligner* a;
+  dyn_batch* ticket;
+  const dyn_align_out* res;
+  uint64_t n;
+  const char* seqs;
+  const uint64_t* seq_offsets;
+  const char* const* readids;
+  const char* const* signalids;
+  const int64_t* sig_offsets;
+  const uint64_t* signal_lengths;
+};
+
+}  // namespace
+
+struct dyn_csv_sink {
+  Zstd z;
+  int level = 3, threads = 4;
+  FILE* out = nullptr;
+  std::string errors_path, error;
+  std::mutex m;
+  std::condition_variable cv_items, cv_jobs, cv_write, cv_space;
+  std::deque<Item> items;
+  std::deque<std::shared_ptr<Job>> todo;             // jobs waiting for a compress thread
+  std::map<uint64_t, std::shared_ptr<Job>> inflight;  // by index, until written
+  uint64_t next_job = 0, next_write = 0;
+  std::atomic<uint64_t> completed{0};
+  uint64_t csv_bytes = 0, zst_bytes = 0;
+  std::atomic<uint64_t> error_lines{0};
+  bool closing = false, items_done = false, jobs_closed = false, failed = false;
+  std::thread t_sink, t_writer;
+  std::vector<std::thread> t_comp;
+  std::vector<std::shared_ptr<Blob>> spare;  // recycled row buffers (first-touch page faults cost more than formatting)
+  std::vector<uint64_t> begin, end;
+  std::vector<int64_t> last_index;
+
+  void fail(const std::string& msg) {  // m held or single-threaded context
+    if (!failed) error = msg;
+    failed = true;
+  }
+
+  void add_job(std::shared_ptr<Blob> blob, const char* src, size_t len, bool last) {
+    std::unique_lock<std::mutex> lk(m);
+    cv_space.wait(lk, [&] { return inflight.size() < (size_t)(4 * threads) || failed; });
+    auto j = std::make_shared<Job>();
+    j->index = next_job++;
+    j->blob = std::move(blob);
+    j->src = src;
+    j->len = len;
+    j->last = last;
+    inflight[j->index] = j;
+    todo.push_back(j);
+    cv_jobs.notify_one();
+  }
+
+  void append(std::shared_ptr<Blob> blob, size_t total) {
+    csv_bytes += total;
+    for (size_t off = 0; off < total; off += kJobBytes) add_job(blob, blob->data.get() + off, std::min(kJobBytes, total - off), false);
+  }
+
+  void compress_loop() {
+    void* ctx = z.createCCtx();
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_jobs.wait(lk, [&] { return !todo.empty() || jobs_closed; });
+        if (todo.empty()) break;
+        j = todo.front();
+        todo.pop_front();
+      }
+      const size_t cap = z.compressBound(j->len) + 64;
+      j->out.resize(cap);
+      size_t rc = z.compressBegin(ctx, level);
+      size_t pos = 0;
+      if (!z.isError(rc) && j->index != 0) {
+        rc = z.compressContinue(ctx, j->out.data(), cap, nullptr, 0);  // this context's frame header: dropped
+        if (!z.isError(rc)) z.invalidateRepCodes(ctx);
+      }
+      if (!z.isError(rc))
+        rc = j->last ? z.compressEnd(ctx, j->out.data(), cap, nullptr, 0) : z.compressContinue(ctx, j->out.data(), cap, j->src, j->len);
+      if (!z.isError(rc)) pos = rc;
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (z.isError(rc)) fail(std::string("zstd: ") + z.getErrorName(rc));
+        j->out.resize(pos);
+        j->blob.reset();
+        j->done = true;
+      }
+      cv_write.notify_one();
+    }
+    z.freeCCtx(ctx);
+  }
+
+  void writer_loop() {
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_write.wait(lk, [&] {
+          auto it = inflight.find(next_write);
+          return (it != inflight.end() && it->second->done) || (jobs_closed && inflight.empty());
+        });
+        auto it = inflight.find(next_write);
+        if (it == inflight.end()) break;
+        j = it->second;
+      }
+      if (!j->out.empty() && std::fwrite(j->out.data(), 1, j->out.size(), out) != j->out.size()) {
+        std::lock_guard<std::mutex> lk(m);
+        fail("write to the output file failed");
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        zst_bytes += j->out.size();
+        inflight.erase(next_write);
+        ++next_write;
+      }
+      cv_space.notify_all();
+      cv_write.notify_one();
+    }
+  }
+
+  void write_error_line(const std::string& line) {
+    FILE* f = std::fopen(errors_path.c_str(), "a");  // created by the first error, like the reference's listener
+    if (!f) {
+      std::lock_guard<std::mutex> lk(m);
+      fail("cannot open " + errors_path);
+      return;
+    }
+    std::fwrite(line.data(), 1, line.size(), f);
+    std::fputc('\n', f);
+    std::fclose(f);
+    ++error_lines;
+  }
+
+  void consume(const Item& it) {
+    const int rc = dyn_batch_wait(it.ticket);
+    if (rc != DYN_OK) {
+      std::lock_guard<std::mutex> lk(m);
+      fail(std::string("batch failed: ") + dyn_aligner_last_error(it.a));
+      return;
+    }
+    if (!it.n) return;
+    last_index.resize(it.n);
+    begin.resize(it.n);
+    end.resize(it.n);
+    for (uint64_t i = 0; i < it.n; ++i) last_index[i] = (int64_t)it.signal_lengths[i] + it.sig_offsets[i];
+    const uint64_t bound = dyn_format_csv_bound(it.a, it.n, it.res, it.readids, it.signalids);
+    std::shared_ptr<Blob> blob;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      for (size_t k = 0; k < spare.size(); ++k)
+        if (spare[k].use_count() == 1 && spare[k]->cap >= bound) {
+          blob = spare[k];
+          break;
+        }
+    }
+    if (!blob) {
+      blob = std::make_shared<Blob>();
+      blob->cap = std::max<size_t>(bound + bound / 8, 1);
+      blob->data.reset(new char[blob->cap]);
+      std::lock_guard<std::mutex> lk(m);
+      if (spare.size() < 4) spare.push_back(blob);
+    }
+    const int frc = dyn_format_csv(it.a, it.n, it.res, it.seqs, it.seq_offsets, it.readids, it.signalids, it.sig_offsets,
+                                   last_index.data(), threads, blob->data.get(), blob->cap, begin.data(), end.data());
+    if (frc != DYN_OK) {
+      std::lock_guard<std::mutex> lk(m);
+      fail("dyn_format_csv failed");
+      return;
+    }
+    const uint64_t total = dyn_csv_compact(blob->data.get(), it.n, begin.data(), end.data());
+    if (total) append(blob, total);
+    for (uint64_t i = 0; i < it.n; ++i) {  // segment.py:172-176
+      if (it.res->status[i] == DYN_READ_OK) continue;
+      char msg[128];
+      dyn_read_strerror(it.res->status[i], it.res->bad_char ? it.res->bad_char[i] : 0, msg, sizeof msg);
+      std::string line = std::string("error: native, ") + msg + "\tT: " + std::to_string(it.signal_lengths[i]) + "\tN: " +
+                         std::to_string(it.seq_offsets[i + 1] - it.seq_offsets[i]) + "\tRid: " + it.readids[i] + "\tSid: " + it.signalids[i];
+      write_error_line(line);
+    }
+  }
+
+  void sink_loop() {
+    {
+      auto hdr = std::make_shared<Blob>();
+      hdr->cap = sizeof kHeader;
+      hdr->data.reset(new char[hdr->cap]);
+      std::memcpy(hdr->data.get(), kHeader, sizeof kHeader - 1);
+      append(hdr, sizeof kHeader - 1);
+    }
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_items.wait(lk, [&] { return !items.empty() || closing; });
+        if (items.empty()) break;
+        it = items.front();
+        items.pop_front();
+      }
+      consume(it);
+      completed.fetch_add(1);
+    }
+    add_job(nullptr, nullptr, 0, true);  // the empty last block that closes the frame
+    {
+      std::lock_guard<std::mutex> lk(m);
+      jobs_closed = true;
+    }
+    cv_jobs.notify_all();
+    cv_write.notify_all();
+  }
+};
+
+extern "C" {
+
+int dyn_csv_sink_open(const char* csv_zst_path, const char* errors_path, int level, int threads, dyn_csv_sink** out,
+                      char* err, uint64_t errcap) {
+  auto put = [&](const std::string& s) {
+    if (err && errcap) {
+      std::snprintf(err, (size_t)errcap, "%s", s.c_str());
+    }
+  };
+  if (!csv_zst_path || !errors_path || !out) return DYN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  std::unique_ptr<dyn_csv_sink> s(new dyn_csv_sink());
+  std::string e;
+  if (!s->z.load(e)) {
+    put(e);
+    return DYN_ERR_RUNTIME;
+  }
+  s->out = std::fopen(csv_zst_path, "wb");
+  if (!s->out) {
+    put(std::string("cannot open ") + csv_zst_path);
+    return DYN_ERR_RUNTIME;
+  }
+  std::setvbuf(s->out, nullptr, _IOFBF, 1 << 20);
+  s->errors_path = errors_path;
+  s->level = level;
+  s->threads = std::max(1, threads);
+  dyn_csv_sink* p = s.release();
+  for (int t = 0; t < p->threads; ++t) p->t_comp.emplace_back([p] { p->compress_loop(); });
+  p->t_writer = std::thread([p] { p->writer_loop(); });
+  p->t_sink = std::thread([p] { p->sink_loop(); });
+  *out = p;
+  return DYN_OK;
+}
+
+int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
+                        const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
+                        const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths) {
+  if (!s || !a || !ticket || !res || !seq_offsets || (n_reads && (!seqs || !readids || !signalids || !sig_offsets || !signal_lengths)))
+    return DYN_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lk(s->m);
+    if (s->closing) return DYN_ERR_INVALID_ARGUMENT;
+    s->items.push_back(Item{a, ticket, res, n_reads, seqs, seq_offsets, readids, signalids, sig_offsets, signal_lengths});
+  }
+  s->cv_items.notify_one();
+  return DYN_OK;
+}
+
+int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line) {
+  if (!s || !line) return DYN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(s->m);  // serialises with nothing but other callers: the sink thread appends through its own handle
+  FILE* f = std::fopen(s->errors_path.c_str(), "a");
+  if (!f) return DYN_ERR_RUNTIME;
+  std::fwrite(line, 1, std::strlen(line), f);
+  std::fputc('\n', f);
+  std::fclose(f);
+  ++s->error_lines;
+  return DYN_OK;
+}
+
+uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s) { return s ? s->completed.load() : 0; }
+
+int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compressed_bytes, uint64_t* error_lines, char* err,
+                       uint64_t errcap) {
+  if (!s) return DYN_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lk(s->m);
+    s->closing = true;
+  }
+  s->cv_items.notify_all();
+  s->t_sink.join();
+  for (auto& t : s->t_comp) t.join();
+  s->t_writer.join();
+  if (std::fclose(s->out) != 0) s->fail("closing the output file failed");
+  if (csv_bytes) *csv_bytes = s->csv_bytes;
+  if (compressed_bytes) *compressed_bytes = s->zst_bytes;
+  if (error_lines) *error_lines = s->error_lines.load();
+  const bool failed = s->failed;
+  if (failed && err && errcap) std::snprintf(err, (size_t)errcap, "%s", s->error.c_str());
+  if (s->z.lib) dlclose(s->z.lib);
+  delete s;
+  return failed ? DYN_ERR_RUNTIME : DYN_OK;
+}
+
+}  // extern "C"

@@ -164,6 +164,10 @@ void HelperPool::parallel_for(int n_tasks, const std::function<void(int)>& fn) {
     for (int i = 0; i < n_tasks; ++i) fn(i);
     return;
   }
+  // ONE job slot: concurrent callers (the pipeline's front and back threads share a pool) take turns. Without
+  // this a second caller overwrote fn_/n_/next_ of a job in progress -- tasks of the first were lost and its
+  // cv_done_ wait could hang (seen once staging became 24 tasks of page-faulting copies).
+  std::lock_guard<std::mutex> turn(call_m_);
   std::unique_lock<std::mutex> lk(m_);
   fn_ = &fn;
   n_ = n_tasks;
@@ -211,7 +215,7 @@ void attach_cache(dyn_batch* b) {
   dyneng::BufCache* c = &b->a->cache;
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
-                    &b->d_pathn})
+                    &b->d_pathn, &b->d_norm, &b->d_meta})
     d->cache = c;
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->cache = c;
 }
@@ -524,16 +528,6 @@ void dyn_host_free(void* p) {
 }  // extern "C"
 
 namespace {
-struct RawSource {
-  const void* raw = nullptr;   // concatenated [start:end) slices
-  int dtype = 0;               // 0 float32, 1 int16, 2 float64
-  const double* shift = nullptr;
-  const double* scale = nullptr;
-  int window = 3;
-  double n_sigmas = 3.0;
-  int compute_f32 = 0;
-};
-
 int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const RawSource* rs,
                 const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
                 dyn_batch** out) {
@@ -577,7 +571,7 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
     if (total_sig) B_TRY(hipMemcpyAsync(b->d_sig.p, signals + sig_offsets[0], total_sig * 8, hipMemcpyHostToDevice, a->stream));
   } else if (total_sig) {
     // P1/P2 on the device (segment.py:146-153): upload the raw slices, normalise, Hampel-filter
-    const size_t esz = rs->dtype == 0 ? 4 : rs->dtype == 1 ? 2 : 8;
+    const size_t esz = rs->elem_size();
     std::vector<uint64_t> offs(n_reads + 1);
     uint64_t max_len = 0;
     for (uint64_t i = 0; i <= n_reads; ++i) offs[i] = sig_offsets[i] - sig_offsets[0];
@@ -593,7 +587,7 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
     B_TRY(hipMemcpyAsync(d_scale.p, rs->scale, n_reads * 8, hipMemcpyHostToDevice, a->stream));
     B_TRY(hipStreamSynchronize(a->stream));  // offs is a local vector
     dynk::launch_preprocess(d_raw.p, rs->dtype, rs->compute_f32, d_offs.as<uint64_t>(), d_shift.as<double>(),
-                            d_scale.as<double>(), d_norm.p, b->d_sig.as<double>(), (int)n_reads, max_len, rs->window,
+                            d_scale.as<double>(), nullptr, nullptr, d_norm.p, b->d_sig.as<double>(), (int)n_reads, max_len, rs->window,
                             rs->n_sigmas, a->stream);
     B_TRY(hipGetLastError());
   }
@@ -658,7 +652,7 @@ void dyn_batch_destroy(dyn_batch* b) {
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
-                    &b->d_pathn})
+                    &b->d_pathn, &b->d_norm, &b->d_meta})
     d->release();
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->release();
   for (hipEvent_t e : b->events) (void)hipEventDestroy(e);

@@ -77,7 +77,7 @@ class HelperPool {
  private:
   void worker();
   std::vector<std::thread> workers_;
-  std::mutex m_;
+  std::mutex m_, call_m_;
   std::condition_variable cv_work_, cv_done_;
   const std::function<void(int)>* fn_ = nullptr;
   int next_ = 0, n_ = 0, active_ = 0;
@@ -123,6 +123,21 @@ struct HostRead {
 
 enum class DynJob { AlignZ, AlignFull, Train };
 
+// P1/P2 on the device (dyn_batch_create_raw / dyn_batch_*_raw_async): the batch's samples arrive as RAW slices
+struct RawSource {
+  const void* raw = nullptr;   // concatenated [start:end) slices; scattered: a table of n_reads pointers, one per slice
+  bool scattered = false;
+  int dtype = 0;               // 0 float32, 1 int16, 2 float64, 3 int16 ADC + per-read float32 calibration
+  const float* cal_offset = nullptr;  // dtype 3: picoampere = (adc + cal_offset) * cal_scale, in float32
+  const float* cal_scale = nullptr;
+  const double* shift = nullptr;
+  const double* scale = nullptr;
+  int window = 3;
+  double n_sigmas = 3.0;
+  int compute_f32 = 0;
+  size_t elem_size() const { return dtype == 0 ? 4 : (dtype == 1 || dtype == 3) ? 2 : 8; }
+};
+
 struct dyn_batch {
   dyn_aligner* a = nullptr;
   uint64_t n = 0;
@@ -137,6 +152,10 @@ struct dyn_batch {
   dyneng::PinnedBuf h_descs, h_state, h_rows;  // h_state/h_rows: D2H targets of the asynchronous path
   dyneng::PinnedBuf h_stats;                   // wave-cycle statistics of the read-queue launch
   dyneng::PinnedBuf h_sig;                     // staging of pageable caller signals (asynchronous path)
+  // raw asynchronous path: [offsets | shift | scale | raw samples] staged in h_sig; device-side scratch of the preprocessing
+  dyneng::DevBuf d_norm, d_meta;
+  bool has_raw = false;
+  RawSource raw_src;
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;  // ev_done: every kernel of the last job has finished
   uint32_t n_chunks = 0;                       // launches enqueued by the last job (0 or 1)

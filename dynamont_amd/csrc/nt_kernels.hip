@@ -1344,16 +1344,27 @@ __global__ void k_final(const ReadDesc* __restrict__ descs, const ReadState* __r
 // |x - med| > n_sigmas * (1.4826 * MAD). Every operation is a single IEEE op in the reference's
 // order, so the result is bit-identical to the NumPy code (tests/test_gpu_preprocess.py).
 // ---------------------------------------------------------------------------------------------
-template <class REAL, class RAW>
+// CAL: the samples are int16 ADC counts with the read's pod5 calibration (pod5_io.py:6-16, `signal_pa`): picoampere
+// = (float(adc) + offset) * scale in float32, one IEEE operation each -- the value the reference's reader hands over.
+template <class REAL, class RAW, bool CAL>
 __global__ void k_normalise(const RAW* __restrict__ raw, const uint64_t* __restrict__ offs,
                             const double* __restrict__ shift, const double* __restrict__ scale,
+                            const float* __restrict__ cal_offset, const float* __restrict__ cal_scale,
                             REAL* __restrict__ norm, int n_reads) {
   const int r = blockIdx.y;
   if (r >= n_reads) return;
   const uint64_t a = offs[r], b = offs[r + 1];
   const REAL sh = (REAL)shift[r], sc = (REAL)scale[r];
+  const float co = CAL ? cal_offset[r] : 0.0f, cs = CAL ? cal_scale[r] : 1.0f;
   for (uint64_t i = a + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b; i += (uint64_t)gridDim.x * blockDim.x) {
-    REAL x = (REAL)raw[i];
+    REAL x;
+    if (CAL) {
+      float pa = (float)raw[i] + co;
+      pa = pa * cs;
+      x = (REAL)pa;
+    } else {
+      x = (REAL)raw[i];
+    }
     x = x - sh;
     norm[i] = x / sc;
   }
@@ -1402,33 +1413,38 @@ __global__ void k_hampel(const REAL* __restrict__ norm, const uint64_t* __restri
 // per-read kernels put the read index in gridDim.y (<= 65 535): larger batches go in slices
 constexpr int MAX_GRID_Y = 65535;
 
-template <class REAL, class RAW>
+template <class REAL, class RAW, bool CAL>
 static void preprocess_t(const RAW* raw, const uint64_t* offs, const double* shift, const double* scale,
-                         void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double ns,
-                         hipStream_t s) {
+                         const float* cal_offset, const float* cal_scale, void* norm_tmp, double* out, int n_reads,
+                         uint64_t max_len, int W, double ns, hipStream_t s) {
   const int bx = (int)std::min<uint64_t>(1024, (max_len + 255) / 256);
   for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {  // offs hold absolute sample positions: slices just shift the read index
     const int nr = std::min(MAX_GRID_Y, n_reads - r0);
-    hipLaunchKernelGGL((k_normalise<REAL, RAW>), dim3(bx ? bx : 1, nr), dim3(256), 0, s, raw, offs + r0, shift + r0,
-                       scale + r0, (REAL*)norm_tmp, nr);
+    hipLaunchKernelGGL((k_normalise<REAL, RAW, CAL>), dim3(bx ? bx : 1, nr), dim3(256), 0, s, raw, offs + r0, shift + r0,
+                       scale + r0, CAL ? cal_offset + r0 : nullptr, CAL ? cal_scale + r0 : nullptr, (REAL*)norm_tmp, nr);
     hipLaunchKernelGGL((k_hampel<REAL>), dim3(bx ? bx : 1, nr), dim3(256), 0, s, (const REAL*)norm_tmp, offs + r0, out,
                        nr, W, ns);
   }
 }
 
 void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
-                       const double* shift, const double* scale, void* norm_tmp, double* out,
-                       int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s) {
+                       const double* shift, const double* scale, const float* cal_offset, const float* cal_scale,
+                       void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s) {
   if (n_reads <= 0) return;
+#define DYN_PRE(REAL, RAW, CAL) \
+  preprocess_t<REAL, RAW, CAL>((const RAW*)raw, offs, shift, scale, cal_offset, cal_scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s)
   if (compute_f32) {
-    if (raw_dtype == 0) preprocess_t<float, float>((const float*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
-    else if (raw_dtype == 1) preprocess_t<float, int16_t>((const int16_t*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
-    else preprocess_t<float, double>((const double*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    if (raw_dtype == 0) DYN_PRE(float, float, false);
+    else if (raw_dtype == 1) DYN_PRE(float, int16_t, false);
+    else if (raw_dtype == 3) DYN_PRE(float, int16_t, true);
+    else DYN_PRE(float, double, false);
   } else {
-    if (raw_dtype == 0) preprocess_t<double, float>((const float*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
-    else if (raw_dtype == 1) preprocess_t<double, int16_t>((const int16_t*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
-    else preprocess_t<double, double>((const double*)raw, offs, shift, scale, norm_tmp, out, n_reads, max_len, W, n_sigmas, s);
+    if (raw_dtype == 0) DYN_PRE(double, float, false);
+    else if (raw_dtype == 1) DYN_PRE(double, int16_t, false);
+    else if (raw_dtype == 3) DYN_PRE(double, int16_t, true);
+    else DYN_PRE(double, double, false);
   }
+#undef DYN_PRE
 }
 
 // ---------------------------------------------------------------------------------------------

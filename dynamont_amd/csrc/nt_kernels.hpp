@@ -116,10 +116,11 @@ struct QueueArgs {
 };
 
 // P1/P2 on the device: out[i] = hampel((REAL(raw[i]) - shift) / scale); REAL = float when compute_f32.
-// raw_dtype: 0 float32, 1 int16, 2 float64. norm_tmp: scratch of total samples * sizeof(REAL).
+// raw_dtype: 0 float32, 1 int16, 2 float64, 3 int16 ADC with per-read float32 calibration (pA = (adc + cal_offset) *
+// cal_scale in float32; cal_* may be null otherwise). norm_tmp: scratch of total samples * sizeof(REAL).
 void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
-                       const double* shift, const double* scale, void* norm_tmp, double* out,
-                       int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s);
+                       const double* shift, const double* scale, const float* cal_offset, const float* cal_scale,
+                       void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s);
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
                         hipStream_t s);
 // free list = pages [first_free, n_pages); queue head = n_static; statistics cleared

@@ -135,3 +135,40 @@ def broadcast_str(comm: "Comm", text: str, src: int = 0) -> str:
         buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
     comm.dist.broadcast(buf, src=src)
     return bytes(buf.cpu().numpy().tobytes()).decode()
+
+
+def abort(comm: "Comm | None", exc: BaseException, grace_s: float = 5.0) -> None:
+    """A rank that fails must not leave the others waiting in a collective until the process-group timeout: print
+    the error, tear the process group down (closing its connections makes peers blocked in a gloo collective fail
+    at once; under ``torch.distributed.run`` the agent kills the remaining ranks as soon as this one has exited
+    non-zero) and leave with exit code 1. Never re-executes anything. A watchdog bounds the teardown itself."""
+    import os
+    import sys
+    import threading
+    import traceback
+    traceback.print_exception(type(exc), exc, exc.__traceback__)
+    print(f"rank {comm.rank if comm else 0}: aborting the job", file=sys.stderr, flush=True)
+    threading.Timer(grace_s, lambda: os._exit(1)).start()
+    try:
+        if comm is not None and comm.dist.is_initialized():
+            comm.dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+    os._exit(1)
+
+
+class abort_on_error:
+    """``with abort_on_error(comm): ...`` -- multi-rank jobs: an exception inside ends the whole job (see abort);
+    single-process runs (comm None): the exception propagates as usual."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if ev is not None and self.comm is not None and not isinstance(ev, SystemExit):
+            abort(self.comm, ev)
+        return False
+

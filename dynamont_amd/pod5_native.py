@@ -287,7 +287,8 @@ class Pod5File:
             return vbz_decompress(col[i].as_py(), samples)
         return np.asarray(col[i].as_py(), dtype=np.int16)  # uncompressed large_list<int16>
 
-    def signal(self, read_id: str, calibrated: bool):
+    def signal_adc(self, read_id: str):
+        """(int16 ADC samples, calibration offset, calibration scale)"""
         if self._index is None:
             self._build_index()
         try:
@@ -297,8 +298,12 @@ class Pod5File:
         rows, offset, scale = self._index[key]  # KeyError = read missing (pod5: missing_ok=False raises too)
         parts = [self._signal_row(int(r)) for r in rows]
         adc = np.concatenate(parts) if len(parts) != 1 else parts[0]
+        return adc, np.float32(offset), np.float32(scale)
+
+    def signal(self, read_id: str, calibrated: bool):
+        adc, offset, scale = self.signal_adc(read_id)
         if calibrated:  # pod5 Calibration: picoampere = (adc + offset) * scale, float32
-            return (adc.astype(np.float32) + np.float32(offset)) * np.float32(scale)
+            return (adc.astype(np.float32) + offset) * scale
         return adc
 
     def close(self):

@@ -22,7 +22,7 @@ from os.path import basename, dirname, exists, isdir, join, splitext
 import numpy as np
 
 from dynamont_amd import Aligner, __version__
-from dynamont_amd.pod5_io import get_signal, iter_basecalls, open_pod5
+from dynamont_amd.pod5_io import get_signal, get_signal_adc, iter_basecalls, open_pod5
 from dynamont_amd.segmentation.utils import get_model, hampel, segmentation_to_string
 from dynamont_amd.zstd_io import open_writer
 
@@ -51,6 +51,10 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
+    p.add_argument("--depth", type=int, default=3, help="batches inside the asynchronous engine at once")
+    p.add_argument("--strict-ties", type=str, default="off", choices=["off", "start", "all"],
+                   help="reproduce the reference's libm bit for bit (dyn_aligner_set_strict): 'start' for reads whose first "
+                        "two k-mers are equal (read-start structural ties), 'all' for every read; ~3.4x the time for those reads")
     p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same bytes)")
     p.add_argument("--parallel-zstd-frames", action="store_true",
                    help="write the CSV as consecutive independent zstd frames (readers must read across frames: "
@@ -148,50 +152,20 @@ def prepare_job(job, is_rna: bool):
 
 
 def prepare_job_raw(job, is_rna: bool):
-    """P1 without the arithmetic: the raw [start:end) slice (float32 picoampere when ``shift <= 400``,
-    int16 ADC otherwise, segment.py:147) and the aligner-orientation read; normalisation and the
-    Hampel filter then run on the device (dyn_batch_create_raw), bit-identically."""
+    """P1 without the arithmetic: the raw [start:end) slice and the aligner-orientation read. The slice is int16 ADC
+    counts; ``cal`` = (offset, scale) when the reference would take the calibrated picoampere signal (``shift <= 400``,
+    segment.py:147), None when it takes the ADC counts themselves. Calibration, normalisation and the Hampel filter
+    then run on the device (dyn_batch_align_raw_async), bit-identically. Returns (raw, read, cal)."""
     raw_file, shift, scale, start, end, read, readid, signalid = job
-    raw = np.ascontiguousarray(get_signal(get_raw(raw_file), signalid, calibrated=shift <= 400)[start:end])
-    if raw.dtype not in (np.float32, np.int16):
+    adc, cal_offset, cal_scale = get_signal_adc(get_raw(raw_file), signalid)
+    raw = adc[start:end]
+    if raw.dtype != np.int16:  # a reader that hands out something else: through the generic float64 path
         raw = raw.astype(np.float64)
     if is_rna:
         read = read[::-1]
         if not read.startswith(POLYA):
             read = POLYA + read
-    return raw, read
-
-
-def _flush(aligner: Aligner, pending, q, is_rna: bool, kmer_size: int, threads: int = 8, raw: bool = False) -> None:
-    """Align one batch and queue CSV bytes / error lines exactly as segment.py:160-176. The rows are
-    formatted by the native dyn_format_csv (same bytes as utils.segmentation_to_string; Python row
-    formatting would be ~50x slower than the GPU)."""
-    if not pending:
-        return
-    from dynamont_amd._dynamont import format_csv
-    signals, reads = [p[0] for p in pending], [p[1] for p in pending]
-    if raw:  # one launch group per raw dtype (float32 pA vs int16 ADC)
-        res = None
-        kinds = sorted({s.dtype.str for s in signals})
-        if len(kinds) > 1:
-            for kd in kinds:
-                _flush(aligner, [p for p in pending if p[0].dtype.str == kd], q, is_rna, kmer_size, threads, raw=True)
-            return
-        with aligner.batch_raw(signals, reads, [p[2][1] for p in pending], [p[2][2] for p in pending]) as b:
-            b.align(True)
-            res = b.fetch(getattr(aligner, "_fetch_cache", None))  # batches run one at a time: refill the arrays
-            aligner._fetch_cache = res
-    else:
-        res = aligner.align_batch(signals, reads, calc_probabilities=True)
-    starts = [p[2][3] for p in pending]
-    buf, begin, end = format_csv(aligner, res, reads, [p[2][6] for p in pending], [p[2][7] for p in pending], starts,
-                                 [len(sig) + st for sig, st in zip(signals, starts)], threads=threads)
-    for i, (signal, read, job) in enumerate(pending):
-        if res.status[i] != 0:
-            _, _, _, _, _, _, readid, signalid = job
-            q.put(f"error: native, {res.error(i)}\tT: {len(signal)}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
-        else:
-            q.put(buf[int(begin[i]):int(end[i])].tobytes())
+    return raw, read, ((cal_offset, cal_scale) if shift <= 400 and raw.dtype == np.int16 else None)
 
 
 class _Collector:
@@ -210,9 +184,212 @@ class _Collector:
         return r, e
 
 
+def _pack_jobs(pending, scattered: bool = False):
+    """(signal slices, reads, jobs) of one batch -> the packed arrays of the C ABI. ``scattered``: the slices stay
+    where they are (a list of arrays; the library gathers them into its pinned staging buffer on its own threads)."""
+    n = len(pending)
+    sig_off = np.zeros(n + 1, dtype=np.uint64)
+    seq_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(p[0]) for p in pending], out=sig_off[1:])
+    np.cumsum([len(p[1]) for p in pending], out=seq_off[1:])
+    if scattered:
+        sig = [p[0] for p in pending]
+    else:
+        sig = np.concatenate([p[0] for p in pending]) if n else np.zeros(0, dtype=np.int16)
+    seqs = "".join(p[1] for p in pending).encode("latin-1")
+    return sig, sig_off, seqs, seq_off
+
+
+class _Pipeline:
+    """The GPU side of dynamont-resquiggle as a stream of batches (the reference keeps a pool of worker processes
+    permanently fed, segment.py:296-325): the caller's thread reads and slices batch k+1 while up to ``depth``
+    batches are inside the asynchronous engine (dyn_batch_align_raw_async: staging, H2D, normalise + Hampel, the
+    read queue, D2H, unpacking -- all overlapped between neighbouring batches), and ONE consumer thread waits for
+    the oldest batch, formats its rows natively (dyn_format_csv, bytes == utils.segmentation_to_string) and hands
+    them to the sink, under the kernels of the batches behind it. Python only moves references; every heavy call
+    releases the GIL."""
+
+    def __init__(self, aligner: Aligner, sink, raw: bool, depth: int = 3, threads: int = 8):
+        self.aligner, self.sink, self.raw, self.threads = aligner, sink, raw, threads
+        self.inflight = queue_mod.Queue(maxsize=max(1, depth))
+        self.free = []            # result objects of completed batches, refilled instead of reallocated
+        self.error = None
+        self.rounds_done = queue_mod.Queue()
+        self.consumer = threading.Thread(target=self._drain, daemon=True)
+        self.consumer.start()
+
+    def submit(self, pending, end_of_round: bool = False) -> None:
+        """Queue one batch (blocks while ``depth`` batches are in flight). Batches whose raw slices have different
+        dtypes (float32 pA vs int16 ADC, segment.py:147) go up as one submission per dtype."""
+        self.check()
+        groups = [pending]
+        if self.raw and pending:  # one submission per kind of raw data: calibrated ADC, plain ADC, anything else
+            kind = lambda p: (p[0].dtype.str, p[3] is not None)  # noqa: E731
+            kinds = sorted({kind(p) for p in pending})
+            if len(kinds) > 1:
+                groups = [[p for p in pending if kind(p) == kd] for kd in kinds]
+        for g in groups:
+            if not g:
+                continue
+            sig, sig_off, seqs, seq_off = _pack_jobs(g, scattered=self.raw)
+            out = self.free.pop() if self.free else None
+            if self.raw:
+                cal = ([p[3][0] for p in g], [p[3][1] for p in g]) if g[0][3] is not None else None
+                t = self.aligner.align_raw_async(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
+                                                 window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out,
+                                                 calibration=cal)
+            else:
+                t = self.aligner.align_async(sig, sig_off, seqs, seq_off, True, out=out)
+            self.inflight.put((t, g, seqs, seq_off))
+        if end_of_round:
+            self.inflight.put("round")
+
+    def check(self) -> None:
+        if self.error is not None:
+            raise self.error
+
+    def wait_round(self) -> None:
+        self.rounds_done.get()
+        self.check()
+
+    def close(self) -> None:
+        """Everything submitted has been formatted and handed to the sink when this returns."""
+        self.inflight.put(None)
+        self.consumer.join()
+        self.check()
+
+    def _finish(self, t, g, seqs, seq_off) -> None:
+        from dynamont_amd._dynamont import format_csv
+        res = t.wait()
+        starts = [p[2][3] for p in g]
+        buf, begin, end = format_csv(self.aligner, res, None, [p[2][6] for p in g], [p[2][7] for p in g], starts,
+                                     [len(p[0]) + st for p, st in zip(g, starts)], threads=self.threads, compact=True,
+                                     seqs_packed=(seqs, seq_off))
+        total = int(end[-1]) if len(end) else 0
+        if total:
+            self.sink.put(buf[:total].tobytes())
+        for i in np.flatnonzero(res.status[:len(g)] != 0):
+            signal, read, job = g[i][:3]
+            self.sink.put(f"error: native, {res.error(i)}\tT: {len(signal)}\tN: {len(read)}\tRid: {job[6]}\tSid: {job[7]}")
+        t.close()
+        self.free.append(res)
+
+    def _drain(self) -> None:
+        while True:
+            item = self.inflight.get()
+            if item is None:
+                return
+            if isinstance(item, str):
+                self.rounds_done.put(True)
+                continue
+            try:
+                if self.error is None:
+                    self._finish(*item)
+                else:
+                    item[0].close()  # after a failure: only release what is still queued
+            except BaseException as e:  # noqa: BLE001  (re-raised on the submitting thread)
+                self.error = e
+                try:
+                    item[0].close()
+                except Exception:  # noqa: BLE001
+                    pass
+
+
+class _NativePipeline:
+    """Single-process form of :class:`_Pipeline` with the whole back half native (csv_sink.cpp): a batch is handed to
+    dyn_batch_align_raw_async and its ticket straight on to the library's CSV sink, whose threads wait for it, format,
+    compress into the one zstd frame and write -- Python only builds the next batch. Same interface as _Pipeline."""
+
+    def __init__(self, aligner: Aligner, outfile: str, raw: bool, depth: int = 3, threads: int = 8):
+        import ctypes as C
+        from dynamont_amd import _native as N
+        self.C, self.N, self.L = C, N, N.lib()
+        self.aligner, self.raw, self.depth = aligner, raw, max(1, depth)
+        errfile = splitext(splitext(outfile)[0])[0] + ".errors"
+        h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = self.L.dyn_csv_sink_open(outfile.encode(), errfile.encode(), 3, int(threads), C.byref(h), err, 1024)
+        if rc != N.DYN_OK:
+            raise OSError(err.value.decode())
+        self.h = h
+        self.submitted = 0
+        self.keep = {}   # batch number -> (ticket, arrays the sink still reads)
+        self.free = []   # result objects of consumed batches
+
+    def put(self, line: str) -> None:
+        """an error line from the producer (reads that failed before the aligner, segment.py:178-187)"""
+        self.L.dyn_csv_sink_error_line(self.h, line.encode())
+
+    def _reap(self, block_until: int | None = None) -> None:
+        import time
+        while True:
+            done = int(self.L.dyn_csv_sink_completed(self.h))
+            for k in [k for k in self.keep if k < done]:
+                t, res = self.keep.pop(k)[:2]
+                t.close()
+                self.free.append(res)
+            if block_until is None or self.submitted - done <= block_until:
+                return
+            time.sleep(0.0005)
+
+    def submit(self, pending, end_of_round: bool = False) -> None:
+        C, N = self.C, self.N
+        groups = [pending]
+        if self.raw and pending:
+            kind = lambda p: (p[0].dtype.str, p[3] is not None)  # noqa: E731
+            kinds = sorted({kind(p) for p in pending})
+            if len(kinds) > 1:
+                groups = [[p for p in pending if kind(p) == kd] for kd in kinds]
+        for g in groups:
+            if not g:
+                continue
+            self._reap(block_until=self.depth - 1)
+            n = len(g)
+            sig, sig_off, seqs, seq_off = _pack_jobs(g, scattered=self.raw)
+            out = self.free.pop() if self.free else None
+            if self.raw:
+                cal = ([p[3][0] for p in g], [p[3][1] for p in g]) if g[0][3] is not None else None
+                t = self.aligner.align_raw_async(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
+                                                 window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out,
+                                                 calibration=cal)
+            else:
+                t = self.aligner.align_async(sig, sig_off, seqs, seq_off, True, out=out)
+            res = t.result
+            rid = (C.c_char_p * n)(*[str(p[2][6]).encode() for p in g])
+            sid = (C.c_char_p * n)(*[str(p[2][7]).encode() for p in g])
+            starts = np.array([p[2][3] for p in g], dtype=np.int64)
+            lengths = np.diff(sig_off).astype(np.uint64)
+            rc = self.L.dyn_csv_sink_submit(self.h, self.aligner._h, t._h, C.byref(res._c), n, seqs,
+                                            seq_off.ctypes.data_as(N.c_u64_p), rid, sid,
+                                            starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p))
+            if rc != N.DYN_OK:
+                t.close()
+                raise RuntimeError("dyn_csv_sink_submit failed")
+            self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths)
+            self.submitted += 1
+
+    def check(self) -> None:
+        pass
+
+    def close(self) -> None:
+        C = self.C
+        if self.h is None:
+            return
+        csv, zst, nerr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        err = C.create_string_buffer(1024)
+        rc = self.L.dyn_csv_sink_close(self.h, C.byref(csv), C.byref(zst), C.byref(nerr), err, 1024)
+        self.h = None
+        for t, *_ in self.keep.values():
+            t.close()
+        self.keep = {}
+        print("Done segmenting reads.", file=sys.stderr)
+        if rc != self.N.DYN_OK:
+            raise RuntimeError(err.value.decode())
+
+
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
-            host_preprocess: bool = False) -> None:
+            host_preprocess: bool = False, depth: int = 3, strict_ties: str = "off") -> None:
     """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
     on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
     the writer (reads are independent; the gather is the only exchange)."""
@@ -221,14 +398,16 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
     rank, world = (comm.rank, comm.world) if comm else (0, 1)
     if comm:
         device = local_rank
-    q = queue_mod.Queue() if rank == 0 else None
+    # single process: the library's native sink owns the output file; multi-rank: rank 0 runs the Python listener
+    # and receives the other ranks' rows through the gather
+    native = comm is None and not ZSTD_PARALLEL_FRAMES
+    q = queue_mod.Queue() if (rank == 0 and not native) else None
     writer = None
-    if rank == 0:
+    if q is not None:
         writer = threading.Thread(target=listener, args=(q, outfile), daemon=True)
         writer.start()
-    sink = q if comm is None else _Collector()
+    sink = None if native else (q if comm is None else _Collector())
     is_rna = "rna" in pore
-    kmer_size = 5 if pore in ("dna_r9", "rna002") else 9
 
     def ship():  # one collective round: everything collected since the last round goes to rank 0
         rows, errs = sink.drain()
@@ -242,58 +421,73 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 for line in blob.decode().split("\n") if blob else []:
                     q.put(line)
 
-    try:
-        aligner = Aligner(model_path, pore, mode=mode, threads=1, band=400, device=device)
-        if mem_budget_gib:
-            aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
-        job_iter = enumerate(generate_jobs(data_path, basecalls, minq))
-        exhausted = False
-        # Two-stage pipeline: this thread reads and slices the next batch (pod5 / BAM, GIL-bound Python)
-        # while one worker thread runs the previous batch through the GPU and the native formatter
-        # (ctypes calls, GIL released). One batch in flight bounds the memory.
-        from concurrent.futures import ThreadPoolExecutor
-        gpu_worker = ThreadPoolExecutor(max_workers=1)
-        in_flight = None
-        while True:
-            pending = []
-            while len(pending) < batch_reads:
-                nxt = next(job_iter, None)
-                if nxt is None:
-                    exhausted = True
-                    break
-                idx, job = nxt
-                if idx % world != rank:  # every rank walks the basecalls and keeps its share
+    # A failing rank ends the whole job (parallel.abort): a barrier in a `finally` would leave the other ranks in
+    # their next collective until the process-group timeout.
+    with parallel.abort_on_error(comm):
+        pipe = None
+        try:
+            aligner = Aligner(model_path, pore, mode=mode, threads=1, band=400, device=device)
+            if mem_budget_gib:
+                aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
+            aligner.set_strict(strict_ties)
+            if native:
+                pipe = sink = _NativePipeline(aligner, outfile, raw=not host_preprocess, depth=depth)
+            else:
+                pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)
+            job_iter = enumerate(generate_jobs(data_path, basecalls, minq))
+            exhausted = False
+            rounds = 0
+            while True:
+                pending = []
+                while len(pending) < batch_reads:
+                    nxt = next(job_iter, None)
+                    if nxt is None:
+                        exhausted = True
+                        break
+                    idx, job = nxt
+                    if idx % world != rank:  # every rank walks the basecalls and keeps its share
+                        continue
+                    try:
+                        if host_preprocess:
+                            signal, read = prepare_job(job, is_rna)
+                            cal = None
+                        else:
+                            signal, read, cal = prepare_job_raw(job, is_rna)
+                    except Exception as error:  # noqa: BLE001  (segment.py:178-187)
+                        _, _, _, _, _, read, readid, signalid = job
+                        sink.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
+                        continue
+                    pending.append((signal, read, job, cal))
+                pipe.submit(pending, end_of_round=comm is not None)
+                if comm is None:
+                    if exhausted:
+                        break
                     continue
+                # multi-rank: round k is on the GPU while round k-1 (complete on every rank) is shipped. Every rank
+                # takes part in every round, with empty payloads once it has run out of reads.
+                if rounds >= 1:
+                    pipe.wait_round()
+                    ship()
+                rounds += 1
+                if not parallel.any_rank(comm, not exhausted):
+                    pipe.wait_round()
+                    ship()
+                    break
+            pipe.close()
+            pipe = None
+            print("Done with segmentation.", file=sys.stderr, flush=True)
+        finally:
+            if pipe is not None:  # an exception is on its way: release what is queued, keep the first error
                 try:
-                    signal, read = prepare_job(job, is_rna) if host_preprocess else prepare_job_raw(job, is_rna)
-                except Exception as error:  # noqa: BLE001  (segment.py:178-187)
-                    _, _, _, _, _, read, readid, signalid = job
-                    sink.put(f"error: worker, {error}\tN: {len(read)}\tRid: {readid}\tSid: {signalid}")
-                    continue
-                pending.append((signal, read, job))
-            if in_flight is not None:
-                in_flight.result()  # re-raises what the batch raised
-            in_flight = gpu_worker.submit(_flush, aligner, pending, sink, is_rna, kmer_size, 8, not host_preprocess)
-            if comm is None:
-                if exhausted:
-                    in_flight.result()
-                    break
-                continue
-            in_flight.result()  # multi-rank: the round's rows must be complete before they are shipped
-            in_flight = None
-            ship()  # collective: every rank takes part in every round, with empty payloads once it is done
-            if not parallel.any_rank(comm, not exhausted):
-                break
-        print("Done with segmentation.", file=sys.stderr, flush=True)
-    finally:
-        if "gpu_worker" in locals():
-            gpu_worker.shutdown(wait=True)
-        if rank == 0:
-            q.put("kill")
-            writer.join()
-        close_raw_cache()
-        if comm is not None and comm.dist.is_initialized():
-            comm.dist.barrier()
+                    pipe.close()
+                except BaseException:  # noqa: BLE001
+                    pass
+            if q is not None:
+                q.put("kill")
+                writer.join()
+            close_raw_cache()
+    if comm is not None and comm.dist.is_initialized():
+        comm.dist.barrier()  # normal completion only
 
 
 def main(argv=None) -> None:
@@ -317,7 +511,7 @@ def main(argv=None) -> None:
     ZSTD_PARALLEL_FRAMES = bool(args.parallel_zstd_frames)
     segment(args.raw, args.basecalls, args.processes, outfile, model_path, args.pore, args.mode, args.qscore,
             device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget,
-            host_preprocess=args.host_preprocess)
+            host_preprocess=args.host_preprocess, depth=args.depth, strict_ties=args.strict_ties)
 
 
 if __name__ == "__main__":

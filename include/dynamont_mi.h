@@ -68,6 +68,11 @@ enum dyn_read_status {
                                     read only (segment.py:172-176), so it is a per-read status, not a batch error */
 };
 
+/* or-ed into raw_dtype of the *_raw_async calls: `raw` is not one concatenated array but a table of n_reads pointers
+ * (const void* const*), one per read's slice; raw_offsets still hold the prefix sums of the slice lengths. The library
+ * gathers the slices into its pinned staging buffer on its helper threads -- no copy on the caller's side. */
+#define DYN_RAW_SCATTERED 0x100
+
 typedef struct dyn_aligner dyn_aligner;
 typedef struct dyn_batch dyn_batch;
 typedef struct dyn_multi dyn_multi;
@@ -230,6 +235,36 @@ int dyn_format_csv(const dyn_aligner* a, uint64_t n_reads, const dyn_align_out* 
                    const int64_t* last_index, int threads, char* out, uint64_t out_cap,
                    uint64_t* row_begin, uint64_t* row_end);
 
+/* Closes the gaps between the per-read ranges dyn_format_csv produced: all rows become one contiguous run at the
+ * front of `out`, in read order; row_begin/row_end are updated. Returns the total byte count. */
+uint64_t dyn_csv_compact(char* out, uint64_t n_reads, uint64_t* row_begin, uint64_t* row_end);
+
+/* ---- the output half of dynamont-resquiggle (src/dynamont/segmentation/segment.py:69-107, the listener) ----
+ *
+ * A sink owns `<out>.csv.zst` (ONE zstd frame at `level`, like the reference's stream writer; header line written at
+ * open) and appends to `<out>.errors`. dyn_csv_sink_submit hands it a ticket of dyn_batch_align[_raw]_async and
+ * returns at once: a sink thread waits for the batch, formats its rows (dyn_format_csv, bytes ==
+ * utils.segmentation_to_string), compresses them on `threads` threads and writes them in submission order; reads
+ * whose status is not DYN_READ_OK get the reference's line
+ * "error: native, <message>\tT: <samples>\tN: <bases>\tRid: <readid>\tSid: <signalid>" (segment.py:172-176).
+ * sig_offsets[i] = sigOffset of segmentation_to_string (the read's first sample in the raw signal), signal_lengths[i]
+ * = its samples (lastIndex = sum). Everything passed to submit (and the ticket) must stay valid until
+ * dyn_csv_sink_completed() has counted the batch; the sink never destroys a ticket. */
+typedef struct dyn_csv_sink dyn_csv_sink;
+int dyn_csv_sink_open(const char* csv_zst_path, const char* errors_path, int level, int threads, dyn_csv_sink** out,
+                      char* err, uint64_t errcap);
+int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
+                        const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
+                        const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths);
+/* one line for `.errors` from the caller (reads that failed before they reached the aligner, segment.py:178-187) */
+int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line);
+/* batches fully consumed so far */
+uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s);
+/* drains, closes the frame and the file, frees the sink; DYN_ERR_RUNTIME + message if any batch, compression or write
+ * failed */
+int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compressed_bytes, uint64_t* error_lines, char* err,
+                       uint64_t errcap);
+
 /* ---- staged form: inputs resident in HBM before the timed region (bench.py, pipelining) ---- */
 
 /* Validate (aligner.cpp:145-164), k-mer-code (aligner.cpp:166-205), and upload one batch. */
@@ -295,6 +330,27 @@ int dyn_batch_align_async(dyn_aligner* a, uint64_t n_reads, const double* signal
 int dyn_batch_train_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
                           const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
                           dyn_train_out* out, double* pooled3n, dyn_batch** ticket);
+/* The asynchronous calls on RAW slices: dyn_batch_create_raw's preprocessing (P1/P2: segment.py:146-153,
+ * train.py:163-170, utils.py:16-43) as the first stage of the same pipeline -- the helper threads gather
+ * [offsets | shift | scale | samples] into pinned staging, one DMA carries them up, k_normalise / k_hampel run on the
+ * compute stream in front of the batch's read queue. This is what dynamont-resquiggle / dynamont-train drive: the
+ * reference keeps its workers fed the same way (segment.py:296-325). raw_dtype 3 (these two calls only): int16 ADC
+ * counts with the read's pod5 calibration, picoampere = (float(adc) + cal_offset[i]) * cal_scale[i] in float32 -- the
+ * value `signal_pa` (src/dynamont/pod5_io.py:6-16) hands the reference, formed on the device instead (half the bytes
+ * over PCIe, no per-read NumPy pass); cal_offset / cal_scale may be NULL for the other dtypes. raw, raw_offsets,
+ * cal_*, shift, scale, seqs, seq_offsets and `out` must stay valid until dyn_batch_wait(ticket) has returned. */
+int dyn_batch_align_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale,
+                              int hampel_window, double hampel_n_sigmas, int compute_f32, const char* seqs,
+                              const uint64_t* seq_offsets, int calc_probabilities, dyn_align_out* out,
+                              dyn_batch** ticket);
+int dyn_batch_train_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw, int raw_dtype,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale,
+                              int hampel_window, double hampel_n_sigmas, int compute_f32, const char* seqs,
+                              const uint64_t* seq_offsets, dyn_train_out* out, double* pooled3n,
+                              dyn_batch** ticket);
 /* Block until the batch behind the ticket is complete; returns its status code, with the message in
  * dyn_aligner_last_error. Returns DYN_OK at once for batches of the synchronous calls. */
 int dyn_batch_wait(dyn_batch* ticket);

@@ -398,3 +398,24 @@ def test_sam_and_bam_readers_round_trip(tmp_path):
     j = jobs[0]
     assert j[0] == "/data/" + tags["fn"] and j[5] == seq and j[6] == name
     assert j[7] == tags.get("pi", name) and j[3] == tags.get("sp", 0) + tags["ts"] and j[4] == tags.get("sp", 0) + tags["ns"]
+
+
+def test_native_csv_sink_frames_header_and_error_lines(native_lib, tmp_path):
+    """csv_sink.cpp without a GPU: an empty run is one zstd frame that holds the CSV header (segment.py:80); error lines
+    handed in by the caller land in `.errors`, one per line (the batches themselves are covered on the GPU box,
+    tests/test_gpu_harness.py compares the CLI's bytes with the oracle pipeline's)."""
+    import ctypes as C
+    from dynamont_amd import zstd_io
+    out, errs = str(tmp_path / "o.csv.zst"), str(tmp_path / "o.errors")
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    assert native_lib.dyn_csv_sink_open(out.encode(), errs.encode(), 3, 4, C.byref(h), err, 512) == 0, err.value
+    assert native_lib.dyn_csv_sink_error_line(h, b"error: worker, boom\tN: 12\tRid: r1\tSid: s1") == 0
+    assert native_lib.dyn_csv_sink_error_line(h, b"error: worker, bang\tN: 7\tRid: r2\tSid: s2") == 0
+    csv, zst, nerr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert native_lib.dyn_csv_sink_close(h, C.byref(csv), C.byref(zst), C.byref(nerr), err, 512) == 0, err.value
+    data = open(out, "rb").read()
+    assert zstd_io.count_frames(data) == 1 and len(data) == zst.value
+    assert zstd_io.decompress(data) == b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
+    assert csv.value == 80 and nerr.value == 2
+    assert open(errs).read().splitlines() == ["error: worker, boom\tN: 12\tRid: r1\tSid: s1", "error: worker, bang\tN: 7\tRid: r2\tSid: s2"]

@@ -100,3 +100,46 @@ def test_gather_and_allreduce(models, tmp_path, oracle_built, world):
     assert np.array_equal(rows["probability"], np.concatenate(prob))
     for r in range(world):
         assert np.allclose(np.load(tmp_path / f"pooled_{r}.npy"), pooled, rtol=1e-12, atol=1e-12)
+
+
+def _failing_worker(rank, world, port):
+    """rounds of the CLIs' collectives; rank 2 fails in round 3 while the others are inside the next gather"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = parallel.Comm()
+    with parallel.abort_on_error(comm):
+        for rnd in range(1000):
+            if rank == 2 and rnd == 3:
+                raise RuntimeError("rank 2 lost its GPU")
+            parallel.gather_bytes(comm, b"rows" * (rank + 1))
+            parallel.any_rank(comm, True)
+    dist.destroy_process_group()
+
+
+def test_one_failing_rank_ends_the_job_within_seconds():
+    """the CLIs ran dist.barrier() in a `finally`, so a rank that raised left the others waiting in their
+    next collective until the process-group timeout (30 min). Now: every rank of a world-4 job exits non-zero within
+    seconds -- the failing one through parallel.abort, the others because their collective fails when its peer is gone."""
+    import time
+    world = 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+    took = time.time() - t0
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(c not in (0, None) for c in codes), codes
+    assert took < 60, took
+

@@ -92,6 +92,7 @@ def test_cli_jobs_from_pod5_equal_jobs_from_npz(models, tmp_path):
         sa, ra = seg.prepare_job(a, True)
         sb, rb = seg.prepare_job(b, True)
         assert ra == rb and np.array_equal(sa, sb)
-        xa, xb = seg.prepare_job_raw(a, True)[0], seg.prepare_job_raw(b, True)[0]
-        assert xa.dtype == xb.dtype and np.array_equal(xa, xb)
+        (xa, _, ca), (xb, _, cb) = seg.prepare_job_raw(a, True), seg.prepare_job_raw(b, True)
+        assert xa.dtype == xb.dtype == np.int16 and np.array_equal(xa, xb)
+        assert ca is not None and ca == cb  # shift <= 400: the calibrated signal, calibration handed on for the device
     seg.close_raw_cache()
