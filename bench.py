@@ -19,6 +19,16 @@ N = 1 workload: BASELINE.json configs[1] -- 1 024 synthetic RNA004 reads x ~20 k
 synthetic 9-mer model, --mode basic, band 400. N > 1: configs[3]'s per-GPU share, 4 096 reads per
 rank and batch, RCCL gather of the segment rows to rank 0 (weak scaling). --mode train: configs[4]'s
 per-GPU share (1 024 reads per rank and batch), RCCL all-reduce of the pooled statistics.
+
+N > 1, what the timed region contains per step and rank: the batch through the drop-in boundary as above, then
+the rank's segment rows (still resident in HBM) into a send buffer, an ASYNCHRONOUS gather to rank 0 over RCCL that
+overlaps the next batch, and on rank 0 the copy of all ranks' rows into pinned host memory -- the line says
+"gather_lands_in": "rank0_pinned_host". The clock stops after the last gather and its host copy have completed.
+
+Import order (asserted below): `torch` is imported BEFORE the first dynamont_amd.Aligner is created. PyTorch's wheel
+bundles its own libamdhip64 and refuses to initialise once another copy is mapped; libdynamont_mi.so links the
+system one and is loaded lazily, at the first Aligner (dynamont_amd/_native.py does the same import itself in any
+process that carries WORLD_SIZE > 1).
 """
 from __future__ import annotations
 
@@ -150,8 +160,9 @@ def main():
     dev = f"cuda:{local_rank}"
     coll_dev = dev if backend == "nccl" else "cpu"
 
-    from dynamont_amd import Aligner
+    from dynamont_amd import Aligner, _native
     from dynamont_amd._dynamont import AlignBatchResult, pinned_empty
+    assert "torch" in sys.modules and _native._lib is None, "torch must be imported before libdynamont_mi.so is loaded"
 
     # ---- the stream of distinct batches, in caller-owned host arrays ----------------------------
     _, mean, sd = synth.read_model_file(model_path)
@@ -172,17 +183,34 @@ def main():
     depth = max(1, args.depth)
     free_results: list = []  # result objects are reused: fresh 50 MB arrays per batch would be page-faulted in every time
 
-    # ---- N > 1: fixed-size device buffers for the gather (sizes differ per rank and batch) -------
-    send_buf = gather_bufs = None
+    # ---- N > 1: fixed-size buffers for the gather (sizes differ per rank and batch), two sets: the gather of step k
+    # is in flight while step k+1 fills the other set
+    NBUF = 2
+    send_bufs = gather_sets = host_sets = None
+    gather_pending = [None] * NBUF
     if use_dist and args.mode == "align":
         cap_local = max(al.segment_capacity(b[3]) for b in batches)
         t = torch.tensor([cap_local], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap_max = int(t.item())
         # [16-byte header: valid bytes][rows ...]
-        send_buf = torch.zeros(16 + cap_max * 16, dtype=torch.uint8, device=dev)
+        send_bufs = [torch.zeros(16 + cap_max * 16, dtype=torch.uint8, device=dev) for _ in range(NBUF)]
         if rank == 0:
-            gather_bufs = [torch.empty_like(send_buf) for _ in range(n_gpus)]
+            gdev = dev if backend == "nccl" else "cpu"
+            gather_sets = [[torch.empty(16 + cap_max * 16, dtype=torch.uint8, device=gdev) for _ in range(n_gpus)] for _ in range(NBUF)]
+            if backend == "nccl":  # where the gathered rows end up: page-locked host memory of rank 0
+                host_sets = [[torch.empty(16 + cap_max * 16, dtype=torch.uint8).pin_memory() for _ in range(n_gpus)] for _ in range(NBUF)]
+
+    def drain_gather(slot):
+        """complete the gather that last used this buffer set; rank 0 then brings the rows to host memory"""
+        work = gather_pending[slot]
+        if work is None:
+            return
+        gather_pending[slot] = None
+        work.wait()  # NCCL: the current stream waits for the collective
+        if rank == 0 and host_sets is not None:
+            for r in range(n_gpus):
+                host_sets[slot][r].copy_(gather_sets[slot][r], non_blocking=True)
 
     def wrap(ptr, nbytes, typestr="|u1", count=None):
         class _A:
@@ -193,6 +221,7 @@ def main():
     kern = collections.Counter()
     launches = collections.Counter()
     done_steps = [0]
+    gather_step = [0]
 
     def submit(j):
         sig, sig_off, seqs, seq_off, _n = batches[j % n_batches]
@@ -213,18 +242,21 @@ def main():
                 else:
                     h = pooled_t.cpu()
                     dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            else:  # config 4: gather of the segment rows to rank 0, device to device over xGMI
+            else:  # config 4: gather of the segment rows to rank 0, device to device over xGMI, asynchronous
+                slot = gather_step[0] % NBUF
+                gather_step[0] += 1
+                drain_gather(slot)
                 ptr, cap, _ = t.device_results()
                 nbytes = cap * 16
-                send_buf[:8].copy_(torch.tensor([nbytes], dtype=torch.int64).view(torch.uint8))
+                sb = send_bufs[slot]
+                sb[:8].copy_(torch.tensor([nbytes], dtype=torch.int64).view(torch.uint8))
                 if nbytes:
-                    send_buf[16:16 + nbytes].copy_(wrap(ptr, nbytes))
+                    sb[16:16 + nbytes].copy_(wrap(ptr, nbytes))
+                torch.cuda.current_stream().synchronize()  # the batch's device buffers are recycled after close()
                 if backend == "nccl":
-                    dist.gather(send_buf, gather_bufs if rank == 0 else None, dst=0)
-                    torch.cuda.current_stream().synchronize()
+                    gather_pending[slot] = dist.gather(sb, gather_sets[slot] if rank == 0 else None, dst=0, async_op=True)
                 else:  # gloo rehearsal: host hop
-                    h = send_buf.cpu()
-                    dist.gather(h, [torch.empty_like(h) for _ in range(n_gpus)] if rank == 0 else None, dst=0)
+                    gather_pending[slot] = dist.gather(sb.cpu(), gather_sets[slot] if rank == 0 else None, dst=0, async_op=True)
         if timed:
             tm = t.timing()
             for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy"):
@@ -248,6 +280,8 @@ def main():
             q.append(submit(s))
         while q:
             last = finish(q.popleft(), timed)
+        for slot in range(NBUF):  # the gathers still in flight (and rank 0's host copies) belong to these steps
+            drain_gather(slot)
         return last
 
     def sync():
@@ -355,6 +389,8 @@ def main():
         if use_dist:
             line["rccl_ranks"] = dist.get_world_size()
             line["collective_backend"] = backend
+            if args.mode == "align":
+                line["gather_lands_in"] = "rank0_pinned_host" if backend == "nccl" else "rank0_host"
             line["per_rank_ms"] = [round(x, 2) for x in per_rank_ms]
         if cpu_out and os.path.exists(cpu_out):
             line["cpu_baseline"] = json.load(open(cpu_out))

@@ -167,6 +167,11 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). dynamont_amd has no CPU or PyTorch fallback.")
+        import sys
+        if "torch" not in sys.modules and int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+            # A multi-rank job will need torch.distributed. PyTorch's wheel bundles its own libamdhip64 and refuses to
+            # initialise once another copy is mapped, so in such a process torch goes first.
+            import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -325,16 +325,14 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap) {
   *out = nullptr;
   const std::string md = mode ? mode : "basic";
-  if (md == "resquiggle" || md == "ntk") {
-    copy_msg(err, errcap, "Aligner mode '" + md + "' (NTK) is outside the scope of the MI355X build; use 'basic'");
-    return DYN_ERR_INVALID_ARGUMENT;
-  }
-  if (md != "basic" && md != "nt") {
+  const bool ntk = md == "resquiggle" || md == "ntk";  // aligner_bindings.cpp:46-49 -> NTKAligner
+  if (!ntk && md != "basic" && md != "nt") {
     copy_msg(err, errcap, "Unknown aligner mode: " + md);  // aligner_bindings.cpp:50
     return DYN_ERR_INVALID_ARGUMENT;
   }
   dyn_aligner* a = new dyn_aligner();
   a->threads = threads;
+  a->ntk = ntk;
   try {
     a->model.load(model_path ? model_path : "", pore, band);
   } catch (const std::invalid_argument& e) {
@@ -472,6 +470,7 @@ int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
     case DYN_READ_TRAIN_Z_MISMATCH: s = "Training failed: alignment scores do not match"; break;
     case DYN_READ_INTERNAL: s = "Traceback left the lattice"; break;
     case DYN_READ_TOO_LARGE: s = "Read too large for the device memory budget"; break;
+    case DYN_READ_NTK_MISMATCH: s = "NTK alignment failed: alignment scores do not match"; break;
     default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
   }
   copy_msg(buf, cap, s);
@@ -843,6 +842,14 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   const PoreModel& m = a->model;
   const int z_fail = job == DynJob::Train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
 
+  // mode "resquiggle"/"ntk": what the reference's NTKAligner does in this snapshot, as observed with the compiled
+  // reference (tests/golden/g11_ntk_messages.json): validateInput / sequenceToKmers errors first, then EVERY read fails
+  // its Zf/Zb check (NTK_aligner_api.cpp:911-917), and train() is the base class's "not implemented" (aligner.cpp:38-44).
+  // No kernel runs; the reads get the per-read status whose message is the reference's exception text.
+  if (a->ntk && job == DynJob::Train) {
+    a->last_error = "Training is not implemented for this aligner";
+    return DYN_ERR_RUNTIME;
+  }
   // Strict reads (align(calc=true) only, opt-in through dyn_aligner_set_strict) take the sweeps that reproduce the
   // reference's libm bit for bit (dp_math_strict.hpp) -- mode 1: reads whose first two k-mers are equal (the symmetric
   // read-start tie, NT_aligner_api.cpp:445-448), mode 2: every read. They run in the SAME launch as the others (a
@@ -856,6 +863,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   for (uint64_t i = 0; i < b->n; ++i) {
     const HostRead& r = b->reads[i];
     if (r.status != DYN_READ_OK) continue;
+    if (a->ntk) continue;  // no read reaches the device; its status is set below
     is_strict[i] = calc && (a->strict_mode == 2 || (a->strict_mode == 1 && r.kc >= 2 && km[r.flat_off] == km[r.flat_off + 1]));
     n_strict += is_strict[i];
     order.push_back((uint32_t)i);
@@ -930,7 +938,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   for (uint64_t i = 0; i < b->n; ++i) {
     st[i].Zb = 0.0;
     st[i].Zf = 0.0;
-    st[i].status = b->reads[i].status;
+    st[i].status = (a->ntk && b->reads[i].status == DYN_READ_OK) ? DYN_READ_NTK_MISMATCH : b->reads[i].status;
     st[i].n_segments = 0;
   }
   if (lattice) {

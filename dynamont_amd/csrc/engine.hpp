@@ -101,6 +101,7 @@ struct dyn_aligner {
   dyneng::DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
   uint64_t mem_budget = 0;
   int strict_mode = 0;  // dyn_aligner_set_strict
+  bool ntk = false;     // created with mode "resquiggle" / "ntk"
   std::string last_error;
   // grow-only lattice workspace pool, reused across batches (only ever touched by work on `stream`,
   // whose order serialises the batches that share it)

@@ -63,6 +63,10 @@ enum dyn_read_status {
   DYN_READ_Z_MISMATCH = 5,       /* "Alignment failed: alignment scores do not match"  NT_aligner_api.cpp:288-291 */
   DYN_READ_TRAIN_Z_MISMATCH = 6, /* "Training failed: alignment scores do not match"   NT_aligner_api.cpp:622-625 */
   DYN_READ_INTERNAL = 7,         /* traceback left the lattice (cannot happen once the Z check passed) */
+  DYN_READ_NTK_MISMATCH = 9,     /* "NTK alignment failed: alignment scores do not match"  NTK_aligner_api.cpp:911-917:
+                                    what every read that passes validation gets from a handle created with mode
+                                    "resquiggle"/"ntk" -- the reference's NTKAligner fails that check on every read in this
+                                    snapshot (observed with the compiled reference, tests/golden/g11_ntk_messages.json) */
   DYN_READ_TOO_LARGE = 8         /* "Read too large for the device memory budget": this read's lattice alone exceeds
                                     the HBM budget (or 2^31 rows); the reference would raise std::bad_alloc for that
                                     read only (segment.py:172-176), so it is a per-read status, not a batch error */
@@ -167,9 +171,14 @@ typedef struct dyn_timing {
 int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errcap);
 
 /* PyAligner ctor -> makeAligner -> NTAligner ctor (aligner_bindings.cpp:34-51,112-130;
- * NT_aligner_api.cpp:11-19; aligner.cpp:13-36,88-143). mode must be "basic" or "nt"
- * ("resquiggle"/"ntk" are out of scope, any other value -> "Unknown aligner mode: <m>").
- * device < 0 -> current HIP device. */
+ * NT_aligner_api.cpp:11-19; aligner.cpp:13-36,88-143). mode "basic" or "nt": the NT path this library accelerates.
+ * mode "resquiggle" or "ntk" (-> NTKAligner, aligner_bindings.cpp:46-49) is accepted like the reference accepts it and
+ * behaves like the reference's does in this snapshot: reads fail validation with the usual messages or get
+ * DYN_READ_NTK_MISMATCH, training returns DYN_ERR_RUNTIME "Training is not implemented for this aligner" (aligner.cpp:
+ * 38-44); no kernel runs. Any other value -> DYN_ERR_INVALID_ARGUMENT "Unknown aligner mode: <m>".
+ * band: the reference takes any value (aligner.cpp:21); this build's kernels hold 448 band slots per lattice row, so
+ * band > 447 -> DYN_ERR_INVALID_ARGUMENT "band <b> exceeds this build's limit of 447 ..." (every caller in the
+ * reference fixes band = 400: segment.py:45, utils.py:161). device < 0 -> current HIP device. */
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap);
 void dyn_aligner_destroy(dyn_aligner* a);

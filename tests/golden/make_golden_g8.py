@@ -11,13 +11,16 @@ What is the reference here
     /root/reference/src/cpp/{aligner,NT_aligner_api}.cpp compiled in place), called exactly where
     train.py calls them: train() with the model file of the current batch (utils.py:163-182), then
     align(calc_probabilities=False) with the NEW model file for the Z change (utils.py:184-191);
-  * the update arithmetic: restated below from /root/reference/src/dynamont/segmentation/train.py
-    -- ManagedList (:19-46: deque(maxlen=100), np.mean), the collectors initialised with the start
-    model and {'e1': 1.0, 'm1': 0.03, 'e2': 0.97} (:76-82,:104-106), per read: transitions added first,
-    then the "skip weird trainings" test on the polyA k-mer mean < 0.5, then EVERY k-mer of the dense
-    per-read model added to its window (:186-205), per batch: parameter := window mean, model file
-    written with f-string formatting, params.csv row `epoch,batch,reads,e1,m1,e2,Zchange` (:210-242).
-    The reference script itself cannot be imported here (pysam / pod5 are not installed).
+  * the update arithmetic: the reference's OWN `ManagedList` class (train.py:19-46) and `write_kmer_model`
+    (utils.py:136-153), imported in place from /root/reference/src/dynamont/segmentation/{train,utils}.py with empty
+    placeholder modules registered for the imports those files make at module scope and this path never touches
+    (pysam, pod5, seaborn, dynamont._dynamont -- the same trick G6 uses for utils.py): one ManagedList per k-mer and
+    parameter, exactly as train.py:104-106 builds them. What is still restated from the text of train() (:68-253; the
+    function itself needs real pod5/BAM input) is the ORDER in which it feeds them: collectors initialised with the
+    start model and {'e1': 1.0, 'm1': 0.03, 'e2': 0.97} (:76-82), per read transitions added first, then the "skip
+    weird trainings" test on the polyA k-mer mean < 0.5, then EVERY k-mer of the dense per-read model added to its
+    window (:186-205), per batch parameter := ManagedList.mean(), model file written, params.csv row
+    `epoch,batch,reads,e1,m1,e2,Zchange` (:210-242).
   * the reads come through OUR reader and preprocessing (dynamont_amd.segmentation.train.read_items,
     host path: float32 `x -= sm; x /= sd; hampel(x, 7, 5.)` as train.py:163-170; hampel is pinned to the
     reference's own outputs by G6), from the seeded synthetic dataset the test regenerates.
@@ -31,10 +34,11 @@ Scenario "a": polyA mean 0.9 -> every read updates the emission windows. Scenari
 """
 from __future__ import annotations
 
+import importlib.util
 import os
 import sys
 import tempfile
-from collections import deque
+import types
 
 import numpy as np
 
@@ -47,7 +51,36 @@ from oracle.pyoracle import Reference  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 PORE, PORE_ID, K = "dna_r10_400bps", 4, 9
 BATCH, N_BATCHES, SEED = 4, 2, 808
-WINDOW = 100
+REFROOT = "/root/reference"
+
+
+def load_reference_train_module():
+    """/root/reference/src/dynamont/segmentation/train.py imported in place (for ManagedList), with utils.py beside it."""
+    for name in ("seaborn", "pysam", "pod5"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    pkg = sys.modules.setdefault("dynamont", types.ModuleType("dynamont"))
+    pkg.Aligner, pkg.__version__, pkg.__path__ = object, "golden", []
+    io_stub = types.ModuleType("dynamont.pod5_io")
+    io_stub.get_signal = io_stub.open_pod5 = None
+    sys.modules["dynamont.pod5_io"] = io_stub
+    seg = types.ModuleType("dynamont.segmentation")
+    seg.__path__ = []
+    sys.modules["dynamont.segmentation"] = seg
+
+    def load(modname, rel):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REFROOT, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    utils = load("dynamont.segmentation.utils", "src/dynamont/segmentation/utils.py")
+    train = load("dynamont.segmentation.train", "src/dynamont/segmentation/train.py")
+    return train, utils
+
+
+REF_TRAIN, REF_UTILS = load_reference_train_module()
+ManagedList = REF_TRAIN.ManagedList
 
 
 def dataset(tmp, polyA):
@@ -61,14 +94,6 @@ def dataset(tmp, polyA):
     return model, mean, sd, raw, bam
 
 
-def write_model_like_reference(path, names, mean, sd):
-    # utils.py:136-153: f'{kmer}\t{mean}\t{stdev}\n' with numpy floats
-    with open(path, "w") as w:
-        w.write("kmer\tlevel_mean\tlevel_stdv\n")
-        for n, m, s in zip(names, mean, sd):
-            w.write(f"{n}\t{m}\t{s}\n")
-
-
 def run(polyA):
     tmp = tempfile.mkdtemp(prefix="g8_")
     model_path, mean0, sd0, _raw, bam = dataset(tmp, polyA)
@@ -76,10 +101,9 @@ def run(polyA):
     nk = 4 ** K
     items = [it for it in read_items(tmp, bam, PORE, 0.0, raw=False) if not isinstance(it, str)]
     assert len(items) == BATCH * N_BATCHES, len(items)
-    # collectors (train.py:104-106): one deque per parameter, initialised with the start value
-    win_mean = [deque([mean0.copy()], maxlen=WINDOW)]  # every k-mer gets the same sequence of adds -> one deque of vectors
-    win_sd = [deque([sd0.copy()], maxlen=WINDOW)]
-    trans = {"e1": deque([1.0], maxlen=WINDOW), "m1": deque([0.03], maxlen=WINDOW), "e2": deque([0.97], maxlen=WINDOW)}
+    # collectors (train.py:104-106): the reference's ManagedList per k-mer and parameter, initialised with the start value
+    collect = [[ManagedList([mean0[c]]), ManagedList([sd0[c]])] for c in range(nk)]
+    trans = {"e1": ManagedList([1.0]), "m1": ManagedList([0.03]), "e2": ManagedList([0.97])}
     cur_mean, cur_sd = mean0.copy(), sd0.copy()
     cur_model = model_path
     out, i = {}, 0
@@ -93,21 +117,21 @@ def run(polyA):
             i += 1
             preZ.append(r["Z"])
             for p in ("m1", "e1", "e2"):
-                trans[p].append(float(r[p]))
+                trans[p].add(float(r[p]))
             touched |= set(np.nonzero((r["mean"] != cur_mean) | (r["stdev"] != cur_sd))[0].tolist())
             if r["mean"][0] < 0.5:  # 'AAAAAAAAA' in newModels and newModels['AAAAAAAAA'][0] < 0.5
                 continue
             any_seen = True
-            win_mean[0].append(r["mean"])
-            win_sd[0].append(r["stdev"])
-        tp = {p: float(np.mean(trans[p])) for p in ("e1", "m1", "e2")}
+            rm, rs = r["mean"], r["stdev"]
+            for c in range(nk):  # train.py:202-205: every k-mer of the dense per-read model goes into its window
+                collect[c][0].add(rm[c])
+                collect[c][1].add(rs[c])
+        tp = {p: float(trans[p].mean()) for p in ("e1", "m1", "e2")}
         if any_seen:  # `for kmer in kmers_seen: model[kmer] = [mean of window, ...]` -- dense results: all k-mers seen
-            # np.mean over the deque of ONE k-mer's scalars = a contiguous 1-D reduction (pairwise from 8 values
-            # on); reducing the last, contiguous axis of a (k-mers, window) array performs the same additions
-            cur_mean = np.ascontiguousarray(np.stack(list(win_mean[0])).T).mean(axis=1)
-            cur_sd = np.ascontiguousarray(np.stack(list(win_sd[0])).T).mean(axis=1)
+            cur_mean = np.array([collect[c][0].mean() for c in range(nk)])
+            cur_sd = np.array([collect[c][1].mean() for c in range(nk)])
         cur_model = os.path.join(tmp, f"trained_0_{cb + 1}.model")
-        write_model_like_reference(cur_model, names, cur_mean, cur_sd)
+        REF_UTILS.write_kmer_model(cur_model, {n: [m, sdev] for n, m, sdev in zip(names, cur_mean, cur_sd)})
         ref2 = Reference(cur_model, PORE_ID)
         postZ = [ref2.align(np.asarray(sig, dtype=np.float64), seq, False)["Z"] for sig, seq, _ in batch]
         dZ = float(np.mean(np.array(postZ) - np.array(preZ)))

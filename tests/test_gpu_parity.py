@@ -307,9 +307,9 @@ def _full_size_properties(reads, res, k):
     assert np.all(np.isfinite(res.Z))
 
 
-def test_cfg2_full_size_properties_and_parity_on_32_reads(models, al9):
+def test_cfg2_full_size_properties_and_parity_on_64_reads(models, al9):
     """BASELINE configs[1]: 1 024 RNA004 reads x ~20 k samples. Size-independent properties on
-    all reads, full parity against the oracle on 32 of them (every 33rd read)."""
+    all reads, full parity against the oracle on every 33rd read and on every read with a structural-tie decision (63 reads)."""
     _, mean, sd = synth.read_model_file(models["syn9"])
     cfg = synth.CONFIGS["cfg2"]
     reads = synth.make_reads(cfg["seed"], cfg["n_reads"], cfg["pore"], mean, sd, cfg["n_bases"])
@@ -344,9 +344,15 @@ def test_cfg4_share_full_size(models, al9):
         tm = b.timing()
     assert tm["reads_ok"] == 4096 and tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == 1024
     _full_size_properties(reads, res, al9.kmer_size)
-    # reads of the first round (longest), of the middle of the queue and of its tail (shortest)
+    # 64 reads against the oracle: 48 spread evenly over the queue (longest first: the first round, the rounds taken
+    # off the queue on the device, the tail) + 16 of the reads that START with a structural tie (pad + A: the first
+    # two 9-mers are equal), spread the same way
     order = np.argsort([-len(r.signal) for r in reads], kind="stable")
-    _oracle_parity(models["syn9"], 1, reads, res, [int(order[j]) for j in (0, 1023, 1024, 2500, 4000, 4095)])
+    picks = {int(order[j]) for j in np.linspace(0, 4095, 48).astype(int)} | {int(order[j]) for j in (1023, 1024)}
+    ties = [int(i) for i in order if reads[i].sequence.startswith("A" * 10)]
+    assert len(ties) > 500
+    picks |= {ties[j] for j in np.linspace(0, len(ties) - 1, 16).astype(int)}
+    _oracle_parity(models["syn9"], 1, reads, res, sorted(picks))
 
 
 def test_cfg3_full_size(models):
@@ -367,9 +373,11 @@ def test_cfg3_full_size(models):
     assert tm["lp_inplace"] == 1 and 0 < tm["n_static"] <= 1024
     _full_size_properties(reads, res, al.kmer_size)
     order = np.argsort([-len(r.signal) for r in reads], kind="stable")
-    # the longest read, reads from the long and the short end of the first round, a mid-queue read, the shortest
-    _oracle_parity(models["syn9"], synth.PORES[cfg["pore"]][0], reads, res,
-                   [int(order[j]) for j in (0, 700, 2048, 4000, 4095)], procs=5)
+    # 64 reads against the oracle, spread evenly over the length order (the longest and the shortest included; up to
+    # ~12 s and 2.6 GB of oracle per read: 8 processes), plus every read that starts with a homopolymer of k+1 bases
+    picks = {int(order[j]) for j in np.linspace(0, 4095, 64).astype(int)}
+    picks |= {i for i, r in enumerate(reads) if len(set(r.sequence[:10])) == 1}
+    _oracle_parity(models["syn9"], synth.PORES[cfg["pore"]][0], reads, res, sorted(picks), procs=8)
     al.close()
 
 
@@ -688,3 +696,24 @@ def test_page_starved_queues_equal_the_unconstrained_run(models, al9, monkeypatc
         assert np.array_equal(a["signal_positions"], c["signal_positions"]) and a["Z"] == c["Z"]
         assert np.array_equal(a["probabilities"], c["probabilities"])
     small.close()
+
+
+def test_g11_ntk_mode_answers_like_the_reference(models):
+    """mode "resquiggle"/"ntk": the reference's NTKAligner fails every read that passes validation with one message
+    and does not train (G11, generated from the compiled reference); these texts reach `.errors`, so they are output."""
+    g = json.load(open(os.path.join(GOLDEN, "g11_ntk_messages.json")))
+    for pore in ("rna002", "dna_r9", "rna004"):
+        cases = [c for c in g["cases"] if c["pore"] == pore]
+        al = Aligner(models[cases[0]["model"]], pore, mode="resquiggle", device=0)
+        res = al.align_batch([np.array(c["signal"]) for c in cases], [c["sequence"] for c in cases], True)
+        assert [res.error(i) for i in range(len(cases))] == [c["align"] for c in cases]
+        assert int(res.n_segments.sum()) == 0
+        for c in cases[:2]:
+            with pytest.raises(RuntimeError) as e:
+                al.align(np.array(c["signal"]), c["sequence"], True)
+            assert str(e.value) == c["align"]
+            with pytest.raises(RuntimeError) as e:
+                al.train(np.array(c["signal"]), c["sequence"])
+            assert str(e.value) == c["train"]
+        al.close()
+
