@@ -369,6 +369,55 @@ DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], 
   for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
 }
 
+// The training sweep's form of log_plus_finish_sigma: the share only has to be good to ~1e-11 relative (the statistics
+// it weights are compared at 1e-9), so sigma stops one degree earlier,
+//   sigma(d_i + r) = s + (u r) ( 1 + r ( w/2 + r (1-6u)/6 ) )        truncation <= |w (1-12u)| / 24 (1/256)^4 u = 1e-11 u,
+// two operations fewer per cell. logPlus itself is the full-accuracy polynomial (Zf goes through the same Z check).
+// Cells [J0, J1) only: the training sweep finishes the seven lookups of a lane in two groups, because the polynomial's
+// temporaries for all seven at once push the row past 256 VGPRs (hipcc then parks values in AGPRs: ~70 moves per row).
+template <int M, int J0, int J1>
+DYN_HD void log_plus_finish_sigma3(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
+  constexpr int K = J1 - J0;
+  double u[K], w[K], p[K], q[K], dp[K];
+  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
+  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = 1.0 - L.s[J0 + j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) u[j] = L.s[J0 + j] * w[j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = w[j] - L.s[J0 + j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) q[j] = fma_(u[j], m10, c120);
+#pragma unroll
+  for (int j = 0; j < K; ++j) q[j] = q[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) p[j] = fma_(u[j], m4, c24);                           // (1 - 6u)/24
+#pragma unroll
+  for (int j = 0; j < K; ++j) dp[j] = fma_(p[j] * 4.0, L.r[J0 + j], w[j] * 0.5);    // w/2 + r (1-6u)/6
+#pragma unroll
+  for (int j = 0; j < K; ++j) p[j] = fma_(q[j], L.r[J0 + j], p[j]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) dp[j] = fma_(dp[j], L.r[J0 + j], 1.0);
+#pragma unroll
+  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], L.r[J0 + j], w[j] * (1.0 / 6.0));
+#pragma unroll
+  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], L.r[J0 + j], 0.5);
+#pragma unroll
+  for (int j = 0; j < K; ++j) u[j] = u[j] * L.r[J0 + j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) sig[J0 + j] = fma_(dp[j], u[j], L.s[J0 + j]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], u[j], L.s[J0 + j]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) out[J0 + j] = L.hi[J0 + j] + fma_(p[j], L.r[J0 + j], L.g0[J0 + j]);
+}
+
+template <int M>
+DYN_HD void log_plus_finish_sigma3(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
+  log_plus_finish_sigma3<M, 0, M>(L, out, sig);
+}
+
 // exp(d) for M independent arguments (training pass: the posterior mass exp(LPE) of every cell), d <= ~0.
 // d = k ln2/64 + r with k = rint(d 64/ln2) by the magic-number addition, |r| <= ln2/128 = 5.4e-3:
 //   exp(d) = 2^(k >> 6) * T[k & 63] * (1 + r(1 + r(1/2 + r(1/6 + r(1/24 + r/120)))))

@@ -173,18 +173,39 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
   return e;
 }
 
-// STRICT (dp_math_strict.hpp): the reference's expressions operation by operation, glibc's exp / log1p bit for bit.
-// The slot that normally carries 1/stdev then carries stdev itself (true IEEE division).
-template <bool STRICT>
+// Arithmetic flavours of the sweeps.
+//  ARITH_DEFAULT  dp_math.hpp: 5-operation emission, table softplus (<= 1 ulp from glibc)
+//  ARITH_STRICT   dp_math_strict.hpp: the reference's expressions operation by operation, glibc's exp / log1p bit for
+//                 bit; the slot that normally carries 1/stdev then carries stdev itself (true IEEE division)
+//  ARITH_FOLDED   training only: -0.5 log 2pi folded into the per-slot constant (4 operations instead of 5). The sums of
+//                 the training pass are compared at 1e-9 and its Z values go through the 1e-8-per-cell check; no integer
+//                 decision hangs on the last bit there, unlike in the align sweeps
+constexpr int ARITH_DEFAULT = 0, ARITH_STRICT = 1, ARITH_FOLDED = 2;
+
+template <int ARITH>
 __device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
   p.set(j, e);
-  if (STRICT) p.inv_stdev[j] = e.stdev;
+  if (ARITH == ARITH_STRICT) p.inv_stdev[j] = e.stdev;
+  if (ARITH == ARITH_FOLDED) p.neg_log_stdev[j] = e.neg_log_stdev - dynmath::HALF_LOG_2PI;
 }
 
-template <bool STRICT>
+template <int ARITH>
 __device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, double (&out)[CPL]) {
-  if constexpr (STRICT) dynmath::log_normal_pdf_strict_vec<CPL>(x, p, out);
-  else log_normal_pdf_vec<CPL>(x, p, out);
+  if constexpr (ARITH == ARITH_STRICT) {
+    dynmath::log_normal_pdf_strict_vec<CPL>(x, p, out);
+  } else if constexpr (ARITH == ARITH_FOLDED) {
+    double z[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) z[j] = x - p.mean[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) z[j] = z[j] * p.inv_stdev[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) z[j] = z[j] * z[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) out[j] = dynmath::fma_(z[j], -0.5, p.neg_log_stdev[j]);
+  } else {
+    log_normal_pdf_vec<CPL>(x, p, out);
+  }
 }
 
 __device__ __forceinline__ const uint64_t* strict_tab(const SoftplusNode* s_tab) {
@@ -297,7 +318,7 @@ __device__ __forceinline__ void ring_read_row(unsigned slot_addr, int lane, doub
 // n+1 < N guards arithmetically; the upper band edge is handled in the window-move block.
 // Returns Zb = bE(0,0) (-inf when the signal holds a non-finite sample).
 // ---------------------------------------------------------------------------------------------
-template <bool STORE, bool STRICT>
+template <bool STORE, int ARITH>
 __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par, double* __restrict__ ws,
@@ -324,7 +345,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     for (int j = 0; j < CPL; ++j) {
       const int slot = lane * CPL + j;
       n[j] = lo + pmod(slot - lo);
-      set_emis<STRICT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
+      set_emis<ARITH>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
       bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
       bM[j] = NEG_INF;
     }
@@ -340,7 +361,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
     bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
-    emission_vec<STRICT>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
+    emission_vec<ARITH>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
     // one lattice row: reads (bE_in, bM_in) = row t+1, writes (bE_out, bM_out) = row t; the loop is unrolled by two and
     // ping-pongs between the two pairs (see forward_sweep: no register moves at the loop's back edge)
     auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
@@ -364,7 +385,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
-            set_emis<STRICT>(p, j, fresh);
+            set_emis<ARITH>(p, j, fresh);
           }
           // Upper band edge: bM(t, top) = A must not see the in-band cell (t+1, top); Y keeps it for
           // the diagonal into (t, top-1). From row t on the slot carries the "no k-mer" parameters, so
@@ -374,7 +395,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
           // e = -inf before anything reads it.
           if (n[j] == top) {
             bM_out[j] = NEG_INF;
-            set_emis<STRICT>(p, j, none);
+            set_emis<ARITH>(p, j, none);
           }
         }
         lo = new_lo;
@@ -384,7 +405,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x2[j] = bM_out[j] + e2;
       SoftplusLookup<CPL> L;
-      if constexpr (STRICT) dynmath::log_plus_strict_vec<CPL>(x1, x2, bE_out, strict_tab(s_tab));
+      if constexpr (ARITH == ARITH_STRICT) dynmath::log_plus_strict_vec<CPL>(x1, x2, bE_out, strict_tab(s_tab));
       else log_plus_issue<CPL>(x1, x2, L, s_tab);
       // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
       // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: the value computed
@@ -393,9 +414,9 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       //  in every row)
       {
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
-        emission_vec<STRICT>(xnext, p, e);
+        emission_vec<ARITH>(xnext, p, e);
       }
-      if constexpr (!STRICT) log_plus_finish<CPL>(L, bE_out);
+      if constexpr (ARITH != ARITH_STRICT) log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
       // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
       if (STORE) store_row_f64<true>(out + rt, lane, bE_out);
@@ -496,14 +517,14 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    set_emis<STRICT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+    set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
     sa.fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     sa.fM[j] = NEG_INF;
     sa.vE[j] = sa.fE[j];                     // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
     sa.vM[j] = NEG_INF;
     sa.b[j] = POST ? lat[r1 + pos_of(lane, j)] : NEG_INF;
   }
-  emission_vec<STRICT>(x0, p, sa.e);  // e(1, n)
+  emission_vec<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(x0, p, sa.e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
@@ -537,8 +558,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
           // and fE/vE(t-1, lo) stay where this row and the right neighbour (fEl/vEl) still read them.
           const bool leaves = n[j] == lo;
           n[j] = leaves ? lo + P : n[j];
-          if (leaves) set_emis<STRICT>(p, j, none);
-          if (n[j] == lo + W) set_emis<STRICT>(p, j, entering);  // first band row of this column is t+1
+          if (leaves) set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, none);
+          if (n[j] == lo + W) set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, entering);  // first band row of this column is t+1
         }
         lo = next_lo;
       }
@@ -552,7 +573,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     for (int j = 0; j < CPL; ++j) a2[j] = (in.fE[j] + in.e[j]) + e2;
     if constexpr (STRICT) {
       dynmath::log_plus_strict_vec<CPL>(a1, a2, out.fE, strict_tab(s_tab));
-      emission_vec<STRICT>(xn, p, out.e);
+      emission_vec<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(xn, p, out.e);
     } else {
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(a1, a2, L, s_tab);
@@ -802,6 +823,20 @@ __device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, cons
 // left are written out at the NEXT window move (or at the end), not in the row loop.
 // Returns Zf; the two transition sums go to tb.trans.
 // ---------------------------------------------------------------------------------------------
+// Round 3 (the sweep is issue-bound): fewer fp64 operations per cell and no register moves at the
+// loop's back edge --
+//  * fM, fE, e are updated IN PLACE, in an order in which every old value has had its last use before its successor is
+//    defined (x1 and op2 first, then the neighbour exchange, then fM; e after the lookups are issued; fE from the
+//    polynomial): the allocator keeps each in one register across iterations. Two full ping-pong sets (as in
+//    forward_sweep) were tried first: 350 registers, ~70 AGPR moves per row;
+//  * gamma_E(t,n) is carried ONE row: it pairs with the same sample as gamma_M of the same row, which is produced one
+//    row late (see above), so each cell adds w = gamma_E(t-1) + gamma_E(t) shareM = one FMA, then aw += w, a1 += w x,
+//    a2 += w x^2 (4 operations instead of 6); the row loop is unrolled by two for these seven values alone; the last
+//    row's gamma_E is added after the loop;
+//  * one transition sum per cell: with awsum = the sum of all column weights, sum gamma_M = awsum - sum gamma_E and the
+//    E->E mass = awsum - 2 sum gamma_M, formed when the column sums are written out;
+//  * sigma to degree 3 (log_plus_finish_sigma3), the exponential from the 2^(k/128) table with the scale assembled
+//    from bits (exp_table128_vec), the emission with its constant folded.
 __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                       const double* __restrict__ sig, const Emis* __restrict__ par,
                                                       const double* __restrict__ ws, TrainBuffers tb, double Z,
@@ -815,118 +850,160 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
+  const uint64_t* __restrict__ etab = strict_tab(s_tab);
   RowCursor cur_dma;
 
   int lo = band_mid(1, ratio) - bw;  // band of row 1
-  int n[CPL];
-  double fM[CPL], fE[CPL], e[CPL], bcur[CPL];
+  double fM[CPL], fE[CPL], e[CPL];
+  double gEa[CPL], gEb[CPL];  // gamma_E of the previous row / of this row, roles alternating
   double aw[CPL], a1[CPL], a2[CPL];
   EmisV<CPL> p;
-  double sumM = 0.0, sumE2 = 0.0;
+  double sumE = 0.0, awsum = 0.0;
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int slot = lane * CPL + j;
-    n[j] = lo + pmod(slot - lo);
-    p.set(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
-    fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;
+    const int nj = lo + pmod(lane * CPL + j - lo);
+    set_emis<ARITH_FOLDED>(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0));
+    fE[j] = (nj == 0) ? 0.0 : NEG_INF;
     fM[j] = NEG_INF;
+    gEa[j] = 0.0;
     aw[j] = a1[j] = a2[j] = 0.0;
   }
-  log_normal_pdf_vec<CPL>(x0, p, e);  // e(1, n)
+  emission_vec<ARITH_FOLDED>(x0, p, e);  // e(1, n)
   // ring prologue: rows 1 .. RING_D (row r lives in ring slot r % RING_D); rows past T repeat the -inf row T
   const double* __restrict__ dma_src = ws + lane * 2;
   for (int r = 1; r <= RING_D; ++r)
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
 
+  // one lattice row t; xp = sample of row t-1, xn = sample of row t+1; g_prev = gamma_E(t-1, .), g_out = gamma_E(t, .)
+  auto row = [&](int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
+    double fEl[CPL], bcur[CPL], x1[CPL], op2[CPL], sgm[CPL], aE[CPL];
+    bool m_smaller[CPL];  // the arrival from M is the smaller operand of the logPlus (kept as lane masks, not as values)
+    // a slot holds column lo + (slot - lo) mod P: recomputed in the rare block below instead of carried in 7 registers
+    const int next_lo = band_mid(t + 1, ratio) - bw;
+    if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
+      const Emis none = load_emis(pr, 0, 0);
+      const Emis entering = load_emis(pr, lo + W, N);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int nj = lo + pmod(lane * CPL + j - lo);
+        // the slot handed on at the PREVIOUS move (column lo-1) has received nothing but zeros since
+        if (nj == lo - 1 + P) {
+          if (lo - 1 >= 1 && lo - 1 < N) {
+            cw[lo - 2] = aw[j];
+            cs1[lo - 2] = a1[j];
+            cs2[lo - 2] = a2[j];
+          }
+          awsum += aw[j];
+          aw[j] = a1[j] = a2[j] = 0.0;
+        }
+        // column lo is in the band for the last time in this row (see forward_sweep): from the next row on its slot
+        // belongs to column lo + P; column lo + W enters the band with the next row
+        if (nj == lo) set_emis<ARITH_FOLDED>(p, j, none);
+        if (nj == lo + W) set_emis<ARITH_FOLDED>(p, j, entering);
+      }
+      lo = next_lo;
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) x1[j] = fM[j] + e[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) op2[j] = (fE[j] + e[j]) + e2;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) m_smaller[j] = op2[j] >= x1[j];
+    from_left(fE, fEl);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) fM[j] = (fEl[j] + e[j]) + m1;
+    SoftplusLookup<CPL> L;
+    log_plus_issue<CPL>(x1, op2, L, s_tab);
+    emission_vec<ARITH_FOLDED>(xn, p, e);
+    // the polynomial (and the exponential below) in two groups of cells: the temporaries of all seven at once push the
+    // row past 256 VGPRs and hipcc then parks values in AGPRs (~70 moves per row instead of ~50)
+    dynmath::log_plus_finish_sigma3<CPL, 0, 4>(L, fE, sgm);
+    __builtin_amdgcn_sched_barrier(0);
+    dynmath::log_plus_finish_sigma3<CPL, 4, CPL>(L, fE, sgm);
+    __builtin_amdgcn_sched_barrier(0);
+    // bE(t, .) from the ring, as late as possible (fewer live values through the lookup and the polynomial); its slot
+    // is then refilled with row t + RING_D
+    wait_vmcnt<RING_WAIT>();
+    ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, bcur);
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) aE[j] = (fE[j] + bcur[j]) - Z;
+    dynmath::exp_table128_vec<CPL, 0, 4>(aE, g_out, etab);
+    __builtin_amdgcn_sched_barrier(0);
+    dynmath::exp_table128_vec<CPL, 4, CPL>(aE, g_out, etab);
+    __builtin_amdgcn_sched_barrier(0);
+    const double xp2 = xp * xp;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      // sgm = share of the SMALLER operand; the arrival from M is x1. gamma_M(t-1,n) = gamma_E(t,n) * shareM, and cell
+      // (t-1,n) contributes gamma_E(t-1,n) + gamma_M(t-1,n) with the sample of row t-1
+      const double shareM = m_smaller[j] ? sgm[j] : 1.0 - sgm[j];
+      const double wgt = dynmath::fma_(g_out[j], shareM, g_prev[j]);
+      aw[j] += wgt;
+      a1[j] = dynmath::fma_(wgt, xp, a1[j]);
+      a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
+      sumE += g_out[j];
+    }
+  };
+
   double xt = x0, xp = 0.0;  // samples of rows t and t-1
+  bool odd = false;
   for (int tb0 = 1; tb0 < T; tb0 += 64) {
     const int idx = tb0 + lane;
     const double xs = (idx < T - 1) ? sg[idx] : 0.0;
     asm volatile("" ::"v"(xs));  // the load's wait belongs here, not into the row loop (see forward_sweep)
     const int iend = min(64, T - tb0);
+    int i = 0;
 #pragma unroll 1
-    for (int i = 0; i < iend; ++i) {
-      const int t = tb0 + i;
-      const double xn = readlane_f64(xs, i);
-      double fEl[CPL];
-      wait_vmcnt<RING_WAIT>();
-      ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, bcur);  // bE(t, .)
-      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
-      from_left(fE, fEl);
-      const int next_lo = band_mid(t + 1, ratio) - bw;
-      if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
-        const Emis none = load_emis(pr, 0, 0);
-        const Emis entering = load_emis(pr, lo + W, N);
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          // the slot handed on at the PREVIOUS move (column lo-1) has received nothing but zeros since
-          if (n[j] == lo - 1 + P) {
-            if (lo - 1 >= 1 && lo - 1 < N) {
-              cw[lo - 2] = aw[j];
-              cs1[lo - 2] = a1[j];
-              cs2[lo - 2] = a2[j];
-            }
-            aw[j] = a1[j] = a2[j] = 0.0;
-          }
-          const bool leaves = n[j] == lo;  // in the band for the last time in this row (see forward_sweep)
-          n[j] = leaves ? lo + P : n[j];
-          if (leaves) p.set(j, none);
-          if (n[j] == lo + W) p.set(j, entering);
-        }
-        lo = next_lo;
-      }
-      double x1[CPL], op2[CPL], fMn[CPL], fEn[CPL], en[CPL], sgm[CPL], aE[CPL], gE[CPL];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) fMn[j] = (fEl[j] + e[j]) + m1;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) x1[j] = fM[j] + e[j];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) op2[j] = (fE[j] + e[j]) + e2;
-      SoftplusLookup<CPL> L;
-      log_plus_issue<CPL>(x1, op2, L, s_tab);
-      log_normal_pdf_vec<CPL>(xn, p, en);
-      dynmath::log_plus_finish_sigma<CPL>(L, fEn, sgm);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) aE[j] = (fEn[j] + bcur[j]) - Z;
-      dynmath::exp_vec<CPL>(aE, gE, reinterpret_cast<const double*>(s_tab + SP_NODES));
-      const double xt2 = xt * xt, xp2 = xp * xp;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const double shareE = (op2[j] >= x1[j]) ? 1.0 - sgm[j] : sgm[j];  // share of the arrival from E
-        const double gT = gE[j] * shareE;             // E(t-1,n) -> E(t,n)
-        const double gMp = gE[j] - gT;                // = exp(LPM(t-1,n)): the rest of the cell's mass
-        aw[j] = (aw[j] + gE[j]) + gMp;
-        a1[j] = dynmath::fma_(gMp, xp, dynmath::fma_(gE[j], xt, a1[j]));
-        a2[j] = dynmath::fma_(gMp, xp2, dynmath::fma_(gE[j], xt2, a2[j]));
-        sumM += gMp;
-        sumE2 += gT;
-        fM[j] = fMn[j];
-        fE[j] = fEn[j];
-        e[j] = en[j];
-      }
+    for (; i + 1 < iend; i += 2) {
+      const double xa = readlane_f64(xs, i), xb = readlane_f64(xs, i + 1);
+      row(tb0 + i, xa, xp, gEa, gEb);
+      row(tb0 + i + 1, xb, xt, gEb, gEa);
+      xp = xa;
+      xt = xb;
+    }
+    if (i < iend) {  // odd tail (last block of a read only): the roles of the two gamma_E sets stay swapped
+      const double xa = readlane_f64(xs, i);
+      row(tb0 + i, xa, xp, gEa, gEb);
       xp = xt;
-      xt = xn;
+      xt = xa;
+      odd = true;
     }
   }
   wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
+  // gamma_E of the last row (xp now holds that row's sample; gamma_M(T-1, .) = 0: no successor)
+  {
+    const double xl2 = xp * xp;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const double g = odd ? gEb[j] : gEa[j];
+      aw[j] += g;
+      a1[j] = dynmath::fma_(g, xp, a1[j]);
+      a2[j] = dynmath::fma_(g, xl2, a2[j]);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    const int c = (n[j] == lo - 1 + P) ? lo - 1 : n[j];  // the slot handed on at the last move still holds that column's sums
+    const int nj = lo + pmod(lane * CPL + j - lo);
+    const int c = (nj == lo - 1 + P) ? lo - 1 : nj;  // the slot handed on at the last move still holds that column's sums
     if (c >= 1 && c < N) {
       cw[c - 1] = aw[j];
       cs1[c - 1] = a1[j];
       cs2[c - 1] = a2[j];
     }
+    awsum += aw[j];
   }
-  // wave reduction of the two transition sums
+  // wave reduction. Every cell's gamma_E and gamma_M are in awsum; gamma_E = (E->E mass) + gamma_M per cell, so
+  // sum gamma_M = awsum - sum gamma_E and the E->E mass = sum gamma_E - sum gamma_M
   for (int off = 32; off >= 1; off >>= 1) {
-    sumM += __shfl_xor(sumM, off);
-    sumE2 += __shfl_xor(sumE2, off);
+    sumE += __shfl_xor(sumE, off);
+    awsum += __shfl_xor(awsum, off);
   }
   if (lane == 0) {
+    const double sumM = awsum - sumE;
     tb.trans[2 * rd.read] = sumM;
-    tb.trans[2 * rd.read + 1] = sumE2;
+    tb.trans[2 * rd.read + 1] = sumE - sumM;
   }
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);
@@ -1133,14 +1210,14 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
       static_assert(JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE, "strict reads exist for align(calc=true) only");
     }
     if (MIXED && strict) {
-      Zb = backward_sweep<LATTICE, MIXED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+      Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
       t2 = __builtin_amdgcn_s_memtime();
       if (JOB == JOB_ALIGN_INPLACE)
         Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
       else
         Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
     } else {
-      Zb = backward_sweep<LATTICE, false>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+      Zb = backward_sweep<LATTICE, JOB == JOB_TRAIN ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
       t2 = __builtin_amdgcn_s_memtime();
       if (JOB == JOB_TRAIN) {
         Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
