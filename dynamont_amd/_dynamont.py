@@ -655,6 +655,62 @@ class Aligner:
         return self.train_batch([signal], [sequence]).read(0, mean, sd)
 
 
+class RcclComm:
+    """dyn_comm_*: the RCCL gather / all-reduce of a one-process-per-GPU job, below Python (no torch needed).
+    ``RcclComm.unique_id()`` on rank 0, hand the 128 bytes to the other ranks, then ``RcclComm(id, rank, n_ranks, device)``
+    on every rank (collective)."""
+
+    ROW = np.dtype([("signal_pos", "<u4"), ("sequence_pos", "<u4"), ("probability", "<f8")])
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        err = C.create_string_buffer(ERRCAP)
+        rc = N.lib().dyn_comm_unique_id(buf, err, ERRCAP)
+        if rc != N.DYN_OK:
+            _raise(rc, err.value.decode())
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, rank: int, n_ranks: int, device: int = 0):
+        self._L = N.lib()
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        h = C.c_void_p()
+        err = C.create_string_buffer(ERRCAP)
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = self._L.dyn_comm_create(idbuf, self.rank, self.n_ranks, int(device), C.byref(h), err, ERRCAP)
+        if rc != N.DYN_OK:
+            _raise(rc, err.value.decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dyn_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def gather_rows(self, batch, root: int = 0, total_rows_hint: int = 0):
+        """(rows, counts): on ``root`` a structured array of every rank's segment rows in rank order; elsewhere rows is
+        None. ``batch``: an aligned Batch or an AsyncBatch ticket. ``total_rows_hint``: capacity to provide on root
+        (default: n_ranks x this rank's own count, retried with the exact total if that was too small)."""
+        counts = np.zeros(self.n_ranks, dtype=np.uint64)
+        own = int(batch.capacity) if hasattr(batch, "capacity") else int(batch.result.cap)
+        cap = int(total_rows_hint) or max(1, own * self.n_ranks)
+        rows = np.empty(cap, dtype=self.ROW) if self.rank == root else None
+        rc = self._L.dyn_comm_gather_rows(self._h, batch._h, int(root), rows.ctypes.data if rows is not None else None,
+                                          cap if rows is not None else 0, _ptr(counts, N.c_u64_p))
+        if rc != N.DYN_OK:
+            _raise(rc, (self._L.dyn_comm_last_error(self._h) or b"").decode())
+        return (rows[:int(counts.sum())] if rows is not None else None), counts
+
+    def allreduce_pooled(self, batch, num_kmers: int) -> np.ndarray:
+        out = np.empty(3 * int(num_kmers))
+        rc = self._L.dyn_comm_allreduce_pooled(self._h, batch._h, _ptr(out, N.c_double_p))
+        if rc != N.DYN_OK:
+            _raise(rc, (self._L.dyn_comm_last_error(self._h) or b"").decode())
+        return out
+
+
 class MultiAligner:
     """dyn_multi_*: one handle driving several GPUs of a node from ONE process. Reads of a batch are cut into
     contiguous ranges of equal lattice work, one per device; results come back in the layout of a single-device

@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "nt_kernels.hip"]
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "rccl_comm.cpp", "nt_kernels.hip"]
 HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
@@ -113,6 +113,12 @@ SIGNATURES = {
     "dyn_batch_wait": (C.c_int, [C.c_void_p]),
     "dyn_host_alloc": (C.c_void_p, [C.c_uint64]),
     "dyn_host_free": (None, [C.c_void_p]),
+    "dyn_comm_unique_id": (C.c_int, [c_u8_p, C.c_char_p, C.c_uint64]),
+    "dyn_comm_create": (C.c_int, [c_u8_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
+    "dyn_comm_destroy": (None, [C.c_void_p]),
+    "dyn_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "dyn_comm_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, c_u64_p]),
+    "dyn_comm_allreduce_pooled": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "dyn_multi_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.c_int,
                                    C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_multi_destroy": (None, [C.c_void_p]),

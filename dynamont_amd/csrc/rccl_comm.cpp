@@ -1,0 +1,263 @@
+// rccl_comm.cpp -- the two exchanges of a multi-GPU job, below Python: an RCCL gather of per-read segment rows to one
+// rank (BASELINE.json config 4) and a sum all-reduce of the pooled Baum-Welch statistics (config 5), straight from the
+// device buffers of a batch, over xGMI.
+//
+// The reference has no counterpart: it scales by forking worker processes on one host
+// (src/dynamont/segmentation/segment.py:296-325) whose results travel through a multiprocessing queue. Reads are
+// independent (NTAligner::align keeps no cross-read state, NT_aligner_api.cpp:230-312), so one process per GPU aligns
+// its shard and these calls are the only traffic between them. RCCL is bound with dlopen at the first dyn_comm_create:
+// processes that never call it (every single-GPU use, dyn_multi_*) neither need nor load librccl.
+//
+// Pattern chosen for point-to-point xGMI (7 links per GPU, no switch): the gather is one ncclSend per non-root rank and
+// one ncclRecv per peer on the root inside a group -- every peer's rows cross its OWN link to the root once, no ring,
+// no padding to a common size (counts are exchanged first with an 8-byte all-gather).
+#include "engine.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  std::string error;
+
+  bool load() {
+    if (lib) return true;
+    // a process that already carries an RCCL (PyTorch bundles one) must not get a second copy: try the global scope first
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      if (lib) break;
+    }
+    if (!lib)
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+      }
+    if (!lib) {
+      error = "librccl.so.1 not found";
+      return false;
+    }
+#define DYN_R(field, name)                                              \
+  field = reinterpret_cast<decltype(field)>(dlsym(lib, name));          \
+  if (!field) {                                                         \
+    error = std::string("librccl lacks ") + name;                       \
+    lib = nullptr;                                                      \
+    return false;                                                       \
+  }
+    DYN_R(GetUniqueId, "ncclGetUniqueId");
+    DYN_R(CommInitRank, "ncclCommInitRank");
+    DYN_R(CommDestroy, "ncclCommDestroy");
+    DYN_R(GetErrorString, "ncclGetErrorString");
+    DYN_R(GroupStart, "ncclGroupStart");
+    DYN_R(GroupEnd, "ncclGroupEnd");
+    DYN_R(Send, "ncclSend");
+    DYN_R(Recv, "ncclRecv");
+    DYN_R(AllReduce, "ncclAllReduce");
+    DYN_R(AllGather, "ncclAllGather");
+#undef DYN_R
+    return true;
+  }
+};
+
+Rccl g_rccl;
+
+void put_err(char* err, uint64_t cap, const std::string& s) {
+  if (err && cap) std::snprintf(err, (size_t)cap, "%s", s.c_str());
+}
+
+}  // namespace
+
+struct dyn_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1, device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t* d_counts = nullptr;  // [n_ranks] rows per rank (all-gather target)
+  void* d_recv = nullptr;        // root: gathered rows
+  size_t recv_bytes = 0;
+  std::string last_error;
+};
+
+#define C_TRY(c, expr)                                                                     \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      (c)->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr; \
+      return DYN_ERR_DEVICE;                                                               \
+    }                                                                                      \
+  } while (0)
+#define N_TRY(c, expr)                                                                          \
+  do {                                                                                          \
+    ncclResult_t _r = (expr);                                                                   \
+    if (_r != ncclSuccess) {                                                                    \
+      (c)->last_error = std::string("RCCL error: ") + g_rccl.GetErrorString(_r) + " at " #expr; \
+      return DYN_ERR_DEVICE;                                                                    \
+    }                                                                                           \
+  } while (0)
+
+extern "C" {
+
+int dyn_comm_unique_id(uint8_t* id_out128, char* err, uint64_t errcap) {
+  if (!id_out128) return DYN_ERR_INVALID_ARGUMENT;
+  if (!g_rccl.load()) {
+    put_err(err, errcap, g_rccl.error);
+    return DYN_ERR_RUNTIME;
+  }
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) {
+    put_err(err, errcap, std::string("RCCL error: ") + g_rccl.GetErrorString(r));
+    return DYN_ERR_DEVICE;
+  }
+  static_assert(sizeof id == DYN_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  std::memcpy(id_out128, &id, sizeof id);
+  return DYN_OK;
+}
+
+int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn_comm** out, char* err, uint64_t errcap) {
+  if (!id128 || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return DYN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!g_rccl.load()) {
+    put_err(err, errcap, g_rccl.error);
+    return DYN_ERR_RUNTIME;
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    put_err(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at hipSetDevice");
+    return DYN_ERR_DEVICE;
+  }
+  dyn_comm* c = new dyn_comm();
+  c->rank = rank;
+  c->n_ranks = n_ranks;
+  c->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  const ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) {
+    put_err(err, errcap, std::string("RCCL error: ") + g_rccl.GetErrorString(r) + " at ncclCommInitRank");
+    delete c;
+    return DYN_ERR_DEVICE;
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_counts), sizeof(uint64_t) * (size_t)n_ranks) != hipSuccess) {
+    put_err(err, errcap, "HIP error while setting up the communicator's stream");
+    dyn_comm_destroy(c);
+    return DYN_ERR_DEVICE;
+  }
+  *out = c;
+  return DYN_OK;
+}
+
+void dyn_comm_destroy(dyn_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* dyn_comm_last_error(const dyn_comm* c) { return c ? c->last_error.c_str() : ""; }
+
+int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* rows_out, uint64_t rows_cap,
+                         uint64_t* counts_out) {
+  if (!c || !b || root < 0 || root >= c->n_ranks) return DYN_ERR_INVALID_ARGUMENT;
+  int rc = dyn_batch_wait(b);  // asynchronous tickets: the rows exist once the batch is complete
+  if (rc != DYN_OK) {
+    c->last_error = dyn_aligner_last_error(b->a);
+    return rc;
+  }
+  void* d_rows = nullptr;
+  uint64_t cap = 0;
+  rc = dyn_batch_device_results(b, &d_rows, &cap, nullptr);
+  if (rc != DYN_OK) {
+    c->last_error = "dyn_comm_gather_rows: the batch has not been aligned";
+    return rc;
+  }
+  C_TRY(c, hipSetDevice(c->device));
+  // every rank learns every rank's row count (8 bytes each)
+  const uint64_t mine = cap;
+  C_TRY(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+  N_TRY(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
+  std::vector<uint64_t> counts((size_t)c->n_ranks);
+  C_TRY(c, hipMemcpyAsync(counts.data(), c->d_counts, sizeof(uint64_t) * counts.size(), hipMemcpyDeviceToHost, c->stream));
+  C_TRY(c, hipStreamSynchronize(c->stream));
+  if (counts_out) std::memcpy(counts_out, counts.data(), sizeof(uint64_t) * counts.size());
+  uint64_t total = 0;
+  for (uint64_t n : counts) total += n;
+  constexpr size_t ROW = sizeof(dyn_segment_row);
+  if (c->rank == root) {
+    if (rows_out && rows_cap < total) {
+      c->last_error = "dyn_comm_gather_rows: rows_cap is smaller than the sum of all ranks' rows";
+      // still take part in the exchange below so that the peers do not hang; the rows are dropped
+    }
+    if (c->recv_bytes < total * ROW) {
+      if (c->d_recv) C_TRY(c, hipFree(c->d_recv));
+      c->d_recv = nullptr;
+      c->recv_bytes = 0;
+      C_TRY(c, hipMalloc(&c->d_recv, std::max<size_t>(total * ROW + total * ROW / 8, ROW)));
+      c->recv_bytes = total * ROW + total * ROW / 8;
+    }
+  }
+  // the rows: each peer's link to the root carries its rows once
+  N_TRY(c, g_rccl.GroupStart());
+  if (c->rank == root) {
+    uint64_t off = 0;
+    for (int r = 0; r < c->n_ranks; ++r) {
+      char* dst = static_cast<char*>(c->d_recv) + off * ROW;
+      if (r == root) {
+        if (counts[(size_t)r]) C_TRY(c, hipMemcpyAsync(dst, d_rows, counts[(size_t)r] * ROW, hipMemcpyDeviceToDevice, c->stream));
+      } else if (counts[(size_t)r]) {
+        N_TRY(c, g_rccl.Recv(dst, counts[(size_t)r] * ROW, ncclUint8, r, c->comm, c->stream));
+      }
+      off += counts[(size_t)r];
+    }
+  } else if (mine) {
+    N_TRY(c, g_rccl.Send(d_rows, mine * ROW, ncclUint8, root, c->comm, c->stream));
+  }
+  N_TRY(c, g_rccl.GroupEnd());
+  if (c->rank == root && rows_out && rows_cap >= total && total)
+    C_TRY(c, hipMemcpyAsync(rows_out, c->d_recv, total * ROW, hipMemcpyDeviceToHost, c->stream));
+  C_TRY(c, hipStreamSynchronize(c->stream));  // the batch's buffers may be released after this call
+  return (c->rank == root && rows_out && rows_cap < total) ? DYN_ERR_INVALID_ARGUMENT : DYN_OK;
+}
+
+int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n) {
+  if (!c || !b) return DYN_ERR_INVALID_ARGUMENT;
+  int rc = dyn_batch_wait(b);
+  if (rc != DYN_OK) {
+    c->last_error = dyn_aligner_last_error(b->a);
+    return rc;
+  }
+  void* d_pooled = nullptr;
+  uint64_t count = 0;
+  rc = dyn_batch_device_pooled(b, &d_pooled, &count);
+  if (rc != DYN_OK) {
+    c->last_error = "dyn_comm_allreduce_pooled: the batch has not been trained";
+    return rc;
+  }
+  C_TRY(c, hipSetDevice(c->device));
+  // linear-domain sums (w, s1, s2)[numKmers]: a plain sum all-reduce is exact up to fp64 association
+  N_TRY(c, g_rccl.AllReduce(d_pooled, d_pooled, count, ncclDouble, ncclSum, c->comm, c->stream));
+  if (pooled3n) C_TRY(c, hipMemcpyAsync(pooled3n, d_pooled, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  C_TRY(c, hipStreamSynchronize(c->stream));
+  return DYN_OK;
+}
+
+}  // extern "C"

@@ -387,6 +387,31 @@ int dyn_multi_align_batch(dyn_multi* m, uint64_t n_reads, const double* signals,
 int dyn_multi_train_batch(dyn_multi* m, uint64_t n_reads, const double* signals, const uint64_t* sig_offsets,
                           const char* seqs, const uint64_t* seq_offsets, dyn_train_out* out, double* pooled3n);
 
+/* ---- one PROCESS per GPU: the two exchanges of a multi-GPU job over RCCL / xGMI ----
+ *
+ * The reference scales by forking worker processes on one host (segment.py:296-325); reads are independent
+ * (NT_aligner_api.cpp:230-312), so a multi-GPU job shards the reads over one process per GPU and needs nothing but
+ *   config 4: a gather of the per-read segment rows to one rank           -> dyn_comm_gather_rows
+ *   config 5: a sum all-reduce of the pooled statistics (w, s1, s2)[4^k]  -> dyn_comm_allreduce_pooled
+ * both straight from the device buffers of a batch. librccl is bound with dlopen at the first call below; nothing else
+ * in this library needs it. Rank 0 creates the 128-byte id and hands it to the other ranks by the host's own means
+ * (a file, MPI, a socket); dyn_comm_create is collective (ncclCommInitRank). One communicator per process and GPU. */
+#define DYN_COMM_ID_BYTES 128
+typedef struct dyn_comm dyn_comm;
+int dyn_comm_unique_id(uint8_t* id_out128, char* err, uint64_t errcap);
+int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn_comm** out, char* err, uint64_t errcap);
+void dyn_comm_destroy(dyn_comm* c);
+const char* dyn_comm_last_error(const dyn_comm* c);
+/* Collective. `b` = an aligned batch or a ticket of dyn_batch_align[_raw]_async (waited for here). Every rank's
+ * dyn_segment_row records (dyn_segment_capacity() of them, read i at seg_offsets[i] as in dyn_align_out) travel device to
+ * device to `root`: one ncclSend per peer, each over its own xGMI link, no padding. On root rows_out (host, may be NULL)
+ * receives them back to back in rank order and counts_out[r] (may be NULL, any rank) the rows of rank r. */
+int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* rows_out, uint64_t rows_cap,
+                         uint64_t* counts_out);
+/* Collective. `b` = a trained batch or a ticket of dyn_batch_train[_raw]_async. Sum over ranks of the device-resident
+ * pooled statistics (dyn_batch_device_pooled; reduced in place), copied to pooled3n (3 * num_kmers doubles, may be NULL). */
+int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n);
+
 #ifdef __cplusplus
 }
 #endif

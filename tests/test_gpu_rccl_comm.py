@@ -1,0 +1,69 @@
+"""GPU (-m gpu): dyn_comm_* -- the RCCL gather of segment rows (BASELINE config 4) and the RCCL all-reduce of the pooled
+statistics (config 5) below Python, from the device buffers of a batch. One GPU is all a gpurun box has, so the
+communicator has ONE rank here: ncclCommInitRank, the count all-gather, the root's own rows through the receive
+buffer, ncclAllReduce and the D2H copies all run; what a one-rank job cannot exercise is ncclSend/ncclRecv between
+peers (the 8-GPU legs of configs 4 and 5 are the driver's to run). The child process imports no torch: librccl is the
+system one, bound by the library's own dlopen."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu]
+
+CHILD = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from dynamont_amd import Aligner, synth
+from dynamont_amd._dynamont import RcclComm
+assert "torch" not in sys.modules
+model = %(model)r
+_, mean, sd = synth.read_model_file(model)
+reads = synth.make_reads(4242, 24, "rna004", mean, sd, (60, 400))
+al = Aligner(model, "rna004", device=0)
+comm = RcclComm(RcclComm.unique_id(), 0, 1, 0)
+sig, so, sq, qo = synth.pack_reads(reads)
+out = {}
+with al.batch_packed(sig, so, sq, qo) as b:
+    b.align(True)
+    res = b.fetch()
+    rows, counts = comm.gather_rows(b, root=0)
+    out["counts"] = counts.tolist()
+    out["capacity"] = int(b.capacity)
+    ok = True
+    for i in range(len(reads)):
+        a, n = int(res.seg_offsets[i]), int(res.n_segments[i])
+        ok &= np.array_equal(rows["signal_pos"][a:a + n], res.signal_positions[a:a + n].astype(np.uint32))
+        ok &= np.array_equal(rows["sequence_pos"][a:a + n], res.sequence_positions[a:a + n].astype(np.uint32))
+        ok &= np.array_equal(rows["probability"][a:a + n], res.probabilities[a:a + n])
+    out["rows_equal_fetch"] = bool(ok)
+t = al.align_async(sig, so, sq, qo, True)      # a ticket works too (the call waits for it)
+rows2, _ = comm.gather_rows(t, root=0)
+out["ticket_rows_equal"] = bool(np.array_equal(rows2, rows))
+t.close()
+with al.batch_packed(sig, so, sq, qo) as b:
+    b.train()
+    want = b.fetch_train(pooled=True).pooled
+    got = comm.allreduce_pooled(b, al.num_kmers)
+    out["pooled_close"] = bool(np.allclose(got, want, rtol=1e-12, atol=1e-12))
+    out["pooled_weight"] = float(got[:al.num_kmers].sum())
+comm.close()
+al.close()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_one_rank_rccl_gather_and_allreduce(models):
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "model": models["syn9"]}], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and line, r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    assert out["counts"] == [out["capacity"]] and out["capacity"] > 1000
+    assert out["rows_equal_fetch"] and out["ticket_rows_equal"] and out["pooled_close"]
+    assert out["pooled_weight"] > 100.0
