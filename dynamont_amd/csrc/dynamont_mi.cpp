@@ -851,11 +851,15 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     return DYN_ERR_RUNTIME;
   }
   // Strict reads (align(calc=true) only, opt-in through dyn_aligner_set_strict) take the sweeps that reproduce the
-  // reference's libm bit for bit (dp_math_strict.hpp) -- mode 1: reads whose first two k-mers are equal (the symmetric
-  // read-start tie, NT_aligner_api.cpp:445-448), mode 2: every read. They run in the SAME launch as the others (a
-  // per-read flag, kernel variant k_read_queue<JOB, true>), ~3.4x as long per lattice row.
+  // reference's libm bit for bit (dp_math_strict.hpp). Mode 2: every read, every row (3.4x the time: 137 vs 40 ms per
+  // cfg2 launch). Mode 1: reads whose first two k-mers are equal (the symmetric read-start tie, NT_aligner_api.cpp:
+  // 445-448) -- for those the backward sweep and the first STRICT_START_ROWS rows of the forward sweep: the Viterbi
+  // values of a row depend on forward values of earlier rows only, so every decision up to that row is the
+  // reference's own; later decisions have the ordinary >= 1e-6 margins. They run in the SAME launch as the others (a
+  // per-read flag, kernel variant k_read_queue<JOB, true>).
   // Queue order: most expensive reads first, so that the tail of the launch is made of the cheapest ones.
-  constexpr uint64_t STRICT_COST_NUM = 17, STRICT_COST_DEN = 5;  // measured: 137 vs 40 ms per cfg2 launch
+  constexpr uint32_t STRICT_START_ROWS = 1024;
+  const uint64_t STRICT_COST_NUM = a->strict_mode == 2 ? 17 : 23, STRICT_COST_DEN = a->strict_mode == 2 ? 5 : 10;  // measured: 3.4x / 2.3x
   const int32_t* km = b->kmers();
   std::vector<uint8_t> is_strict(b->n, 0);
   std::vector<uint32_t> order;
@@ -1021,7 +1025,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     d.path_off = rows_total;
     d.n_pages = lattice ? pages_of(r.S) : 0;
     d.first_page = dynk::NO_PAGE;
-    d.flags = is_strict[i] ? dynk::READ_STRICT : 0u;
+    d.flags = !is_strict[i] ? 0u : a->strict_mode == 2 ? dynk::READ_STRICT : dynk::READ_STRICT_START;
+    d.strict_rows = STRICT_START_ROWS;
     if (reserving && k < n_slots && (!lattice || (uint64_t)used_pages + d.n_pages <= pool.n_pages)) {
       d.first_page = lattice ? used_pages : 0;
       used_pages += d.n_pages;

@@ -474,7 +474,10 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
                                                 const double* __restrict__ sig, const Emis* __restrict__ par,
                                                 const double* __restrict__ ws_rd, float* __restrict__ lp_out,
                                                 uint64_t* __restrict__ bits, double Z, double m1, double e2,
-                                                const SoftplusNode* s_tab, unsigned ring_base) {
+                                                const SoftplusNode* s_tab, unsigned ring_base, int strict_rows = 0) {
+  // STRICT instantiation: rows t <= strict_rows are computed with the bit-for-bit arithmetic, later rows with the default
+  // one (strict_rows = INT_MAX: the whole sweep). The Viterbi values of a row depend on forward values of rows <= t only,
+  // so with a strict backward sweep every decision up to row strict_rows is the reference's own.
   const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
@@ -511,20 +514,45 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   };
   RowState sa, sb;
   EmisV<CPL> p;
+  double p_stdev[STRICT ? CPL : 1];  // STRICT instantiation: the divisor of the reference's emission, beside 1/stdev
+  auto set_p = [&](int j, const Emis& e) {
+    p.set(j, e);
+    if constexpr (STRICT) p_stdev[j] = e.stdev;
+  };
+  // emission of one sample against the lane's cells, in the flavour of the row it belongs to
+  auto emission = [&](bool strict_row, double x, double (&out)[CPL]) {
+    if constexpr (STRICT) {
+      if (strict_row) {
+        double z[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) z[j] = x - p.mean[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) z[j] = z[j] / p_stdev[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) z[j] = (-0.5 * z[j]) * z[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) z[j] = z[j] + p.neg_log_stdev[j];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) out[j] = z[j] - dynmath::HALF_LOG_2PI;
+        return;
+      }
+    }
+    log_normal_pdf_vec<CPL>(x, p, out);
+  };
   const double x0 = sg[0];
   const size_t r1 = POST ? (size_t)cur_out.at(w, 1) * P : 0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+    set_p(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
     sa.fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     sa.fM[j] = NEG_INF;
     sa.vE[j] = sa.fE[j];                     // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
     sa.vM[j] = NEG_INF;
     sa.b[j] = POST ? lat[r1 + pos_of(lane, j)] : NEG_INF;
   }
-  emission_vec<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(x0, p, sa.e);  // e(1, n)
+  emission(1 <= strict_rows, x0, sa.e);  // e(1, n)
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
@@ -558,8 +586,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
           // and fE/vE(t-1, lo) stay where this row and the right neighbour (fEl/vEl) still read them.
           const bool leaves = n[j] == lo;
           n[j] = leaves ? lo + P : n[j];
-          if (leaves) set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, none);
-          if (n[j] == lo + W) set_emis<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(p, j, entering);  // first band row of this column is t+1
+          if (leaves) set_p(j, none);
+          if (n[j] == lo + W) set_p(j, entering);  // first band row of this column is t+1
         }
         lo = next_lo;
       }
@@ -571,9 +599,9 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     for (int j = 0; j < CPL; ++j) a1[j] = in.fM[j] + in.e[j];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) a2[j] = (in.fE[j] + in.e[j]) + e2;
-    if constexpr (STRICT) {
+    if (STRICT && t <= strict_rows) {  // wave-uniform
       dynmath::log_plus_strict_vec<CPL>(a1, a2, out.fE, strict_tab(s_tab));
-      emission_vec<STRICT ? ARITH_STRICT : ARITH_DEFAULT>(xn, p, out.e);
+      emission(t + 1 <= strict_rows, xn, out.e);  // e(t+1, .) belongs to row t+1
     } else {
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(a1, a2, L, s_tab);
@@ -1203,19 +1231,23 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     cyc_w += t1 - t0;
 
-    const bool strict = MIXED && (rd.flags & READ_STRICT) != 0;  // wave-uniform
+    // READ_STRICT: every row bit for bit. READ_STRICT_START: the backward sweep and the first rd.strict_rows rows of the
+    // forward sweep -- every decision up to that row is then the reference's own (see forward_sweep), which is what a
+    // read-start structural tie needs, at about half the price
+    const bool strict = MIXED && (rd.flags & (READ_STRICT | READ_STRICT_START)) != 0;  // wave-uniform
     double Zb, Zf;
     uint64_t t2;
     if constexpr (MIXED) {
       static_assert(JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE, "strict reads exist for align(calc=true) only");
     }
     if (MIXED && strict) {
+      const int strict_rows = (rd.flags & READ_STRICT) ? 0x7fffffff : (int)rd.strict_rows;
       Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
       t2 = __builtin_amdgcn_s_memtime();
       if (JOB == JOB_ALIGN_INPLACE)
-        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
       else
-        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
     } else {
       Zb = backward_sweep<LATTICE, JOB == JOB_TRAIN ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
       t2 = __builtin_amdgcn_s_memtime();

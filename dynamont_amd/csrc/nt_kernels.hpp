@@ -46,10 +46,11 @@ struct ReadDesc {
   uint32_t first_page;  // pages first_page .. first_page+n_pages-1 were reserved by the host (first round of a
                         // launch), or NO_PAGE: the wave takes n_pages from the pool's free list
   uint32_t n_pages;     // lattice rows 0..T in pages; 0 for jobs without a stored lattice
-  uint32_t flags;       // READ_STRICT: this read takes the bit-for-bit sweeps (dp_math_strict.hpp)
-  uint32_t reserved;
+  uint32_t flags;       // READ_STRICT / READ_STRICT_START: this read takes the bit-for-bit sweeps (dp_math_strict.hpp)
+  uint32_t strict_rows; // READ_STRICT_START: forward rows 1 .. strict_rows in the strict arithmetic
 };
-constexpr uint32_t READ_STRICT = 1u;
+constexpr uint32_t READ_STRICT = 1u;        // every row of both sweeps
+constexpr uint32_t READ_STRICT_START = 2u;  // the backward sweep and the first strict_rows rows of the forward sweep
 
 struct ReadState {
   double Zb;          // backwardE(0,0)          (NT_aligner_api.cpp:286)

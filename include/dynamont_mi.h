@@ -193,9 +193,13 @@ int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
  * exact arithmetic and the reference's choice rests on the last bits of glibc's exp/log1p inside logPlus
  * (aligner.cpp:276-285). The default kernels use a table softplus that is <= 1 ulp away from those and reproduce
  * 997 of 1 000 such reads (tests/golden/g10_ties.npz lists the three); the strict kernels restate glibc 2.35's
- * x86-64 exp (FMA variant) and fdlibm log1p and the reference's emission expression bit for bit (Z becomes
- * bit-identical too), at ~1/3 of the default speed for the reads they run.
- *   mode 0: off (default)   mode 1: reads whose first two k-mers are equal   mode 2: every read */
+ * x86-64 exp (FMA variant) and fdlibm log1p and the reference's emission expression bit for bit.
+ *   mode 0: off (default)
+ *   mode 1: reads whose first two k-mers are equal take the strict backward sweep (Z becomes bit-identical) and the
+ *           strict arithmetic for the first 1 024 rows of the forward sweep -- the Viterbi values of a row depend on
+ *           forward values of earlier rows only, so every decision up to there is the reference's own; 2.3x the time
+ *           of such a read
+ *   mode 2: every read, every row of both sweeps; 3.4x */
 int dyn_aligner_set_strict(dyn_aligner* a, int mode);
 /* Message of the last failing call on this handle (thread-unsafe like the handle itself). */
 const char* dyn_aligner_last_error(const dyn_aligner* a);
