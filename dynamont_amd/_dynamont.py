@@ -591,6 +591,39 @@ class Aligner:
             _raise(rc, self.last_error())
         return AsyncBatch(self, h, out, (raw, raw_off, shift, scale, seqs, seq_off, cal))
 
+    def align_vbz_async(self, chunks, raw_offsets, shift, scale, seqs: bytes, seq_offsets, window: int = 3,
+                        n_sigmas: float = 3.0, f32: bool = False, calc_probabilities: bool = True,
+                        out: AlignBatchResult | None = None, calibration=None) -> AsyncBatch:
+        """dyn_batch_align_vbz_async: the batch's signal as POD5 chunks that are still VBZ-compressed. ``chunks`` =
+        (ptrs uint64[c], nbytes uint64[c], samples uint32[c], read_chunk_offsets uint64[n+1], slice_start uint64[n]);
+        ``raw_offsets`` = prefix sums of the slice lengths. The library's helper threads decode straight into the pinned
+        staging buffer."""
+        ptrs, nbytes, samples, read_off, skip = (np.ascontiguousarray(x, dtype=d) for x, d in
+                                                 zip(chunks, (np.uint64, np.uint64, np.uint32, np.uint64, np.uint64)))
+        shift = np.ascontiguousarray(shift, dtype=np.float64)
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        cal = (None, None)
+        if calibration is not None:
+            cal = (np.ascontiguousarray(calibration[0], dtype=np.float32), np.ascontiguousarray(calibration[1], dtype=np.float32))
+        raw_off = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        seq_off = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(raw_off) - 1
+        cap = int(self._L.dyn_segment_capacity(self._h, n, _ptr(seq_off, N.c_u64_p)))
+        if out is None or out.n != n or out.cap < cap:
+            out = AlignBatchResult(n, cap + cap // 8)
+        h = C.c_void_p()
+        rc = self._L.dyn_batch_align_vbz_async(self._h, n, ptrs.ctypes.data, _ptr(nbytes, N.c_u64_p),
+                                               samples.ctypes.data_as(C.POINTER(C.c_uint32)), _ptr(read_off, N.c_u64_p),
+                                               _ptr(skip, N.c_u64_p), _ptr(raw_off, N.c_u64_p),
+                                               _ptr(cal[0], N.c_float_p) if calibration is not None else None,
+                                               _ptr(cal[1], N.c_float_p) if calibration is not None else None,
+                                               _ptr(shift, N.c_double_p), _ptr(scale, N.c_double_p), int(window), float(n_sigmas),
+                                               int(bool(f32)), seqs, _ptr(seq_off, N.c_u64_p), int(bool(calc_probabilities)),
+                                               C.byref(out._c), C.byref(h))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        return AsyncBatch(self, h, out, (ptrs, nbytes, samples, read_off, skip, raw_off, shift, scale, seqs, seq_off, cal))
+
     def train_raw_async(self, raw, raw_offsets, shift, scale, seqs: bytes, seq_offsets, window: int = 7,
                         n_sigmas: float = 5.0, f32: bool = True, pooled: bool = False,
                         emissions: bool = True, calibration=None) -> AsyncBatch:

@@ -12,8 +12,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "rccl_comm.cpp", "nt_kernels.hip"]
-HEADERS = ["engine.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "rccl_comm.cpp",
+           "nt_kernels.hip"]
+HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
 DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)
@@ -110,6 +111,10 @@ SIGNATURES = {
     "dyn_batch_train_raw_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_float_p, c_float_p, c_double_p, c_double_p,
                                             C.c_int, C.c_double, C.c_int, C.c_char_p, c_u64_p,
                                             C.POINTER(DynTrainOut), c_double_p, C.POINTER(C.c_void_p)]),
+    "dyn_batch_align_vbz_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, c_u64_p, C.POINTER(C.c_uint32), c_u64_p, c_u64_p, c_u64_p,
+                                            c_float_p, c_float_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_char_p,
+                                            c_u64_p, C.c_int, C.POINTER(DynAlignOut), C.POINTER(C.c_void_p)]),
+    "dyn_vbz_decode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_char_p, C.c_uint64]),
     "dyn_batch_wait": (C.c_int, [C.c_void_p]),
     "dyn_host_alloc": (C.c_void_p, [C.c_uint64]),
     "dyn_host_free": (None, [C.c_void_p]),

@@ -15,6 +15,7 @@
 // Stream order does all GPU-side synchronisation (events between the three streams); the only host
 // waits are the back thread's hipEventSynchronize on a batch's last D2H and the caller's wait().
 #include "engine.hpp"
+#include "vbz_decode.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -200,7 +201,42 @@ int Pipeline::front_stage(dyn_batch* b) {
     std::memcpy(h_shift, rs.shift, n * 8);
     std::memcpy(h_scale, rs.scale, n * 8);
     const uint64_t bytes = total_sig * esz;
-    if (rs.scattered) {  // one pointer per read: the gather into the staging buffer IS the only host copy
+    if (rs.vbz) {
+      // POD5 chunks, still compressed: every helper thread decodes whole reads (zstd + svb16 + zigzag + delta, the
+      // decode ONT's pod5 library does inside record.signal) and copies the [start:end) slice into the staging buffer
+      std::atomic<int> failed{0};
+      std::string first_error;
+      std::mutex err_mu;
+      const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 4)));
+      helpers.parallel_for(parts, [&](int t) {
+        std::vector<uint8_t> tmp;
+        std::vector<int16_t> whole;
+        std::string err;
+        for (uint64_t i = n * t / parts; i < n * (t + 1) / parts; ++i) {
+          const uint64_t len = h_offs[i + 1] - h_offs[i];
+          uint64_t total = 0;
+          for (uint64_t c = rs.vbz_read_off[i]; c < rs.vbz_read_off[i + 1]; ++c) total += rs.vbz_samples[c];
+          bool ok = rs.vbz_skip[i] + len <= total;
+          if (!ok) err = "VBZ: the read's chunks hold fewer samples than its [start:end) slice needs";
+          if (ok && whole.size() < total) whole.resize(total);
+          uint64_t pos = 0;
+          for (uint64_t c = rs.vbz_read_off[i]; ok && c < rs.vbz_read_off[i + 1]; ++c) {
+            ok = dynvbz::decode_chunk(rs.vbz_chunks[c], (size_t)rs.vbz_bytes[c], rs.vbz_samples[c], whole.data() + pos, tmp, err);
+            pos += rs.vbz_samples[c];
+          }
+          if (ok) {
+            std::memcpy(h_raw + h_offs[i] * 2, whole.data() + rs.vbz_skip[i], len * 2);
+          } else if (!failed.exchange(1)) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            first_error = err + " (read " + std::to_string(i) + " of the batch)";
+          }
+        }
+      });
+      if (failed.load()) {
+        b->error = first_error;
+        return DYN_ERR_RUNTIME;
+      }
+    } else if (rs.scattered) {  // one pointer per read: the gather into the staging buffer IS the only host copy
       const void* const* slices = static_cast<const void* const*>(rs.raw);
       const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 8)));
       helpers.parallel_for(parts, [&](int t) {
@@ -436,6 +472,34 @@ int dyn_batch_train_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw,
   rs.n_sigmas = hampel_n_sigmas;
   rs.compute_f32 = compute_f32;
   return submit_common(a, n_reads, nullptr, raw_offsets, seqs, seq_offsets, DynJob::Train, nullptr, out, pooled3n, ticket, &rs);
+}
+
+int dyn_batch_align_vbz_async(dyn_aligner* a, uint64_t n_reads, const void* const* chunk_ptrs, const uint64_t* chunk_bytes,
+                              const uint32_t* chunk_samples, const uint64_t* read_chunk_offsets, const uint64_t* slice_start,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale, int hampel_window, double hampel_n_sigmas,
+                              int compute_f32, const char* seqs, const uint64_t* seq_offsets, int calc_probabilities,
+                              dyn_align_out* out, dyn_batch** ticket) {
+  if (!out || !read_chunk_offsets || !slice_start || (n_reads && (!chunk_ptrs || !chunk_bytes || !chunk_samples)))
+    return DYN_ERR_INVALID_ARGUMENT;
+  RawSource rs;
+  rs.raw = chunk_ptrs;  // not read as samples: vbz
+  rs.dtype = cal_offset ? 3 : 1;
+  rs.cal_offset = cal_offset;
+  rs.cal_scale = cal_scale;
+  rs.shift = shift;
+  rs.scale = scale;
+  rs.window = hampel_window;
+  rs.n_sigmas = hampel_n_sigmas;
+  rs.compute_f32 = compute_f32;
+  rs.vbz = true;
+  rs.vbz_chunks = chunk_ptrs;
+  rs.vbz_bytes = chunk_bytes;
+  rs.vbz_samples = chunk_samples;
+  rs.vbz_read_off = read_chunk_offsets;
+  rs.vbz_skip = slice_start;
+  return submit_common(a, n_reads, nullptr, raw_offsets, seqs, seq_offsets, calc_probabilities ? DynJob::AlignFull : DynJob::AlignZ,
+                       out, nullptr, nullptr, ticket, &rs);
 }
 
 int dyn_batch_wait(dyn_batch* b) {

@@ -17,8 +17,7 @@
 // does not lean on repeat offsets the decoder will not have at that point; an empty last block closes the frame.
 // Any zstd decoder sees one ordinary frame (tests/test_harness.py, tests/test_gpu_harness.py).
 #include "../../include/dynamont_mi.h"
-
-#include <dlfcn.h>
+#include "zstd_dl.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -34,48 +33,6 @@
 #include <vector>
 
 namespace {
-
-struct Zstd {
-  void* lib = nullptr;
-  void* (*createCCtx)() = nullptr;
-  size_t (*freeCCtx)(void*) = nullptr;
-  size_t (*compressBegin)(void*, int) = nullptr;
-  size_t (*compressContinue)(void*, void*, size_t, const void*, size_t) = nullptr;
-  size_t (*compressEnd)(void*, void*, size_t, const void*, size_t) = nullptr;
-  void (*invalidateRepCodes)(void*) = nullptr;
-  size_t (*compressBound)(size_t) = nullptr;
-  unsigned (*isError)(size_t) = nullptr;
-  const char* (*getErrorName)(size_t) = nullptr;
-
-  bool load(std::string& err) {
-    for (const char* name : {"libzstd.so.1", "libzstd.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
-    }
-    if (!lib) {
-      err = "libzstd.so.1 not found";
-      return false;
-    }
-    auto sym = [&](const char* n) { return dlsym(lib, n); };
-#define DYN_Z(field, name)                                        \
-  field = reinterpret_cast<decltype(field)>(sym(name));           \
-  if (!field) {                                                   \
-    err = std::string("libzstd lacks ") + name;                   \
-    return false;                                                 \
-  }
-    DYN_Z(createCCtx, "ZSTD_createCCtx");
-    DYN_Z(freeCCtx, "ZSTD_freeCCtx");
-    DYN_Z(compressBegin, "ZSTD_compressBegin");
-    DYN_Z(compressContinue, "ZSTD_compressContinue");
-    DYN_Z(compressEnd, "ZSTD_compressEnd");
-    DYN_Z(invalidateRepCodes, "ZSTD_invalidateRepCodes");
-    DYN_Z(compressBound, "ZSTD_compressBound");
-    DYN_Z(isError, "ZSTD_isError");
-    DYN_Z(getErrorName, "ZSTD_getErrorName");
-#undef DYN_Z
-    return true;
-  }
-};
 
 constexpr size_t kJobBytes = 4u << 20;
 const char kHeader[] = "readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n";  // segment.py:80
@@ -111,7 +68,7 @@ struct Item {
 }  // namespace
 
 struct dyn_csv_sink {
-  Zstd z;
+  dynzstd::Zstd z;
   int level = 3, threads = 4;
   FILE* out = nullptr;
   std::string errors_path, error;
@@ -387,7 +344,6 @@ int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compresse
   if (error_lines) *error_lines = s->error_lines.load();
   const bool failed = s->failed;
   if (failed && err && errcap) std::snprintf(err, (size_t)errcap, "%s", s->error.c_str());
-  if (s->z.lib) dlclose(s->z.lib);
   delete s;
   return failed ? DYN_ERR_RUNTIME : DYN_OK;
 }

@@ -128,6 +128,14 @@ enum class DynJob { AlignZ, AlignFull, Train };
 struct RawSource {
   const void* raw = nullptr;   // concatenated [start:end) slices; scattered: a table of n_reads pointers, one per slice
   bool scattered = false;
+  // vbz: the samples arrive as POD5 signal chunks still compressed (VBZ); read i = chunks [vbz_read_off[i], vbz_read_off[i+1])
+  // decoded back to back, of which the slice [vbz_skip[i], vbz_skip[i] + length_i) is the read's signal
+  bool vbz = false;
+  const void* const* vbz_chunks = nullptr;
+  const uint64_t* vbz_bytes = nullptr;
+  const uint32_t* vbz_samples = nullptr;
+  const uint64_t* vbz_read_off = nullptr;
+  const uint64_t* vbz_skip = nullptr;
   int dtype = 0;               // 0 float32, 1 int16, 2 float64, 3 int16 ADC + per-read float32 calibration
   const float* cal_offset = nullptr;  // dtype 3: picoampere = (adc + cal_offset) * cal_scale, in float32
   const float* cal_scale = nullptr;

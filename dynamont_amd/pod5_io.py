@@ -105,6 +105,32 @@ def get_signal_adc(reader, read_id: str):
     return record.signal, np.float32(record.calibration.offset), np.float32(record.calibration.scale)
 
 
+class VbzSlice:
+    """A read's [start:end) signal slice as POD5 chunks that are still compressed (VBZ): what ``prepare_job_raw`` hands on
+    when the reader can point at the chunks in the memory-mapped file. ``len()`` = samples of the slice, clipped to the
+    read like ``signal[start:end]`` clips; decoding happens in the library's helper threads
+    (dyn_batch_align_vbz_async)."""
+    dtype = np.dtype(np.int16)
+    vbz = True
+
+    def __init__(self, ptrs, nbytes, samples, start: int, end: int, owner=None):
+        self.owner = owner  # the reader whose memory map the addresses point into: alive as long as this slice is
+        total = int(samples.sum())
+        s = min(max(int(start), 0), total)
+        e = min(max(int(end), s), total)
+        self.ptrs, self.nbytes, self.samples, self.start, self.length = ptrs, nbytes, samples, s, e - s
+
+    def __len__(self):
+        return self.length
+
+
+def get_signal_chunks(reader, read_id: str):
+    """(chunk addresses, chunk bytes, chunk samples, calibration offset, calibration scale) when the reader can hand
+    out the read's signal without decoding it (pod5_native.Pod5File on a VBZ file), else None."""
+    fn = getattr(reader, "signal_chunks", None)
+    return fn(read_id) if fn is not None else None
+
+
 class BasecallRecord:
     """The subset of pysam.AlignedSegment the reference touches (segment.py:222-245)."""
 

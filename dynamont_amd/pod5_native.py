@@ -242,6 +242,7 @@ class Pod5File:
         sig = self._tables[CT_SIGNAL]
         self._sig_rows = np.cumsum([0] + [sig.get_batch(i).num_rows for i in range(sig.num_record_batches)])
         self._sig_cache = (-1, None)
+        self._sig_meta = {}
         self._index = None
         self.closed = False
 
@@ -287,6 +288,54 @@ class Pod5File:
             return vbz_decompress(col[i].as_py(), samples)
         return np.asarray(col[i].as_py(), dtype=np.int16)  # uncompressed large_list<int16>
 
+    def _batch_chunk_meta(self, bi: int):
+        """(data address, offsets[int64], samples[uint32]) of signal-table batch bi when its signal column is VBZ
+        (binary / large_binary), None when it holds uncompressed int16 lists. Zero copy: the Arrow buffers are views of
+        the memory-mapped file, so the addresses stay valid until close()."""
+        meta = self._sig_meta.get(bi)
+        if meta is None:
+            import pyarrow as pa
+            b = self._tables[CT_SIGNAL].get_batch(bi)
+            names = b.schema.names
+            col = b.column(names.index("signal"))
+            col = col.storage if hasattr(col, "storage") else col
+            if pa.types.is_large_binary(col.type) or pa.types.is_binary(col.type):
+                bufs = col.buffers()
+                dt = np.int64 if pa.types.is_large_binary(col.type) else np.int32
+                offs = np.frombuffer(bufs[1], dtype=dt)[col.offset:col.offset + len(col) + 1].astype(np.int64)
+                samples = b.column(names.index("samples")).to_numpy(zero_copy_only=False).astype(np.uint32)
+                meta = (int(bufs[2].address), offs, samples, b)  # b keeps the buffers alive
+            else:
+                meta = False
+            self._sig_meta[bi] = meta
+        return meta or None
+
+    def signal_chunks(self, read_id: str):
+        """The read's signal still compressed: (chunk addresses uint64[c], chunk bytes uint64[c], chunk samples
+        uint32[c], calibration offset, calibration scale) for dyn_batch_align_vbz_async / dyn_vbz_decode, or None when
+        the file stores uncompressed samples. Nothing is decoded or copied here."""
+        if self._index is None:
+            self._build_index()
+        try:
+            key = uuid.UUID(read_id).bytes
+        except ValueError:
+            raise KeyError(read_id) from None
+        rows, offset, scale = self._index[key]
+        ptrs = np.empty(len(rows), dtype=np.uint64)
+        nbytes = np.empty(len(rows), dtype=np.uint64)
+        samples = np.empty(len(rows), dtype=np.uint32)
+        for k, r in enumerate(rows):
+            bi = int(np.searchsorted(self._sig_rows, r, side="right") - 1)
+            meta = self._batch_chunk_meta(bi)
+            if meta is None:
+                return None
+            base, offs, smp, _ = meta
+            i = int(r) - int(self._sig_rows[bi])
+            ptrs[k] = base + int(offs[i])
+            nbytes[k] = int(offs[i + 1] - offs[i])
+            samples[k] = smp[i]
+        return ptrs, nbytes, samples, np.float32(offset), np.float32(scale)
+
     def signal_adc(self, read_id: str):
         """(int16 ADC samples, calibration offset, calibration scale)"""
         if self._index is None:
@@ -312,8 +361,8 @@ class Pod5File:
             self._sig_cache = (-1, None)
             try:
                 self._mm.close()
-            except BufferError:  # an Arrow buffer still references the map; the GC releases it
-                pass
+            except BufferError:  # an Arrow buffer still references the map (e.g. the chunk tables that VbzSlice objects of
+                pass             # batches in flight point into, via their `owner`): the GC releases it with the last of them
             self._fh.close()
             self.closed = True
 

@@ -22,7 +22,7 @@ from os.path import basename, dirname, exists, isdir, join, splitext
 import numpy as np
 
 from dynamont_amd import Aligner, __version__
-from dynamont_amd.pod5_io import get_signal, get_signal_adc, iter_basecalls, open_pod5
+from dynamont_amd.pod5_io import VbzSlice, get_signal, get_signal_adc, get_signal_chunks, iter_basecalls, open_pod5
 from dynamont_amd.segmentation.utils import get_model, hampel, segmentation_to_string
 from dynamont_amd.zstd_io import open_writer
 
@@ -157,10 +157,16 @@ def prepare_job_raw(job, is_rna: bool):
     segment.py:147), None when it takes the ADC counts themselves. Calibration, normalisation and the Hampel filter
     then run on the device (dyn_batch_align_raw_async), bit-identically. Returns (raw, read, cal)."""
     raw_file, shift, scale, start, end, read, readid, signalid = job
-    adc, cal_offset, cal_scale = get_signal_adc(get_raw(raw_file), signalid)
-    raw = adc[start:end]
-    if raw.dtype != np.int16:  # a reader that hands out something else: through the generic float64 path
-        raw = raw.astype(np.float64)
+    reader = get_raw(raw_file)
+    chunks = get_signal_chunks(reader, signalid)
+    if chunks is not None:  # a .pod5 file with VBZ chunks: they go to the library as they are (decoded on its helper threads)
+        ptrs, nbytes, samples, cal_offset, cal_scale = chunks
+        raw = VbzSlice(ptrs, nbytes, samples, start, end, owner=reader)
+    else:
+        adc, cal_offset, cal_scale = get_signal_adc(reader, signalid)
+        raw = adc[start:end]
+        if raw.dtype != np.int16:  # a reader that hands out something else: through the generic float64 path
+            raw = raw.astype(np.float64)
     if is_rna:
         read = read[::-1]
         if not read.startswith(POLYA):
@@ -192,7 +198,13 @@ def _pack_jobs(pending, scattered: bool = False):
     seq_off = np.zeros(n + 1, dtype=np.uint64)
     np.cumsum([len(p[0]) for p in pending], out=sig_off[1:])
     np.cumsum([len(p[1]) for p in pending], out=seq_off[1:])
-    if scattered:
+    if n and getattr(pending[0][0], "vbz", False):  # compressed POD5 chunks: flattened chunk tables
+        counts = [len(p[0].ptrs) for p in pending]
+        read_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(counts, out=read_off[1:])
+        sig = (np.concatenate([p[0].ptrs for p in pending]), np.concatenate([p[0].nbytes for p in pending]),
+               np.concatenate([p[0].samples for p in pending]), read_off, np.array([p[0].start for p in pending], dtype=np.uint64))
+    elif scattered:
         sig = [p[0] for p in pending]
     else:
         sig = np.concatenate([p[0] for p in pending]) if n else np.zeros(0, dtype=np.int16)
@@ -224,7 +236,7 @@ class _Pipeline:
         self.check()
         groups = [pending]
         if self.raw and pending:  # one submission per kind of raw data: calibrated ADC, plain ADC, anything else
-            kind = lambda p: (p[0].dtype.str, p[3] is not None)  # noqa: E731
+            kind = lambda p: (p[0].dtype.str, p[3] is not None, getattr(p[0], "vbz", False))  # noqa: E731
             kinds = sorted({kind(p) for p in pending})
             if len(kinds) > 1:
                 groups = [[p for p in pending if kind(p) == kd] for kd in kinds]
@@ -235,9 +247,9 @@ class _Pipeline:
             out = self.free.pop() if self.free else None
             if self.raw:
                 cal = ([p[3][0] for p in g], [p[3][1] for p in g]) if g[0][3] is not None else None
-                t = self.aligner.align_raw_async(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
-                                                 window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out,
-                                                 calibration=cal)
+                submit_raw = self.aligner.align_vbz_async if isinstance(sig, tuple) else self.aligner.align_raw_async
+                t = submit_raw(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
+                               window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out, calibration=cal)
             else:
                 t = self.aligner.align_async(sig, sig_off, seqs, seq_off, True, out=out)
             self.inflight.put((t, g, seqs, seq_off))
@@ -336,7 +348,7 @@ class _NativePipeline:
         C, N = self.C, self.N
         groups = [pending]
         if self.raw and pending:
-            kind = lambda p: (p[0].dtype.str, p[3] is not None)  # noqa: E731
+            kind = lambda p: (p[0].dtype.str, p[3] is not None, getattr(p[0], "vbz", False))  # noqa: E731
             kinds = sorted({kind(p) for p in pending})
             if len(kinds) > 1:
                 groups = [[p for p in pending if kind(p) == kd] for kd in kinds]
@@ -349,9 +361,9 @@ class _NativePipeline:
             out = self.free.pop() if self.free else None
             if self.raw:
                 cal = ([p[3][0] for p in g], [p[3][1] for p in g]) if g[0][3] is not None else None
-                t = self.aligner.align_raw_async(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
-                                                 window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out,
-                                                 calibration=cal)
+                submit_raw = self.aligner.align_vbz_async if isinstance(sig, tuple) else self.aligner.align_raw_async
+                t = submit_raw(sig, sig_off, [p[2][1] for p in g], [p[2][2] for p in g], seqs, seq_off,
+                               window=3, n_sigmas=3.0, f32=False, calc_probabilities=True, out=out, calibration=cal)
             else:
                 t = self.aligner.align_async(sig, sig_off, seqs, seq_off, True, out=out)
             res = t.result
@@ -365,7 +377,7 @@ class _NativePipeline:
             if rc != N.DYN_OK:
                 t.close()
                 raise RuntimeError("dyn_csv_sink_submit failed")
-            self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths)
+            self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g)  # g: the slices (and their readers) stay alive
             self.submitted += 1
 
     def check(self) -> None:

@@ -174,7 +174,7 @@ def pack_reads(reads: list[SynthRead]):
 
 def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, seed: int = 0,
                   drop_polya_every: int = 3, lead: int = 37, sm: float = 90.0, sd: float = 15.0,
-                  container: str = "npz"):
+                  container: str = "npz", pod5_chunk_samples: int = 102400):
     """Write reads as the vendor-free containers of ``dynamont_amd.pod5_io``: ``<name>.dynraw.npz``
     (int16 ADC + calibration) and ``<name>.dynbam.tsv`` (the BAM fields segment.py:222-256 reads).
 
@@ -220,7 +220,7 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
     raw = os.path.join(outdir, raw_name)
     if container == "pod5":
         from dynamont_amd.pod5_native import write_pod5
-        write_pod5(raw, ids, adcs, np.full(len(reads), offset), np.full(len(reads), scale))
+        write_pod5(raw, ids, adcs, np.full(len(reads), offset), np.full(len(reads), scale), chunk_samples=pod5_chunk_samples)
     else:
         np.savez(raw, read_ids=np.array(ids), offsets=np.array(offs, dtype=np.int64), adc=np.concatenate(adcs),
                  cal_scale=np.full(len(reads), scale), cal_offset=np.full(len(reads), offset))

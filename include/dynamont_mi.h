@@ -364,6 +364,22 @@ int dyn_batch_train_raw_async(dyn_aligner* a, uint64_t n_reads, const void* raw,
                               int hampel_window, double hampel_n_sigmas, int compute_f32, const char* seqs,
                               const uint64_t* seq_offsets, dyn_train_out* out, double* pooled3n,
                               dyn_batch** ticket);
+/* The same for a batch whose signal is still in POD5 form: VBZ-compressed chunks (POD5 format specification: zstd around
+ * StreamVByte-16 of the zigzag-coded sample deltas) -- the decode ONT's pod5 library performs inside `record.signal`,
+ * which the reference calls per read (src/dynamont/pod5_io.py:6-16). Read i's signal is the concatenation of the chunks
+ * [read_chunk_offsets[i], read_chunk_offsets[i+1]) (chunk c: chunk_bytes[c] compressed bytes at chunk_ptrs[c] holding
+ * chunk_samples[c] samples), of which the slice [slice_start[i], slice_start[i] + (raw_offsets[i+1] - raw_offsets[i]))
+ * is aligned (segment.py:147: signal[start:end]). The pipeline's helper threads decode whole reads straight into the
+ * pinned staging buffer. cal_offset / cal_scale as for raw_dtype 3, or both NULL for plain ADC counts (raw_dtype 1).
+ * A chunk that does not decode fails the batch with DYN_ERR_RUNTIME ("VBZ: ..."). */
+int dyn_batch_align_vbz_async(dyn_aligner* a, uint64_t n_reads, const void* const* chunk_ptrs, const uint64_t* chunk_bytes,
+                              const uint32_t* chunk_samples, const uint64_t* read_chunk_offsets, const uint64_t* slice_start,
+                              const uint64_t* raw_offsets, const float* cal_offset, const float* cal_scale,
+                              const double* shift, const double* scale, int hampel_window, double hampel_n_sigmas,
+                              int compute_f32, const char* seqs, const uint64_t* seq_offsets, int calc_probabilities,
+                              dyn_align_out* out, dyn_batch** ticket);
+/* One VBZ chunk -> `samples` int16 values (host only; tests, other readers). */
+int dyn_vbz_decode(const void* blob, uint64_t blob_bytes, uint32_t samples, int16_t* out, char* err, uint64_t errcap);
 /* Block until the batch behind the ticket is complete; returns its status code, with the message in
  * dyn_aligner_last_error. Returns DYN_OK at once for batches of the synchronous calls. */
 int dyn_batch_wait(dyn_batch* ticket);

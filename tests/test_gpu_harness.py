@@ -113,3 +113,30 @@ def test_train_cli(models, tmp_path, aggregate):
             assert abs(m1[name][0] - s1[c] / w[c]) <= 1e-9
             var = max(s2[c] / w[c] - (s1[c] / w[c]) ** 2, 1e-12)
             assert abs(m1[name][1] - np.sqrt(var)) <= 1e-7
+
+
+def test_resquiggle_cli_on_a_pod5_file_equals_the_npz_container(models, tmp_path):
+    """The same reads from a .pod5 file (VBZ chunks handed to dyn_batch_align_vbz_async still compressed, decoded by the
+    library's helper threads; UUID read ids) and from the .npz container: the rows must be byte-identical apart from the
+    id columns, for reads that span several chunks too, and a read whose [start:end) slice is cut short still fails
+    with the reference's message."""
+    pore = "rna004"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(72, 11, pore, mean, sd, (60, 900))
+    rows = {}
+    for container in ("npz", "pod5"):
+        d = tmp_path / container
+        raw, bam, _ = synth.write_dataset(str(d / "in"), "ds", reads, pore, seed=9, container=container, pod5_chunk_samples=1000)
+        lines = open(bam).read().splitlines()
+        f = lines[5].split("\t"); f[4] = str(int(f[5]) + 30); lines[5] = "\t".join(f)   # ns = ts + 30 samples: too short
+        open(bam, "w").write("\n".join(lines) + "\n")
+        out = d / "out" / "res.csv"
+        seg.main(["-r", str(d / "in"), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore, "--model_path", model,
+                  "--batch-reads", "4"])
+        body = zstd_io.decompress(open(str(out) + ".zst", "rb").read()).decode().splitlines()
+        rows[container] = [",".join(r.split(",")[2:]) for r in body[1:]]
+        errs = open(str(d / "out" / "res.errors")).read().splitlines()
+        assert len(errs) == 1 and "Signal too short compared to sequence" in errs[0]
+        seg.close_raw_cache()
+    assert len(rows["pod5"]) > 1000 and rows["pod5"] == rows["npz"]

@@ -93,6 +93,48 @@ def test_cli_jobs_from_pod5_equal_jobs_from_npz(models, tmp_path):
         sb, rb = seg.prepare_job(b, True)
         assert ra == rb and np.array_equal(sa, sb)
         (xa, _, ca), (xb, _, cb) = seg.prepare_job_raw(a, True), seg.prepare_job_raw(b, True)
-        assert xa.dtype == xb.dtype == np.int16 and np.array_equal(xa, xb)
+        # .npz: a view of the int16 samples; .pod5: the still-compressed chunks (decoded by the library, see below)
+        assert xa.dtype == xb.dtype == np.int16 and isinstance(xb, pod5_io.VbzSlice) and len(xa) == len(xb)
         assert ca is not None and ca == cb  # shift <= 400: the calibrated signal, calibration handed on for the device
+    seg.close_raw_cache()
+
+
+def test_native_vbz_decoder_equals_the_numpy_one(native_lib):
+    """dyn_vbz_decode (what the asynchronous engine's helper threads run for .pod5 input) against the NumPy decoder of
+    pod5_native on chunk sizes around the 8-value key groups, spikes that need two-byte deltas, and a truncated chunk."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 7, 8, 9, 15, 16, 17, 100, 4096, 20011, 102400):
+        x = rng.normal(500, 120, n).astype(np.int16)
+        if n > 10:
+            x[rng.integers(0, n, max(1, n // 50))] = rng.integers(-32768, 32767)
+        blob = P.vbz_compress(x)
+        out = np.empty(max(n, 1), dtype=np.int16)
+        err = C.create_string_buffer(256)
+        assert native_lib.dyn_vbz_decode(blob, len(blob), n, out.ctypes.data, err, 256) == 0, err.value
+        assert np.array_equal(out[:n], x) and np.array_equal(P.vbz_decompress(blob, n), x)
+    assert native_lib.dyn_vbz_decode(blob[:len(blob) // 2], len(blob) // 2, n, out.ctypes.data, err, 256) != 0
+    assert err.value.startswith(b"VBZ:")
+
+
+def test_signal_chunks_point_at_the_reads_compressed_signal(models, tmp_path, native_lib):
+    """Pod5File.signal_chunks -> VbzSlice (prepare_job_raw on a .pod5 file): decoding the chunks natively and cutting
+    [start:end) gives exactly what signal_adc()[start:end] gives; the calibration travels with it."""
+    import ctypes as C
+    pore = "rna004"
+    _, mean, sd = synth.read_model_file(model_for(models, pore))
+    reads = synth.make_reads(77, 6, pore, mean, sd, (100, 1500))
+    _, bam, _ = synth.write_dataset(str(tmp_path / "p"), "ds", reads, pore, seed=4, container="pod5")
+    for job in seg.generate_jobs(str(tmp_path / "p"), bam, 0):
+        raw, _, cal = seg.prepare_job_raw(job, True)
+        assert isinstance(raw, pod5_io.VbzSlice) and raw.owner is not None
+        adc, off, sc = pod5_io.get_signal_adc(seg.get_raw(job[0]), job[7])
+        parts = []
+        for p, nb, sm in zip(raw.ptrs, raw.nbytes, raw.samples):
+            buf = np.empty(int(sm), dtype=np.int16)
+            err = C.create_string_buffer(256)
+            assert native_lib.dyn_vbz_decode(C.c_void_p(int(p)), int(nb), int(sm), buf.ctypes.data, err, 256) == 0, err.value
+            parts.append(buf)
+        whole = np.concatenate(parts)
+        assert np.array_equal(whole[raw.start:raw.start + len(raw)], adc[job[3]:job[4]]) and cal == (off, sc)
     seg.close_raw_cache()

@@ -9,14 +9,19 @@ from dynamont_amd.segmentation import segment as seg
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 extra = sys.argv[2:]  # e.g. --parallel-zstd-frames
+container = "npz"
+if "--container" in extra:  # --container pod5: the raw signal in a .pod5 file (VBZ chunks, vendor-free reader)
+    k = extra.index("--container")
+    container = extra[k + 1]
+    del extra[k:k + 2]
 d = tempfile.mkdtemp(prefix="dyn_e2e_")
 model = synth.write_model(os.path.join(d, "m9.model"), 9)
 _, mean, sd = synth.read_model_file(model)
 t0 = time.time()
 reads = synth.make_reads(5, n, "rna004", mean, sd, 2000)
-raw, bam, _ = synth.write_dataset(os.path.join(d, "in"), "ds", reads, "rna004", seed=1)
+raw, bam, _ = synth.write_dataset(os.path.join(d, "in"), "ds", reads, "rna004", seed=1, container=container)
 samples = sum(len(r.signal) for r in reads)
-print(f"dataset: {n} reads, {samples/1e6:.1f} Msamples, generated in {time.time()-t0:.1f} s", flush=True)
+print(f"dataset: {n} reads, {samples/1e6:.1f} Msamples, container {container} ({os.path.getsize(raw)/1e6:.0f} MB), generated in {time.time()-t0:.1f} s", flush=True)
 del reads
 pr = cProfile.Profile()
 t0 = time.time()
