@@ -418,65 +418,6 @@ DYN_HD void log_plus_finish_sigma3(const SoftplusLookup<M>& L, double (&out)[M],
   log_plus_finish_sigma3<M, 0, M>(L, out, sig);
 }
 
-// exp(d) for M independent arguments (training pass: the posterior mass exp(LPE) of every cell), d <= ~0.
-// d = k ln2/64 + r with k = rint(d 64/ln2) by the magic-number addition, |r| <= ln2/128 = 5.4e-3:
-//   exp(d) = 2^(k >> 6) * T[k & 63] * (1 + r(1 + r(1/2 + r(1/6 + r(1/24 + r/120)))))
-// with T[i] = 2^(i/64) (64 doubles kept behind the softplus nodes in LDS, EXP_TAB_NODES of them).
-// Truncation r^6/720 <= 3.5e-17 relative; with the rounding of T, of the polynomial and of their product
-// <= 3e-16 relative (tests/test_dp_math.py). 13 fp64 operations + 3 integer ones and one ds_read_b64; the
-// table-free form of rounds 1-2 (ln2 reduction, degree-11 polynomial) took 20. d < -1000, -inf and NaN
-// clamp to -1000 (result 0).
-constexpr int EXP_TAB_SIZE = 64;
-constexpr int EXP_TAB_NODES = EXP_TAB_SIZE / 2;  // in units of SoftplusNode (two doubles)
-
-inline void exp_build_table(double* t) {
-  for (int i = 0; i < EXP_TAB_SIZE; ++i) t[i] = (double)exp2l((long double)i / EXP_TAB_SIZE);
-}
-
-template <int M>
-DYN_HD void exp_vec(double (&d)[M], double (&out)[M], const double* __restrict__ tab) {
-  const double INV = 0x1.71547652b82fep+6;      // 64/ln2
-  const double LN2_64_HI = 0x1.62e42fee00000p-7;  // ln2/64 = HI + LO, HI with 21 trailing zero bits (k HI exact)
-  const double LN2_64_LO = 0x1.a39ef35793c76p-39;
-  double m[M], kf[M], r[M], q[M], T[M];
-  int k[M];
-  const double magic = vreg_const(SP_MAGIC), c24 = vreg_const(1.0 / 24.0);
-  const double inv = sreg_const(INV), c120 = sreg_const(1.0 / 120.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(d[j], -1000.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) m[j] = fma_(d[j], inv, magic);
-#pragma unroll
-  for (int j = 0; j < M; ++j) kf[j] = m[j] - magic;
-#pragma unroll
-  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_64_HI, d[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) r[j] = fma_(-kf[j], LN2_64_LO, r[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) k[j] = low_word(m[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) T[j] = tab[k[j] & (EXP_TAB_SIZE - 1)];
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], c120, c24);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], 1.0 / 6.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], 0.5);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], 1.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(q[j], r[j], 1.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = q[j] * T[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    out[j] = __builtin_amdgcn_ldexp(q[j], k[j] >> 6);
-#else
-    out[j] = std::ldexp(q[j], k[j] >> 6);
-#endif
-  }
-}
 
 // Structure-of-arrays emission constants of the M cells of a lane.
 template <int M>

@@ -137,28 +137,47 @@ DYN_HD void exp_strict_vec(const double (&x)[M], double (&out)[M], const uint64_
   }
 }
 
-// exp(x) for the training sweep's posterior masses, x <= ~0, on the SAME 2^(k/128) table (already in LDS): glibc's
-// reduction, the scale assembled from the table's bit pattern (no ldexp, no multiply), but a degree-4 polynomial and no
-// tail correction: |r| <= ln2/256, truncation r^5/120 = 1.2e-15 relative; with the dropped tail (<= 2^-53) <= 2e-15.
-// 10 fp64 operations (exp_vec: 13 + ldexp). Arguments below -700 (and -inf, NaN) are clamped: the result, 1e-304, is
-// zero for every sum it enters.
+// exp(x) for the training sweeps (emission probabilities, posterior masses), x <= ~1, on glibc's 2^(i/128) values kept
+// as plain doubles (exp128_build_table: 128 of them behind the softplus nodes in LDS): glibc's reduction, a degree-4
+// polynomial and no tail correction: |r| <= ln2/256, truncation r^5/120 = 1.2e-15 relative; with the dropped tail
+// (<= 2^-53) <= 2e-15 (tests/test_dp_math_strict.py). 11 fp64/integer operations and one ds_read_b64. The power of two
+// is applied with ldexp, so the result runs down through the denormals to an exact 0 below -745.2, like exp itself;
+// -inf and NaN give 0 (the argument is clamped to -750 first). The exact zero matters to the linear-domain sweeps: a
+// cell that cannot be represented must lose its mass visibly (the read is then redone in the log domain), not keep
+// 1e-304 of it.
+constexpr int EXP128_SIZE = 128;
+constexpr int EXP128_NODES = EXP128_SIZE / 2;  // in units of SoftplusNode (two doubles)
+inline void exp128_build_table(double* t) {
+  const uint64_t* T = strict_exp_table();  // glibc keeps asuint64(2^(i/128)) - (i << 45)
+  for (int i = 0; i < EXP128_SIZE; ++i) t[i] = of_bits(T[2 * i + 1] + ((uint64_t)i << 45));
+}
+
+DYN_HD double ldexp_(double v, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ldexp(v, e);
+#else
+  return __builtin_ldexp(v, e);
+#endif
+}
+
 template <int M, int J0 = 0, int J1 = M>
-DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const uint64_t* __restrict__ tab) {
+DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const double* __restrict__ tab) {
   constexpr int K = J1 - J0;
   const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52;
   const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
-  double kd[K], r[K], r2[K], p[K];
-  uint64_t sb[K];
+  double kd[K], r[K], r2[K], p[K], tv[K];
+  int ke[K];
   const double shift = vreg_const(Shift), c6 = vreg_const(1.0 / 6.0);
   const double inv = sreg_const(InvLn2N), c24 = sreg_const(1.0 / 24.0);
 #pragma unroll
-  for (int j = 0; j < K; ++j) x[J0 + j] = __builtin_fmax(x[J0 + j], -700.0);
+  for (int j = 0; j < K; ++j) x[J0 + j] = __builtin_fmax(x[J0 + j], -750.0);
 #pragma unroll
   for (int j = 0; j < K; ++j) kd[j] = fma_(x[J0 + j], inv, shift);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const uint64_t ki = bits_of(kd[j]);
-    sb[j] = tab[2u * ((unsigned)ki & 127u) + 1] + (ki << 45);
+    const int ki = (int)(unsigned)bits_of(kd[j]);  // the low word of kd: round(x 128 / ln2), two's complement
+    tv[j] = tab[(unsigned)ki & 127u];  // 2^(i/128), i = ki mod 128
+    ke[j] = ki >> 7;
   }
 #pragma unroll
   for (int j = 0; j < K; ++j) kd[j] = kd[j] - shift;
@@ -175,10 +194,7 @@ DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const uint64_t* _
 #pragma unroll
   for (int j = 0; j < K; ++j) p[j] = fma_(p[j], r2[j], r[j]);   // exp(r) - 1
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const double scale = of_bits(sb[j]);
-    out[J0 + j] = fma_(scale, p[j], scale);
-  }
+  for (int j = 0; j < K; ++j) out[J0 + j] = ldexp_(fma_(tv[j], p[j], tv[j]), ke[j]);
 }
 
 // ---- log1p(x), x in [0, 1] ----------------------------------------------------------------------

@@ -384,10 +384,10 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
                      hipMemcpyHostToDevice)) != hipSuccess)
     return fail(e, "hipMemcpy(model)");
   {
-    std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES + dynmath::EXP_TAB_NODES + dynmath::STRICT_EXP_WORDS / 2);
+    std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2);
     dynmath::softplus_build_table(tab.data());
-    dynmath::exp_build_table(reinterpret_cast<double*>(tab.data() + dynmath::SP_NODES));  // 2^(i/64), training pass
-    std::memcpy(tab.data() + dynmath::SP_NODES + dynmath::EXP_TAB_NODES, dynmath::strict_exp_table(),
+    dynmath::exp128_build_table(reinterpret_cast<double*>(tab.data() + dynmath::SP_NODES));  // 2^(i/128), training sweeps
+    std::memcpy(tab.data() + dynmath::SP_NODES + dynmath::EXP128_NODES, dynmath::strict_exp_table(),
                 dynmath::STRICT_EXP_WORDS * 8);  // 2^(k/128) of the strict exp
     if ((e = a->d_sptab.ensure(sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess) return fail(e, "hipMalloc(softplus table)");
     if ((e = hipMemcpy(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
@@ -1070,6 +1070,11 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   q.tr = dynk::TrainBuffers{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
   q.m1 = m.log_m1;
   q.e2 = m.log_e2;
+  q.m1_lin = std::exp(m.log_m1);
+  q.e2_lin = std::exp(m.log_e2);
+  q.lin_park = 950;
+  // tests: a low park leaves the linear-domain sweeps too little range, which sends reads through the log-domain redo
+  if (const char* f = std::getenv("DYN_LIN_PARK")) q.lin_park = std::min(950, std::max(-900, std::atoi(f)));
   q.sp_tab = a->d_sptab.as<dynmath::SoftplusNode>();
   q.z_fail_status = z_fail;
   const dynk::QueueJob qjob = job == DynJob::Train ? dynk::JOB_TRAIN
@@ -1125,6 +1130,7 @@ int collect_timing(dyn_batch* b) {
     a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
     return DYN_ERR_DEVICE;
   }
+  tm.reads_log_redo = b->h_stats.as<uint32_t>()[6];
   const uint64_t* s = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::QUEUE_STATS);
   const double life = (double)s[4];
   tm.ms_dp = ms01;

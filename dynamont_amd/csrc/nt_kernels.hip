@@ -209,7 +209,10 @@ __device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, doub
 }
 
 __device__ __forceinline__ const uint64_t* strict_tab(const SoftplusNode* s_tab) {
-  return reinterpret_cast<const uint64_t*>(s_tab + SP_NODES + dynmath::EXP_TAB_NODES);
+  return reinterpret_cast<const uint64_t*>(s_tab + SP_NODES + dynmath::EXP128_NODES);
+}
+__device__ __forceinline__ const double* exp128_tab(const SoftplusNode* s_tab) {
+  return reinterpret_cast<const double*>(s_tab + SP_NODES);
 }
 
 // ---- paged lattice rows --------------------------------------------------------------------------
@@ -878,7 +881,7 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
-  const uint64_t* __restrict__ etab = strict_tab(s_tab);
+  const double* __restrict__ etab = exp128_tab(s_tab);
   RowCursor cur_dma;
 
   int lo = band_mid(1, ratio) - bw;  // band of row 1
@@ -1042,6 +1045,423 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
   return readlane_f64(zf, sf / CPL);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training in the LINEAR domain (round 3). No integer decision is taken in train(): its outputs are sums of
+// posteriors, compared with the reference at 1e-9. The forward-backward recursions therefore run on probabilities
+// instead of log-probabilities -- one multiply-add per transition instead of a 19-operation logPlus, posteriors as
+// products instead of exp(fE + bE - Z) -- with the classic remedy against underflow, applied exactly:
+//   * every stored or carried row is value x 2^K with an INTEGER exponent K per row (multiplying by a power of two is
+//     exact, so the arithmetic is that of the unscaled recursion wherever nothing underflows); a row is rescaled when
+//     its largest value leaves [2^-150, 2^150] (checked per row with lane-local maxima and one ballot each way);
+//   * the emission probability is K_n exp(-z^2/2) with the exponential of exp_table128_vec; when a sample is so far
+//     from EVERY k-mer of the band that all exponents are below -300 (garbage signal, spikes) the row's exponents are
+//     shifted by a multiple of ln 2 first and the shift joins the row's integer exponent -- ratios between cells stay
+//     exact down to e^-700 below the best cell, as far as any posterior matters;
+//   * Z = ln(value) + K ln 2, one logarithm per sweep.
+// The backward sweep stores B(t, .) at scale 2^Kb(t) and writes Kb(t) (as a double) into a band slot that is out of
+// band in row t, so that it reaches the forward sweep through the same LDS-DMA ring as the row itself.
+// Reference: NT_aligner_api.cpp:110-207 (recursions), :462-561 and :641-725 (statistics).
+// ---------------------------------------------------------------------------------------------
+constexpr double INV_SQRT_2PI = 0x1.9884533d43651p-2;  // 1/sqrt(2 pi)
+constexpr double LIN_MASS_TOL = 1e-8;  // |sum of weights / (T-1) - 1| the linear-domain sweeps must keep (they keep 1e-12)
+// The exponent of a stored row rides in a band slot that is OUT of the band in that row: the first slot above the band
+// whose register index is CPL-1, so that it travels in the row's own 8-byte store of register 6 (a separate store to an
+// address the row store also writes can overtake it: non-temporal and ordinary stores are not ordered with each other).
+__device__ __forceinline__ int exponent_slot(int lo, int W) {
+  const int s0 = pmod(lo + W);
+  int off = (CPL - 1) - (s0 % CPL);  // 0 .. CPL-1; P is a multiple of CPL, so slot % CPL survives the wrap
+  if (off >= P - W) off = 0;          // bands wider than P - CPL: any free slot (see store_exponent_row)
+  return pmod(lo + W + off);
+}
+
+__device__ __forceinline__ void set_emis_lin(EmisV<CPL>& p, int j, const Emis& e) {
+  p.set(j, e);
+  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: probability 0, exponent -inf (mean = +inf)
+  p.neg_log_stdev[j] = none ? 0.0 : e.inv_stdev * INV_SQRT_2PI;  // K_n
+  if (none) p.mean[j] = __builtin_huge_val();
+}
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+__device__ __forceinline__ double pow2_f64(int k) { return __hiloint2double((1023 + k) << 20, 0); }  // |k| < 1023
+__device__ __forceinline__ int exponent_f64(double v) { return ((__double2hiint(v) >> 20) & 0x7ff) - 1023; }
+
+// P^(x; cell) = K_n exp(-z^2/2) 2^(-kshift) for the lane's cells; kshift (<= 0, wave-uniform) is 0 unless every cell of
+// the wave sits below e^-300. Exponents are kept as (integer-valued) doubles: one sample 4e4 standard deviations away
+// costs 2^-1.4e9, a read may hold a million of them, and the sum stays below 2^53.
+__device__ __forceinline__ double emission_prob_vec(double x, const EmisV<CPL>& p, double (&out)[CPL], const double* etab) {
+  double a[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) a[j] = x - p.mean[j];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) a[j] = a[j] * p.inv_stdev[j];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) a[j] = a[j] * a[j];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) a[j] = a[j] * -0.5;
+  // guard: some cell above e^-300? (columns without a k-mer have the exponent -inf and do not count)
+  double best = a[0];
+#pragma unroll
+  for (int j = 1; j < CPL; ++j) best = fmax(best, a[j]);
+  double kshift = 0.0;
+  if (__builtin_expect(!__any(best > -300.0), 0)) {
+    const double amax = wave_max_f64(best);
+    if (!(amax > -1e9)) {  // a sample further out than that (or inf / NaN): the row is dead here, Z = -inf, and the
+#pragma unroll         // read is done again in the log domain, which answers as the reference does
+      for (int j = 0; j < CPL; ++j) out[j] = 0.0;
+      return 0.0;
+    }
+    {  // shift by a whole number of ln 2 (two-step, exact to ~1e-13)
+      const double kf = floor(amax * 0x1.71547652b82fep+0);
+      kshift = kf;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-kf, 0x1.62e42fee00000p-1, a[j]);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-kf, 0x1.a39ef35793c76p-33, a[j]);
+    }
+  }
+  dynmath::exp_table128_vec<CPL>(a, out, etab);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) out[j] = out[j] * p.neg_log_stdev[j];
+  return kshift;
+}
+
+// Rows are scaled by exact powers of two so that the largest value of a row is PARKED NEAR THE TOP of the fp64 range, in
+// 2^900 .. 2^1000: nothing in a row exceeds its maximum, so everything down to 2^-1074 -- e^1370 below the maximum --
+// stays representable. What this range has to cover is how far the forward (backward) value of the cell the path goes
+// through lies below the row's largest: more than e^350 for three of four cfg5 reads (park = -500 loses their mass),
+// under e^700 for all of them (park = 0 loses none). A read that needs more is caught by its weight sum and redone in
+// the log domain (k_read_queue). rescale_exponent() returns the exponent to divide the row by, 0 in the common case.
+struct LinPark {
+  double hi, lo;  // 2^(park + 50), 2^(park - 50): the row maximum stays between them
+  int park;
+  __device__ __forceinline__ explicit LinPark(int p) : hi(pow2_f64(p + 50)), lo(pow2_f64(p - 50)), park(p) {}
+};
+// The norm of a row is the largest of BOTH its vectors: at a level change the forward mass of a row sits in fM alone
+// (fE is 2^60 and more below it, and back up one row later), and nothing bounds bM / bE from above when e2 is small.
+__device__ __forceinline__ int rescale_exponent(const LinPark& lp, const double (&v)[CPL], const double (&u)[CPL]) {
+  double mx = fmax(v[0], u[0]);
+#pragma unroll
+  for (int j = 1; j < CPL; ++j) mx = fmax(mx, fmax(v[j], u[j]));
+  const bool too_big = __any(mx > lp.hi), none_big_enough = !__any(mx > lp.lo);
+  if (__builtin_expect(too_big || none_big_enough, 0)) {
+    const double m = wave_max_f64(mx);
+    if (m > 0.0 && m < __builtin_huge_val()) {
+      const int k = exponent_f64(m) - lp.park;  // the maximum lands in [2^park, 2^(park+1))
+      return k < -1000 ? -1000 : k;            // (a denormal maximum: one exact power of two at a time)
+    }
+  }
+  return 0;
+}
+
+// Backward sweep of train(), linear domain. B(t,n) = P(sig[t] | n) [ m1 BM'(t+1,n+1) + e2 BE(t+1,n) ] in the notation of
+// backward_sweep: BM(t,n) = BE(t+1,n) P(t+1,n); BE(t,n) = m1 BM(t+1,n+1) P(t+1,n+1) + e2 BM(t,n).
+// Returns ln Zb; *zhat / *Kb0 = the stored value and exponent of cell (0,0).
+__device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
+                                                     const Emis* __restrict__ par, double* __restrict__ ws, double m1, double e2,
+                                                     int park, const SoftplusNode* s_tab, double* zhat, double* Kb0) {
+  const LinPark lp(park);
+  const int lane = w.lane;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const double ratio = rd.ratio;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const Emis* __restrict__ pr = par + rd.par_off;
+  const double* __restrict__ etab = exp128_tab(s_tab);
+  double* __restrict__ out = ws;
+  RowCursor cur;
+
+  bool bad_sample = false;
+  int lo = band_mid(T - 1, ratio) - bw;
+  const int n_init = lo + bw;
+  int n[CPL];
+  double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], pe[CPL];
+  EmisV<CPL> p;
+  double K = 0.0, ks_pending = 0.0;
+  // one row with its exponent in the exponent slot (the value that slot would carry is 0: out of band)
+  auto store_row_k = [&](size_t rt, int lo_t, double kbits, const double (&x)[CPL], auto nt) {
+    const int slot = exponent_slot(lo_t, W);
+    double y[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) y[j] = x[j];
+    if (__builtin_expect(slot % CPL == CPL - 1, 1)) {
+      y[CPL - 1] = (lane == slot / CPL) ? kbits : x[CPL - 1];
+    } else {  // very wide bands only
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) y[j] = (lane * CPL + j == slot) ? kbits : x[j];
+    }
+    store_row_f64<decltype(nt)::value>(out + rt, lane, y);
+  };
+  {
+    const size_t rT = (size_t)cur.at(w, T) * P, rT1 = (size_t)cur.at(w, T - 1) * P;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int slot = lane * CPL + j;
+      n[j] = lo + pmod(slot - lo);
+      set_emis_lin(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+      bE[j] = (n[j] == n_init) ? 1.0 : 0.0;
+      bM[j] = 0.0;
+    }
+    store_row_k(rT1, lo, 0.0, bE, std::false_type{});
+    store_row_f64<false>(out + rT, lane, bM);  // all zero: rows past the lattice, streamed by the ring's tail
+  }
+
+  for (int thi = T - 2; thi >= 0; thi -= 64) {
+    const int base = thi - 63;
+    const int idx = base + lane;
+    const double xs = (idx >= 0) ? sg[idx] : 0.0;
+    bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
+    const int ilo = base < 0 ? -base : 0;
+    ks_pending = emission_prob_vec(readlane_f64(xs, 63), p, pe, etab);  // P(thi+1, n) from sig[thi]
+    auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
+      const int t = base + i;
+      double Y[CPL], Yr[CPL];
+      K += ks_pending;  // the emission factors of this row carry 2^ks
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) Y[j] = bM_in[j] * pe[j];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) bM_out[j] = bE_in[j] * pe[j];
+      from_right(Y, Yr);
+      const int new_lo = band_mid(t, ratio) - bw;
+      if (__builtin_expect(new_lo != lo, 0)) {  // wave-uniform: the window moved down by one column (see backward_sweep)
+        const int leaving = lo + P - 1;
+        const int top = lo + W - 1;
+        const Emis fresh = load_emis(pr, new_lo, N);
+        const Emis none = load_emis(pr, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          if (n[j] == leaving) {
+            n[j] = new_lo;
+            set_emis_lin(p, j, fresh);
+          }
+          if (n[j] == top) {
+            bM_out[j] = 0.0;
+            set_emis_lin(p, j, none);
+          }
+        }
+        lo = new_lo;
+      }
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) bE_out[j] = dynmath::fma_(Yr[j], m1, bM_out[j] * e2);
+      // emission factors of the NEXT row (sample t-1); at i == 0 the value computed here is thrown away (see backward_sweep)
+      ks_pending = emission_prob_vec(readlane_f64(xs, i > 0 ? i - 1 : 0), p, pe, etab);
+      const int k = rescale_exponent(lp, bE_out, bM_out);
+      if (__builtin_expect(k != 0, 0)) {
+        const double f = pow2_f64(-k);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          bE_out[j] *= f;
+          bM_out[j] *= f;
+        }
+        K += k;
+      }
+      const size_t rt = (size_t)cur.at(w, t) * P;
+      store_row_k(rt, lo, K, bE_out, std::true_type{});
+    };
+    int i = 63;
+#pragma unroll 1
+    for (; i - 1 >= ilo; i -= 2) {
+      row(i, bE, bM, bE2, bM2);
+      row(i - 1, bE2, bM2, bE, bM);
+    }
+    if (i >= ilo) {
+      row(i, bE, bM, bE2, bM2);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        bE[j] = bE2[j];
+        bM[j] = bM2[j];
+      }
+    }
+  }
+  const bool any_bad = __any(bad_sample);
+  const double z0 = readlane_f64(bE[0], 0);  // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
+  *zhat = z0;
+  *Kb0 = K;
+  return any_bad ? NEG_INF : log(z0) + (double)K * 0x1.62e42fefa39efp-1;
+}
+
+// Forward sweep of train() with the Baum-Welch statistics, linear domain (see forward_train_sweep for the statistics):
+//   fM(t,n) = fE(t-1,n-1) P(t,n) m1;  x1 = fM(t-1,n) P(t,n);  fE(t,n) = x1 + e2 fE(t-1,n) P(t,n)
+//   gamma_E(t,n) = fE(t,n) B(t,n) / Z;  gamma_M(t-1,n) = x1 B(t,n) / Z        (bM(t-1,n) = B(t,n) P(t,n))
+__device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
+                                                    const Emis* __restrict__ par, const double* __restrict__ ws, TrainBuffers tb,
+                                                    double zhat, double Kb0, double m1, double e2, int park,
+                                                    const SoftplusNode* s_tab, unsigned ring_base, double* total_weight) {
+  const LinPark lp(park);
+  const int lane = w.lane;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const double ratio = rd.ratio;
+  const double* __restrict__ sg = sig + rd.sig_off;
+  const Emis* __restrict__ pr = par + rd.par_off;
+  double* __restrict__ cw = tb.col_w + rd.par_off;
+  double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
+  double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
+  const double* __restrict__ etab = exp128_tab(s_tab);
+  RowCursor cur_dma;
+  const double inv_z = 1.0 / zhat;
+
+  int lo = band_mid(1, ratio) - bw;  // band of row 1
+  double fM[CPL], fE[CPL], pe[CPL];
+  double gEa[CPL], gEb[CPL];
+  double aw[CPL], a1[CPL], a2[CPL];
+  EmisV<CPL> p;
+  double sumE = 0.0, awsum = 0.0;
+  double K = 0.0;
+  const double x0 = sg[0];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int nj = lo + pmod(lane * CPL + j - lo);
+    set_emis_lin(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0));
+    fE[j] = (nj == 0) ? 1.0 : 0.0;
+    fM[j] = 0.0;
+    gEa[j] = 0.0;
+    aw[j] = a1[j] = a2[j] = 0.0;
+  }
+  double ks_pending = emission_prob_vec(x0, p, pe, etab);  // P(1, n)
+  const double* __restrict__ dma_src = ws + lane * 2;
+  for (int r = 1; r <= RING_D; ++r)
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
+
+  auto row = [&](int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
+    double fEl[CPL], bcur[CPL], x1[CPL], q[CPL];
+    const int lo_t = lo;  // the band of row t (the exponent's slot is defined by it)
+    const int next_lo = band_mid(t + 1, ratio) - bw;
+    K += ks_pending;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) x1[j] = fM[j] * pe[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) q[j] = fE[j] * pe[j];
+    from_left(fE, fEl);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) fM[j] = (fEl[j] * pe[j]) * m1;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) fE[j] = dynmath::fma_(q[j], e2, x1[j]);
+    if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
+      const Emis none = load_emis(pr, 0, 0);
+      const Emis entering = load_emis(pr, lo + W, N);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int nj = lo + pmod(lane * CPL + j - lo);
+        if (nj == lo - 1 + P) {  // handed on at the PREVIOUS move: nothing but zeros since
+          if (lo - 1 >= 1 && lo - 1 < N) {
+            cw[lo - 2] = aw[j];
+            cs1[lo - 2] = a1[j];
+            cs2[lo - 2] = a2[j];
+          }
+          awsum += aw[j];
+          aw[j] = a1[j] = a2[j] = 0.0;
+        }
+        if (nj == lo) set_emis_lin(p, j, none);
+        if (nj == lo + W) set_emis_lin(p, j, entering);
+      }
+      lo = next_lo;
+    }
+    ks_pending = emission_prob_vec(xn, p, pe, etab);  // P(t+1, .)
+    // B(t, .) and its exponent from the ring; the slot is then refilled with row t + RING_D
+    wait_vmcnt<RING_WAIT>();
+    const unsigned slot_addr = ring_base + (t % RING_D) * ROW_BYTES;
+    ring_read_row(slot_addr, lane, bcur);
+    double kb_d;
+    {
+      const unsigned kaddr = slot_addr + (unsigned)row_pos(exponent_slot(lo_t, W)) * 8u;
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kb_d) : "v"(kaddr) : "memory");
+    }
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, slot_addr);
+    const double Kb = readlane_f64(kb_d, 0);
+    // posteriors: fE x B / Z = fE^ x (B^ / zhat) x 2^(K + Kb - Kb0); with both rows parked near 2^950 the power of two
+    // alone is ~2^-950 and B^ / zhat ~ 1: the quotient first, then the exponent, per cell
+    const int ex = max(-4000, min(4000, (int)((K - Kb0) + Kb)));  // (the conversion saturates)
+    const double xp2 = xp * xp;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const double g = __builtin_amdgcn_ldexp(bcur[j] * inv_z, ex);
+      g_out[j] = fE[j] * g;                                       // gamma_E(t, n)
+      const double wgt = dynmath::fma_(x1[j], g, g_prev[j]);      // + gamma_M(t-1, n): both carry the sample of row t-1
+      aw[j] += wgt;
+      a1[j] = dynmath::fma_(wgt, xp, a1[j]);
+      a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
+      sumE += g_out[j];
+    }
+    const int k = rescale_exponent(lp, fE, fM);
+    if (__builtin_expect(k != 0, 0)) {
+      const double f = pow2_f64(-k);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        fE[j] *= f;
+        fM[j] *= f;
+      }
+      K += k;
+    }
+  };
+
+  double xt = x0, xp = 0.0;
+  bool odd = false;
+  for (int tb0 = 1; tb0 < T; tb0 += 64) {
+    const int idx = tb0 + lane;
+    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    asm volatile("" ::"v"(xs));
+    const int iend = min(64, T - tb0);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 1 < iend; i += 2) {
+      const double xa = readlane_f64(xs, i), xb = readlane_f64(xs, i + 1);
+      row(tb0 + i, xa, xp, gEa, gEb);
+      row(tb0 + i + 1, xb, xt, gEb, gEa);
+      xp = xa;
+      xt = xb;
+    }
+    if (i < iend) {
+      const double xa = readlane_f64(xs, i);
+      row(tb0 + i, xa, xp, gEa, gEb);
+      xp = xt;
+      xt = xa;
+      odd = true;
+    }
+  }
+  wait_vmcnt<0>();
+  {
+    const double xl2 = xp * xp;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const double g = odd ? gEb[j] : gEa[j];
+      aw[j] += g;
+      a1[j] = dynmath::fma_(g, xp, a1[j]);
+      a2[j] = dynmath::fma_(g, xl2, a2[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int nj = lo + pmod(lane * CPL + j - lo);
+    const int c = (nj == lo - 1 + P) ? lo - 1 : nj;
+    if (c >= 1 && c < N) {
+      cw[c - 1] = aw[j];
+      cs1[c - 1] = a1[j];
+      cs2[c - 1] = a2[j];
+    }
+    awsum += aw[j];
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    sumE += __shfl_xor(sumE, off);
+    awsum += __shfl_xor(awsum, off);
+  }
+  if (lane == 0) {
+    const double sumM = awsum - sumE;
+    tb.trans[2 * rd.read] = sumM;
+    tb.trans[2 * rd.read + 1] = sumE - sumM;
+  }
+  *total_weight = awsum;
+  const int nf = band_mid(T - 1, ratio);
+  const int sf = pmod(nf);
+  double zf = 0.0;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j)
+    if (j == sf % CPL) zf = fE[j];
+  return log(readlane_f64(zf, sf / CPL)) + (double)K * 0x1.62e42fefa39efp-1;
+}
+
 // ---- read queue and page pool -------------------------------------------------------------------------
 // Shared control words are only ever touched with agent-scope atomics (sc1 accesses: the per-XCD L2s are
 // not coherent with each other, MI355X_MICROARCH.md "inter-workgroup visibility"); a lock serialises the
@@ -1057,7 +1477,7 @@ __device__ __forceinline__ void ctl_store(uint32_t* p, uint32_t v) {
 // Every wait below is bounded: a wave that has waited for seconds (a lost lock, a page count that never
 // recovers) raises the abort word, which drains the queue -- the grid always terminates, and the host
 // reports the launch as failed instead of hanging the device.
-constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5;
+constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5, CTL_LOG_REDO = 6;
 constexpr int LOCK_SPINS_MAX = 1 << 24;   // x ~0.3 us
 constexpr int PAGE_WAITS_MAX = 1 << 18;   // x ~30 us
 
@@ -1172,8 +1592,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
                                                    const double* __restrict__ sig, const Emis* __restrict__ par,
                                                    const SoftplusNode* __restrict__ sp_tab) {
   constexpr bool LATTICE = JOB != JOB_Z;
-  // + 2^(i/64) (exp_vec) + the 2^(k/128) table of the strict exp (dp_math_strict.hpp)
-  constexpr int TAB_NODES = SP_NODES + dynmath::EXP_TAB_NODES + dynmath::STRICT_EXP_WORDS / 2;
+  // + 2^(i/128) as plain doubles (exp_table128_vec) + glibc's table of the strict exp (dp_math_strict.hpp)
+  constexpr int TAB_NODES = SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2;
   __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[TAB_NODES];
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
   __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
@@ -1249,16 +1669,45 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
       else
         Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
     } else {
-      Zb = backward_sweep<LATTICE, JOB == JOB_TRAIN ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
-      t2 = __builtin_amdgcn_s_memtime();
-      if (JOB == JOB_TRAIN) {
+      if constexpr (JOB == JOB_TRAIN) {
+#ifndef DYN_TRAIN_LOG_DOMAIN
+        // linear domain first. Its one weakness is the range of fp64 WITHIN a row (e^1300 below the row's largest value):
+        // a row whose path cell lies further down loses posterior mass, and the loss shows -- every signal sample carries
+        // total weight 1, so the weights of the read sum to T - 1, and Z agrees both ways. A read that fails either check
+        // is done again in the log domain, which has no such limit (and decides whether Z really disagrees).
+        double lin_zhat = 0.0, total = 0.0, lin_Kb0 = 0.0;
+        Zb = backward_train_lin(rd, w, sig, par, q.pool.ws, q.m1_lin, q.e2_lin, q.lin_park, s_tab, &lin_zhat, &lin_Kb0);
+        t2 = __builtin_amdgcn_s_memtime();
+        Zf = forward_train_lin(rd, w, sig, par, q.pool.ws, q.tr, lin_zhat, lin_Kb0, q.m1_lin, q.e2_lin, q.lin_park, s_tab, ring_base, &total);
+        const double S = (double)(rd.T - 1);
+        const bool lin_ok = z_ok(rd, Zf, Zb) && fabs(total - S) <= LIN_MASS_TOL * S;  // (NaN fails)
+#ifdef DYN_DBG_LIN
+        if (w.lane == 0) printf("read %u T %u Zf %.12g Zb %.12g total %.12g ok %d\n", rd.read, rd.T, Zf, Zb, total, (int)lin_ok);
+#endif
+#ifndef DYN_TRAIN_NO_FALLBACK
+        if (__builtin_expect(!lin_ok, 0)) {
+          Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+          Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
+          if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_LOG_REDO], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#else
+        if (!lin_ok) Zf = NEG_INF;
+#endif
+#else
+        Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+        t2 = __builtin_amdgcn_s_memtime();
         Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
-      } else if (JOB == JOB_ALIGN) {
-        Zf = forward_sweep<true, false, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
-      } else if (JOB == JOB_ALIGN_INPLACE) {
-        Zf = forward_sweep<true, true, false>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+#endif
       } else {
-        Zf = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+        Zb = backward_sweep<LATTICE, ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+        t2 = __builtin_amdgcn_s_memtime();
+        if (JOB == JOB_ALIGN) {
+          Zf = forward_sweep<true, false, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+        } else if (JOB == JOB_ALIGN_INPLACE) {
+          Zf = forward_sweep<true, true, false>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
+        } else {
+          Zf = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+        }
       }
     }
     cyc_b += t2 - t1;

@@ -12,7 +12,7 @@ from conftest import ROOT
 from oracle import pyoracle
 
 SRC = r'''
-#include "%s/dynamont_amd/csrc/dp_math.hpp"
+#include "%s/dynamont_amd/csrc/dp_math_strict.hpp"
 #include <vector>
 extern "C" {
 void eval_softplus(const double* d, double* out, long n) { for (long i = 0; i < n; ++i) out[i] = dynmath::softplus_nonpos(d[i]); }
@@ -49,13 +49,13 @@ void eval_softplus_table(const double* d, double* out, long n) {
     for (int j = 0; j < 7; ++j) out[i + j] = g[j];
   }
 }
-void eval_exp_vec(const double* d, double* out, long n) {
+void eval_exp_vec(const double* d, double* out, long n) {   // exp_table128_vec: the training sweeps' exponential
   for (long i = 0; i + 7 <= n; i += 7) {
     double a[7], g[7];
     for (int j = 0; j < 7; ++j) a[j] = d[i + j];
-    static double ET[dynmath::EXP_TAB_SIZE]; static bool init = false;
-    if (!init) { dynmath::exp_build_table(ET); init = true; }
-    dynmath::exp_vec<7>(a, g, ET);
+    static double ET[dynmath::EXP128_SIZE]; static bool init = false;
+    if (!init) { dynmath::exp128_build_table(ET); init = true; }
+    dynmath::exp_table128_vec<7>(a, g, ET);
     for (int j = 0; j < 7; ++j) out[i + j] = g[j];
   }
 }
@@ -227,16 +227,26 @@ def test_logplus_sigma_share(mathlib):
     assert list(s7[:3]) == [0.0, 0.0, 0.0] and s7[3] == 0.5 and s7[4] == 0.0 and s7[5] == 0.0 and s7[6] == 0.5
 
 
-def test_exp_vec_accuracy(mathlib):
+def test_exp_table128_vec_accuracy_and_exact_zero(mathlib):
+    """2e-15 relative down to the smallest normal number, gradual underflow below it (like exp itself: half a unit of
+    the denormal spacing), exactly 0 from -745.2 on and for -inf / NaN -- a cell the linear-domain sweeps cannot
+    represent must vanish, not keep 1e-304."""
     rng = np.random.default_rng(5)
-    d = np.concatenate([-rng.uniform(0, 60, 3500), rng.uniform(-1e-9, 1e-9, 700), rng.uniform(0, 5, 693), [0.0, -745.0, -999.0, -1e9, 1e-300, -1e-300, -0.5]])
+    d = np.concatenate([-rng.uniform(0, 60, 3500), -rng.uniform(600, 708, 1400), rng.uniform(-1e-9, 1e-9, 700), rng.uniform(0, 5, 686),
+                        -rng.uniform(708, 746, 700), [0.0, -745.0, -745.2, -999.0, -1e9, 1e-300, -1e-300, -0.5, -np.inf, np.nan, -746.0, -750.0, -751.0, -1e300]])
     d = d[: len(d) // 7 * 7].copy()
     out = np.empty_like(d)
     mathlib.eval_exp_vec(d.ctypes.data_as(dp), out.ctypes.data_as(dp), C.c_long(len(d)))
     mp.mp.dps = 40
     worst = 0.0
+    tiny = mp.mpf(2) ** -1074
     for x, y in zip(d, out):
-        t = mp.exp(mp.mpf(float(max(x, -1000.0))))
-        if t > mp.mpf(10) ** -300:
+        if not np.isfinite(x) or x < -745.14:
+            assert y == 0.0, (x, y)
+            continue
+        t = mp.exp(mp.mpf(float(x)))
+        if t > mp.mpf(2) ** -1022:
             worst = max(worst, float(abs(mp.mpf(float(y)) - t) / t))
-    assert worst < 3e-16, worst
+        else:
+            assert abs(mp.mpf(float(y)) - t) <= tiny * mp.mpf("0.51") + t * mp.mpf("3e-15"), (x, y)
+    assert worst < 2.5e-15, worst
