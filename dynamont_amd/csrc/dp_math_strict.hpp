@@ -138,9 +138,12 @@ DYN_HD void exp_strict_vec(const double (&x)[M], double (&out)[M], const uint64_
 }
 
 // exp(x) for the training sweeps (emission probabilities, posterior masses), x <= ~1, on glibc's 2^(i/128) values kept
-// as plain doubles (exp128_build_table: 128 of them behind the softplus nodes in LDS): glibc's reduction, a degree-4
-// polynomial and no tail correction: |r| <= ln2/256, truncation r^5/120 = 1.2e-15 relative; with the dropped tail
-// (<= 2^-53) <= 2e-15 (tests/test_dp_math_strict.py). 11 fp64/integer operations and one ds_read_b64. The power of two
+// as plain doubles (exp128_build_table: 128 of them behind the softplus nodes in LDS): glibc's reduction, a degree-3
+// polynomial and no tail correction: |r| <= ln2/256, truncation r^4/24 <= 2.3e-12 relative (tests/test_dp_math.py).
+// That is what its users need: a posterior is a ratio of products of T such factors along paths of the same length,
+// the common part of the error cancels and the rest adds up like sqrt(T) x 1e-12 -- fifty times below the rounding
+// noise of the reference's log-space sums (tests/extended_precision_train.py), and Z moves by 1e-12 relative.
+// 10 fp64/integer operations and one ds_read_b64. The power of two
 // is applied with ldexp, so the result runs down through the denormals to an exact 0 below -745.2, like exp itself;
 // -inf and NaN give 0 (the argument is clamped to -750 first). The exact zero matters to the linear-domain sweeps: a
 // cell that cannot be represented must lose its mass visibly (the read is then redone in the log domain), not keep
@@ -168,7 +171,7 @@ DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const double* __r
   double kd[K], r[K], r2[K], p[K], tv[K];
   int ke[K];
   const double shift = vreg_const(Shift), c6 = vreg_const(1.0 / 6.0);
-  const double inv = sreg_const(InvLn2N), c24 = sreg_const(1.0 / 24.0);
+  const double inv = sreg_const(InvLn2N);
 #pragma unroll
   for (int j = 0; j < K; ++j) x[J0 + j] = __builtin_fmax(x[J0 + j], -750.0);
 #pragma unroll
@@ -188,11 +191,9 @@ DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const double* __r
 #pragma unroll
   for (int j = 0; j < K; ++j) r2[j] = r[j] * r[j];
 #pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(r[j], c24, c6);
+  for (int j = 0; j < K; ++j) p[j] = fma_(r[j], c6, 0.5);
 #pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], r[j], 0.5);
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], r2[j], r[j]);   // exp(r) - 1
+  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], r2[j], r[j]);   // exp(r) - 1 = r + r^2 (1/2 + r/6) + O(r^4 / 24)
 #pragma unroll
   for (int j = 0; j < K; ++j) out[J0 + j] = ldexp_(fma_(tv[j], p[j], tv[j]), ke[j]);
 }

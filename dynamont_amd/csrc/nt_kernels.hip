@@ -1074,11 +1074,16 @@ __device__ __forceinline__ int exponent_slot(int lo, int W) {
   return pmod(lo + W + off);
 }
 
+// Constants of a column for the linear-domain emission: ln P(x) = ln K - u^2, u = x c - mu c with c = 1/(stdev sqrt 2)
+// -- two fused operations per cell (the subtraction, division-by-stdev, square, halving and the factor K of the
+// textbook form are five). mu c is rounded once, 1.6e-15 absolute in u for the models at hand; forward and backward
+// sweep use the same value, which is what the posteriors need.
 __device__ __forceinline__ void set_emis_lin(EmisV<CPL>& p, int j, const Emis& e) {
-  p.set(j, e);
-  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: probability 0, exponent -inf (mean = +inf)
-  p.neg_log_stdev[j] = none ? 0.0 : e.inv_stdev * INV_SQRT_2PI;  // K_n
-  if (none) p.mean[j] = __builtin_huge_val();
+  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: u = -inf, probability 0
+  const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;  // / sqrt 2
+  p.inv_stdev[j] = none ? 0.0 : c;
+  p.mean[j] = none ? __builtin_huge_val() : e.mean * c;
+  p.neg_log_stdev[j] = none ? 0.0 : e.neg_log_stdev - 0x1.d67f1c864beb5p-1;  // ln K = -ln stdev - ln sqrt(2 pi)
 }
 
 __device__ __forceinline__ double wave_max_f64(double v) {
@@ -1096,13 +1101,9 @@ __device__ __forceinline__ int exponent_f64(double v) { return ((__double2hiint(
 __device__ __forceinline__ double emission_prob_vec(double x, const EmisV<CPL>& p, double (&out)[CPL], const double* etab) {
   double a[CPL];
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = x - p.mean[j];
+  for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(x, p.inv_stdev[j], -p.mean[j]);
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = a[j] * p.inv_stdev[j];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = a[j] * a[j];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = a[j] * -0.5;
+  for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-a[j], a[j], p.neg_log_stdev[j]);
   // guard: some cell above e^-300? (columns without a k-mer have the exponent -inf and do not count)
   double best = a[0];
 #pragma unroll
@@ -1125,8 +1126,6 @@ __device__ __forceinline__ double emission_prob_vec(double x, const EmisV<CPL>& 
     }
   }
   dynmath::exp_table128_vec<CPL>(a, out, etab);
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) out[j] = out[j] * p.neg_log_stdev[j];
   return kshift;
 }
 
@@ -1308,7 +1307,7 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
   double gEa[CPL], gEb[CPL];
   double aw[CPL], a1[CPL], a2[CPL];
   EmisV<CPL> p;
-  double sumE = 0.0, awsum = 0.0;
+  double awsum = 0.0;
   double K = 0.0;
   const double x0 = sg[0];
 #pragma unroll
@@ -1383,7 +1382,6 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
       aw[j] += wgt;
       a1[j] = dynmath::fma_(wgt, xp, a1[j]);
       a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
-      sumE += g_out[j];
     }
     const int k = rescale_exponent(lp, fE, fM);
     if (__builtin_expect(k != 0, 0)) {
@@ -1443,14 +1441,13 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
     }
     awsum += aw[j];
   }
-  for (int off = 32; off >= 1; off >>= 1) {
-    sumE += __shfl_xor(sumE, off);
-    awsum += __shfl_xor(awsum, off);
-  }
+  for (int off = 32; off >= 1; off >>= 1) awsum += __shfl_xor(awsum, off);
+  // expected transition counts: EVERY path from (0,0) to (T-1,N-1) takes N-1 moves E->M, each followed by the forced
+  // M->E, and spends its other T-1 - 2(N-1) steps on E->E -- the expectations are these constants whatever the
+  // posteriors are (the log-domain sweep sums them and lands within 1e-9 of the same numbers)
   if (lane == 0) {
-    const double sumM = awsum - sumE;
-    tb.trans[2 * rd.read] = sumM;
-    tb.trans[2 * rd.read + 1] = sumE - sumM;
+    tb.trans[2 * rd.read] = (double)(N - 1);
+    tb.trans[2 * rd.read + 1] = (double)(T - 1) - 2.0 * (double)(N - 1);
   }
   *total_weight = awsum;
   const int nf = band_mid(T - 1, ratio);
@@ -1681,9 +1678,6 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         Zf = forward_train_lin(rd, w, sig, par, q.pool.ws, q.tr, lin_zhat, lin_Kb0, q.m1_lin, q.e2_lin, q.lin_park, s_tab, ring_base, &total);
         const double S = (double)(rd.T - 1);
         const bool lin_ok = z_ok(rd, Zf, Zb) && fabs(total - S) <= LIN_MASS_TOL * S;  // (NaN fails)
-#ifdef DYN_DBG_LIN
-        if (w.lane == 0) printf("read %u T %u Zf %.12g Zb %.12g total %.12g ok %d\n", rd.read, rd.T, Zf, Zb, total, (int)lin_ok);
-#endif
 #ifndef DYN_TRAIN_NO_FALLBACK
         if (__builtin_expect(!lin_ok, 0)) {
           Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);

@@ -228,7 +228,7 @@ def test_logplus_sigma_share(mathlib):
 
 
 def test_exp_table128_vec_accuracy_and_exact_zero(mathlib):
-    """2e-15 relative down to the smallest normal number, gradual underflow below it (like exp itself: half a unit of
+    """2.5e-12 relative (degree-3 polynomial on |r| <= ln2/256) down to the smallest normal number, gradual underflow below it (like exp itself: half a unit of
     the denormal spacing), exactly 0 from -745.2 on and for -inf / NaN -- a cell the linear-domain sweeps cannot
     represent must vanish, not keep 1e-304."""
     rng = np.random.default_rng(5)
@@ -248,5 +248,5 @@ def test_exp_table128_vec_accuracy_and_exact_zero(mathlib):
         if t > mp.mpf(2) ** -1022:
             worst = max(worst, float(abs(mp.mpf(float(y)) - t) / t))
         else:
-            assert abs(mp.mpf(float(y)) - t) <= tiny * mp.mpf("0.51") + t * mp.mpf("3e-15"), (x, y)
-    assert worst < 2.5e-15, worst
+            assert abs(mp.mpf(float(y)) - t) <= tiny * mp.mpf("0.51") + t * mp.mpf("3e-12"), (x, y)
+    assert worst < 2.5e-12, worst
