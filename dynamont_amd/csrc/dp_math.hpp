@@ -30,6 +30,19 @@ constexpr double NEG_INF = -__builtin_huge_val();
 
 DYN_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// max as the hardware does it (a NaN operand loses). __builtin_fmax means the same, but the compiler canonicalises
+// every operand it cannot prove NaN-free first (v_max_f64 x, x, x): one wasted instruction per operand in the
+// training sweeps, where the values come out of selects.
+DYN_HD double max_hw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return __builtin_fmax(a, b);
+#endif
+}
+
 // 1/x to ~1 ulp for x in [2, 4]: hardware seed + two Newton steps (same structure the compiler
 // uses for fp64 division, minus scaling/fixup that this range never needs).
 DYN_HD double rcp_seed(double x) {

@@ -171,9 +171,9 @@ DYN_HD void exp_table128_vec(double (&x)[M], double (&out)[M], const double* __r
   double kd[K], r[K], r2[K], p[K], tv[K];
   int ke[K];
   const double shift = vreg_const(Shift), c6 = vreg_const(1.0 / 6.0);
-  const double inv = sreg_const(InvLn2N);
+  const double inv = sreg_const(InvLn2N), floor750 = vreg_const(-750.0);
 #pragma unroll
-  for (int j = 0; j < K; ++j) x[J0 + j] = __builtin_fmax(x[J0 + j], -750.0);
+  for (int j = 0; j < K; ++j) x[J0 + j] = max_hw(x[J0 + j], floor750);
 #pragma unroll
   for (int j = 0; j < K; ++j) kd[j] = fma_(x[J0 + j], inv, shift);
 #pragma unroll

@@ -1107,7 +1107,7 @@ __device__ __forceinline__ double emission_prob_vec(double x, const EmisV<CPL>& 
   // guard: some cell above e^-300? (columns without a k-mer have the exponent -inf and do not count)
   double best = a[0];
 #pragma unroll
-  for (int j = 1; j < CPL; ++j) best = fmax(best, a[j]);
+  for (int j = 1; j < CPL; ++j) best = dynmath::max_hw(best, a[j]);
   double kshift = 0.0;
   if (__builtin_expect(!__any(best > -300.0), 0)) {
     const double amax = wave_max_f64(best);
@@ -1143,9 +1143,9 @@ struct LinPark {
 // The norm of a row is the largest of BOTH its vectors: at a level change the forward mass of a row sits in fM alone
 // (fE is 2^60 and more below it, and back up one row later), and nothing bounds bM / bE from above when e2 is small.
 __device__ __forceinline__ int rescale_exponent(const LinPark& lp, const double (&v)[CPL], const double (&u)[CPL]) {
-  double mx = fmax(v[0], u[0]);
+  double mx = dynmath::max_hw(v[0], u[0]);
 #pragma unroll
-  for (int j = 1; j < CPL; ++j) mx = fmax(mx, fmax(v[j], u[j]));
+  for (int j = 1; j < CPL; ++j) mx = dynmath::max_hw(mx, dynmath::max_hw(v[j], u[j]));
   const bool too_big = __any(mx > lp.hi), none_big_enough = !__any(mx > lp.lo);
   if (__builtin_expect(too_big || none_big_enough, 0)) {
     const double m = wave_max_f64(mx);
