@@ -1215,7 +1215,7 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
     bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
     ks_pending = emission_prob_vec(readlane_f64(xs, 63), p, pe, etab);  // P(thi+1, n) from sig[thi]
-    auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
+    auto row = [&](auto rescale, int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
       const int t = base + i;
       double Y[CPL], Yr[CPL];
       K += ks_pending;  // the emission factors of this row carry 2^ks
@@ -1247,7 +1247,10 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
       for (int j = 0; j < CPL; ++j) bE_out[j] = dynmath::fma_(Yr[j], m1, bM_out[j] * e2);
       // emission factors of the NEXT row (sample t-1); at i == 0 the value computed here is thrown away (see backward_sweep)
       ks_pending = emission_prob_vec(readlane_f64(xs, i > 0 ? i - 1 : 0), p, pe, etab);
-      const int k = rescale_exponent(lp, bE_out, bM_out);
+      // (every second row: two rows grow the values by at most K^2 (m1 + e2)^2, far inside the 2^24 between the top
+      // of the parking window and the end of the range; a row that overflows or collapses before its check loses mass
+      // and the read is redone. Every fourth row was measured too: no faster.)
+      const int k = decltype(rescale)::value ? rescale_exponent(lp, bE_out, bM_out) : 0;
       if (__builtin_expect(k != 0, 0)) {
         const double f = pow2_f64(-k);
 #pragma unroll
@@ -1263,11 +1266,11 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
     int i = 63;
 #pragma unroll 1
     for (; i - 1 >= ilo; i -= 2) {
-      row(i, bE, bM, bE2, bM2);
-      row(i - 1, bE2, bM2, bE, bM);
+      row(std::false_type{}, i, bE, bM, bE2, bM2);
+      row(std::true_type{}, i - 1, bE2, bM2, bE, bM);
     }
     if (i >= ilo) {
-      row(i, bE, bM, bE2, bM2);
+      row(std::true_type{}, i, bE, bM, bE2, bM2);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         bE[j] = bE2[j];
@@ -1324,7 +1327,7 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
   for (int r = 1; r <= RING_D; ++r)
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
 
-  auto row = [&](int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
+  auto row = [&](auto rescale, int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
     double fEl[CPL], bcur[CPL], x1[CPL], q[CPL];
     const int lo_t = lo;  // the band of row t (the exponent's slot is defined by it)
     const int next_lo = band_mid(t + 1, ratio) - bw;
@@ -1383,7 +1386,7 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
       a1[j] = dynmath::fma_(wgt, xp, a1[j]);
       a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
     }
-    const int k = rescale_exponent(lp, fE, fM);
+    const int k = decltype(rescale)::value ? rescale_exponent(lp, fE, fM) : 0;
     if (__builtin_expect(k != 0, 0)) {
       const double f = pow2_f64(-k);
 #pragma unroll
@@ -1406,14 +1409,14 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
 #pragma unroll 1
     for (; i + 1 < iend; i += 2) {
       const double xa = readlane_f64(xs, i), xb = readlane_f64(xs, i + 1);
-      row(tb0 + i, xa, xp, gEa, gEb);
-      row(tb0 + i + 1, xb, xt, gEb, gEa);
+      row(std::false_type{}, tb0 + i, xa, xp, gEa, gEb);
+      row(std::true_type{}, tb0 + i + 1, xb, xt, gEb, gEa);
       xp = xa;
       xt = xb;
     }
     if (i < iend) {
       const double xa = readlane_f64(xs, i);
-      row(tb0 + i, xa, xp, gEa, gEb);
+      row(std::true_type{}, tb0 + i, xa, xp, gEa, gEb);
       xp = xt;
       xt = xa;
       odd = true;
