@@ -1,14 +1,15 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun): rocprofv3 evidence for the bench workloads. Kernel trace/stats and each PMC group are
 # separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other traces).
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r02 [regex of run names, e.g. train]
 set -u
 R=${1:-r02}
+ONLY=${2:-.}
 OUT=/root/repo/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=/root/repo/bench.py
-run() { name=$1; shift; echo "== $name"; timeout -k 10 280 "$@" > $OUT/$name.log 2>&1 || echo "   rc=$?"; }
+run() { name=$1; shift; [[ $name =~ $ONLY ]] || return 0; echo "== $name"; timeout -k 10 280 "$@" > $OUT/$name.log 2>&1 || echo "   rc=$?"; }
 run stats_align   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_align   -- python3 $B --no-cpu-baseline --steps 8
 run stats_train   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train   -- python3 $B --no-cpu-baseline --steps 8 --mode train
 run stats_cfg3    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3    -- python3 $B --no-cpu-baseline --workload cfg3 --steps 3 --warmup 1 --batches 1
