@@ -1078,6 +1078,17 @@ __device__ __forceinline__ int exponent_slot(int lo, int W) {
 // -- two fused operations per cell (the subtraction, division-by-stdev, square, halving and the factor K of the
 // textbook form are five). mu c is rounded once, 1.6e-15 absolute in u for the models at hand; forward and backward
 // sweep use the same value, which is what the posteriors need.
+// Where the exponent of the row with band start lo lives: register CPL-1 of lane `lane` (the common case), or an
+// arbitrary slot (lane < 0; bands wider than P - CPL only). Recomputed when the band moves, not per row: the two
+// modulo operations are ~25 scalar instructions.
+struct KSlot {
+  int lane, slot;
+};
+__device__ __forceinline__ KSlot kslot_of(int lo, int W) {
+  const int s = exponent_slot(lo, W);
+  return KSlot{s % CPL == CPL - 1 ? s / CPL : -1, s};
+}
+
 __device__ __forceinline__ void set_emis_lin(EmisV<CPL>& p, int j, const Emis& e) {
   const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: u = -inf, probability 0
   const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;  // / sqrt 2
@@ -1180,17 +1191,17 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
   double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], pe[CPL];
   EmisV<CPL> p;
   double K = 0.0, ks_pending = 0.0;
+  KSlot kslot{-1, 0};
   // one row with its exponent in the exponent slot (the value that slot would carry is 0: out of band)
-  auto store_row_k = [&](size_t rt, int lo_t, double kbits, const double (&x)[CPL], auto nt) {
-    const int slot = exponent_slot(lo_t, W);
+  auto store_row_k = [&](size_t rt, const KSlot& ks, double kbits, const double (&x)[CPL], auto nt) {
     double y[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) y[j] = x[j];
-    if (__builtin_expect(slot % CPL == CPL - 1, 1)) {
-      y[CPL - 1] = (lane == slot / CPL) ? kbits : x[CPL - 1];
+    if (__builtin_expect(ks.lane >= 0, 1)) {
+      y[CPL - 1] = (lane == ks.lane) ? kbits : x[CPL - 1];
     } else {  // very wide bands only
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) y[j] = (lane * CPL + j == slot) ? kbits : x[j];
+      for (int j = 0; j < CPL; ++j) y[j] = (lane * CPL + j == ks.slot) ? kbits : x[j];
     }
     store_row_f64<decltype(nt)::value>(out + rt, lane, y);
   };
@@ -1204,7 +1215,8 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
       bE[j] = (n[j] == n_init) ? 1.0 : 0.0;
       bM[j] = 0.0;
     }
-    store_row_k(rT1, lo, 0.0, bE, std::false_type{});
+    kslot = kslot_of(lo, W);
+    store_row_k(rT1, kslot, 0.0, bE, std::false_type{});
     store_row_f64<false>(out + rT, lane, bM);  // all zero: rows past the lattice, streamed by the ring's tail
   }
 
@@ -1242,6 +1254,7 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
           }
         }
         lo = new_lo;
+        kslot = kslot_of(lo, W);
       }
 #pragma unroll
       for (int j = 0; j < CPL; ++j) bE_out[j] = dynmath::fma_(Yr[j], m1, bM_out[j] * e2);
@@ -1261,7 +1274,7 @@ __device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const W
         K += k;
       }
       const size_t rt = (size_t)cur.at(w, t) * P;
-      store_row_k(rt, lo, K, bE_out, std::true_type{});
+      store_row_k(rt, kslot, K, bE_out, std::true_type{});
     };
     int i = 63;
 #pragma unroll 1
@@ -1312,6 +1325,7 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
   EmisV<CPL> p;
   double awsum = 0.0;
   double K = 0.0;
+  KSlot kslot = kslot_of(lo, W);
   const double x0 = sg[0];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
@@ -1329,7 +1343,7 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
 
   auto row = [&](auto rescale, int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
     double fEl[CPL], bcur[CPL], x1[CPL], q[CPL];
-    const int lo_t = lo;  // the band of row t (the exponent's slot is defined by it)
+    const KSlot ks_t = kslot;  // of the band of row t
     const int next_lo = band_mid(t + 1, ratio) - bw;
     K += ks_pending;
 #pragma unroll
@@ -1360,19 +1374,23 @@ __device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const Wa
         if (nj == lo + W) set_emis_lin(p, j, entering);
       }
       lo = next_lo;
+      kslot = kslot_of(lo, W);
     }
     ks_pending = emission_prob_vec(xn, p, pe, etab);  // P(t+1, .)
     // B(t, .) and its exponent from the ring; the slot is then refilled with row t + RING_D
     wait_vmcnt<RING_WAIT>();
     const unsigned slot_addr = ring_base + (t % RING_D) * ROW_BYTES;
     ring_read_row(slot_addr, lane, bcur);
-    double kb_d;
-    {
-      const unsigned kaddr = slot_addr + (unsigned)row_pos(exponent_slot(lo_t, W)) * 8u;
+    double Kb;  // the row's exponent: register CPL-1 of one lane of the row just read
+    if (__builtin_expect(ks_t.lane >= 0, 1)) {
+      Kb = readlane_f64(bcur[CPL - 1], ks_t.lane);
+    } else {
+      double kb_d;
+      const unsigned kaddr = slot_addr + (unsigned)row_pos(ks_t.slot) * 8u;
       asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kb_d) : "v"(kaddr) : "memory");
+      Kb = readlane_f64(kb_d, 0);
     }
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, slot_addr);
-    const double Kb = readlane_f64(kb_d, 0);
     // posteriors: fE x B / Z = fE^ x (B^ / zhat) x 2^(K + Kb - Kb0); with both rows parked near 2^950 the power of two
     // alone is ~2^-950 and B^ / zhat ~ 1: the quotient first, then the exponent, per cell
     const int ex = max(-4000, min(4000, (int)((K - Kb0) + Kb)));  // (the conversion saturates)
