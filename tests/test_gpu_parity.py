@@ -134,6 +134,41 @@ def test_random_reads_against_oracle(models, pore, nb):
         assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
 
 
+@pytest.mark.parametrize("pore,nb", [("rna002", (60, 400)), ("rna004", (150, 700)), ("dna_r10_400bps", (300, 700))])
+def test_models_with_a_stdev_per_kmer(models, tmp_path, pore, nb):
+    """The seeded synthetic models give every k-mer the same stdev; real ones do not (rna004: 0.05 .. 0.5). A model with
+    log-normal stdevs over a factor of 25 -- different 1/stdev, log stdev and density constant in every cell of a
+    lane -- through align(calc=true) and train() against the oracle."""
+    pid, rna, k = synth.PORES[pore]
+    rng = np.random.default_rng(2025 + k)
+    mean = rng.standard_normal(4 ** k)
+    sd = np.clip(0.15 * np.exp(0.6 * rng.standard_normal(4 ** k)), 0.03, 0.75)
+    path = synth.write_model_values(str(tmp_path / "varsd.model"), k, mean, sd)
+    reads = synth.make_reads(77 + k, 10, pore, mean, sd, nb)
+    al = Aligner(path, pore, device=0)
+    orc = Oracle(path, pid)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    tr = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
+    for i, r in enumerate(reads):
+        want, got = orc.align(r.signal, r.sequence, True), res.read(i)
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), i
+        assert np.array_equal(got["signal_positions"], want["signal_positions"]), i
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT, i
+        assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"])), i
+        wt = orc.train(r.signal, r.sequence)
+        assert tr.status[i] == 0 and abs(tr.Z[i] - wt["Z"]) <= 1e-9 * max(1.0, abs(wt["Z"])), i
+        assert abs(tr.transitions[3 * i] - wt["m1"]) <= 1e-8 and abs(tr.transitions[3 * i + 2] - wt["e2"]) <= 1e-8, i
+        code, m, sdev = tr.sparse(i)
+        touched = np.nonzero(wt["weight"] > 0)[0]
+        assert np.array_equal(code, touched), i
+        a = int(tr.em_offsets[i])
+        assert np.allclose(tr.em_weight[a:a + len(code)], wt["weight"][touched], rtol=1e-7, atol=1e-12), i
+        heavy = wt["weight"][touched] > 1e-3
+        assert np.abs(m[heavy] - wt["mean"][touched][heavy]).max() <= 1e-7, i
+        assert np.abs(sdev[heavy] - wt["stdev"][touched][heavy]).max() <= 1e-6, i
+    al.close()
+
+
 @pytest.mark.parametrize("pore,band,dwell", [("rna004", 400, 0.5), ("dna_r9", 400, 2.5), ("rna004", 100, 0.5),
                                              ("dna_r10_260bps", 446, 3.0), ("rna002", 30, 1.0)])
 def test_dense_reads_moving_window(models, pore, band, dwell):
