@@ -261,7 +261,7 @@ def main():
             tm = t.timing()
             for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy"):
                 kern[key] += tm[key]
-            for key in ("launches", "cells", "lp_inplace", "reads_strict", "reads_log_redo"):
+            for key in ("launches", "cells", "lp_inplace", "reads_strict"):
                 launches[key] += tm[key]
             launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
             launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
@@ -381,7 +381,6 @@ def main():
             "reads_per_s": round(total_reads / elapsed, 1),
             "reads_ok_last_batch": ok,
             **({"strict_mode": args.strict, "strict_reads_per_step": launches["reads_strict"] / steps} if args.strict != "off" else {}),
-            **({"log_domain_redo_reads_per_step": launches["reads_log_redo"] / steps} if args.mode == "train" else {}),
             "kernel_ms_per_step": {k_: round(v / steps, 3) for k_, v in kern.items() if k_.startswith("ms_")},
             "kernel_resident_Msamp_s": round(resident["samples"] / resident["ms_total"] / 1e3, 3) if resident and resident["ms_total"] else None,
             "pipeline_efficiency": round((total_samples / n_gpus / elapsed / 1e6) / (resident["samples"] / resident["ms_total"] / 1e3), 4) if resident and resident["ms_total"] else None,

@@ -52,7 +52,7 @@ class DynTiming(C.Structure):
                 ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
                 ("launches", C.c_uint32), ("lp_inplace", C.c_uint32), ("pool_pages", C.c_uint32),
                 ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32),
-                ("reads_strict", C.c_uint32), ("reads_log_redo", C.c_uint32)]
+                ("reads_strict", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)

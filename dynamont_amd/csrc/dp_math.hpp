@@ -42,6 +42,15 @@ DYN_HD double max_hw(double a, double b) {
   return __builtin_fmax(a, b);
 #endif
 }
+DYN_HD double min_hw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return __builtin_fmin(a, b);
+#endif
+}
 
 // 1/x to ~1 ulp for x in [2, 4]: hardware seed + two Newton steps (same structure the compiler
 // uses for fp64 division, minus scaling/fixup that this range never needs).
@@ -335,102 +344,6 @@ DYN_HD void softplus_table_vec(double (&d)[M], double (&g)[M], const SoftplusNod
   log_plus_issue<M>(zero, d, L, tab);  // hi = 0 for d <= 0
   log_plus_finish<M>(L, g);
 }
-
-// log_plus_finish plus the logistic value sigma(d) = e^d / (1 + e^d) at the SAME argument d = lo - hi:
-// sigma is the first derivative of the softplus, so it is the derivative of the same polynomial,
-//   sigma(d_i + r) = s + (u r) ( 1 + r ( w/2 + r ( (1-6u)/6 + r w (1-12u)/24 ) ) )
-// (5 more operations; truncation <= |g6|/120 (1/256)^5 = 1.9e-15 u, relative to a value in (0, 1/2]).
-// exp(lo - logPlus(x, y)) = sigma and exp(hi - logPlus(x, y)) = 1 - sigma: the shares of the two
-// operands in the sum, which is what the training pass needs (nt_kernels.hip, forward_train_sweep) --
-// without an exponential. d <= -40 (and -inf, NaN) gives sigma = 0 exactly.
-template <int M>
-DYN_HD void log_plus_finish_sigma(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
-  double u[M], w[M], p[M], q[M], dp[M];
-  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
-  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
-#pragma unroll
-  for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) u[j] = L.s[j] * w[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], m10, c120);
-#pragma unroll
-  for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], m4, c24);
-#pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(q[j] * 5.0, L.r[j], p[j] * 4.0);   // (1-6u)/6 + r w (1-12u)/24
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(q[j], L.r[j], p[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], w[j] * 0.5);
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], w[j] * (1.0 / 6.0));
-#pragma unroll
-  for (int j = 0; j < M; ++j) dp[j] = fma_(dp[j], L.r[j], 1.0);
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], 0.5);
-#pragma unroll
-  for (int j = 0; j < M; ++j) u[j] = u[j] * L.r[j];
-#pragma unroll
-  for (int j = 0; j < M; ++j) sig[j] = fma_(dp[j], u[j], L.s[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], u[j], L.s[j]);
-#pragma unroll
-  for (int j = 0; j < M; ++j) out[j] = L.hi[j] + fma_(p[j], L.r[j], L.g0[j]);
-}
-
-// The training sweep's form of log_plus_finish_sigma: the share only has to be good to ~1e-11 relative (the statistics
-// it weights are compared at 1e-9), so sigma stops one degree earlier,
-//   sigma(d_i + r) = s + (u r) ( 1 + r ( w/2 + r (1-6u)/6 ) )        truncation <= |w (1-12u)| / 24 (1/256)^4 u = 1e-11 u,
-// two operations fewer per cell. logPlus itself is the full-accuracy polynomial (Zf goes through the same Z check).
-// Cells [J0, J1) only: the training sweep finishes the seven lookups of a lane in two groups, because the polynomial's
-// temporaries for all seven at once push the row past 256 VGPRs (hipcc then parks values in AGPRs: ~70 moves per row).
-template <int M, int J0, int J1>
-DYN_HD void log_plus_finish_sigma3(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
-  constexpr int K = J1 - J0;
-  double u[K], w[K], p[K], q[K], dp[K];
-  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
-  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
-#pragma unroll
-  for (int j = 0; j < K; ++j) w[j] = 1.0 - L.s[J0 + j];
-#pragma unroll
-  for (int j = 0; j < K; ++j) u[j] = L.s[J0 + j] * w[j];
-#pragma unroll
-  for (int j = 0; j < K; ++j) w[j] = w[j] - L.s[J0 + j];
-#pragma unroll
-  for (int j = 0; j < K; ++j) q[j] = fma_(u[j], m10, c120);
-#pragma unroll
-  for (int j = 0; j < K; ++j) q[j] = q[j] * w[j];
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(u[j], m4, c24);                           // (1 - 6u)/24
-#pragma unroll
-  for (int j = 0; j < K; ++j) dp[j] = fma_(p[j] * 4.0, L.r[J0 + j], w[j] * 0.5);    // w/2 + r (1-6u)/6
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(q[j], L.r[J0 + j], p[j]);
-#pragma unroll
-  for (int j = 0; j < K; ++j) dp[j] = fma_(dp[j], L.r[J0 + j], 1.0);
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], L.r[J0 + j], w[j] * (1.0 / 6.0));
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], L.r[J0 + j], 0.5);
-#pragma unroll
-  for (int j = 0; j < K; ++j) u[j] = u[j] * L.r[J0 + j];
-#pragma unroll
-  for (int j = 0; j < K; ++j) sig[J0 + j] = fma_(dp[j], u[j], L.s[J0 + j]);
-#pragma unroll
-  for (int j = 0; j < K; ++j) p[j] = fma_(p[j], u[j], L.s[J0 + j]);
-#pragma unroll
-  for (int j = 0; j < K; ++j) out[J0 + j] = L.hi[J0 + j] + fma_(p[j], L.r[J0 + j], L.g0[J0 + j]);
-}
-
-template <int M>
-DYN_HD void log_plus_finish_sigma3(const SoftplusLookup<M>& L, double (&out)[M], double (&sig)[M]) {
-  log_plus_finish_sigma3<M, 0, M>(L, out, sig);
-}
-
 
 // Structure-of-arrays emission constants of the M cells of a lane.
 template <int M>

@@ -1070,11 +1070,6 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   q.tr = dynk::TrainBuffers{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
   q.m1 = m.log_m1;
   q.e2 = m.log_e2;
-  q.m1_lin = std::exp(m.log_m1);
-  q.e2_lin = std::exp(m.log_e2);
-  q.lin_park = 950;
-  // tests: a low park leaves the linear-domain sweeps too little range, which sends reads through the log-domain redo
-  if (const char* f = std::getenv("DYN_LIN_PARK")) q.lin_park = std::min(950, std::max(-900, std::atoi(f)));
   q.sp_tab = a->d_sptab.as<dynmath::SoftplusNode>();
   q.z_fail_status = z_fail;
   const dynk::QueueJob qjob = job == DynJob::Train ? dynk::JOB_TRAIN
@@ -1130,7 +1125,6 @@ int collect_timing(dyn_batch* b) {
     a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
     return DYN_ERR_DEVICE;
   }
-  tm.reads_log_redo = b->h_stats.as<uint32_t>()[6];
   const uint64_t* s = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::QUEUE_STATS);
   const double life = (double)s[4];
   tm.ms_dp = ms01;

@@ -830,48 +830,33 @@ __device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward fused with the Baum-Welch statistics of runTraining / trainTransition.
-// Per lattice cell (t >= 1, n >= 1), with gamma_M = exp(LPM), gamma_E = exp(LPE):
-//   w[kmer] += gamma_M + gamma_E ; s1 += gamma*x ; s2 += gamma*x*x      NT_aligner_api.cpp:505-512
-// Transition expectations (:683,:690) are rewritten through the recursions they sum over:
-//   fE(t,n)+m1+e(t+1,n+1)+bM(t+1,n+1) = fM(t+1,n+1)+bM(t+1,n+1)  ->  sum exp(LPM) over cells
-//   fE(t,n)+e2+e(t+1,n)+bE(t+1,n)     = second logPlus operand of fE(t+1,n) + bE(t+1,n)
-// so both are plain sums of per-cell posteriors (linear domain, relative to Zb).
-//
-// ONE exponential per cell instead of three. fE(t,n) = logPlus(x1, op2) with x1 = fM(t-1,n) + e(t,n)
-// (arrival from M) and op2 = fE(t-1,n) + e(t,n) + e2 (arrival from E), and an M cell has exactly one
-// way on, M(t-1,n) -> E(t,n) with e1 = 1. The posterior mass of E(t,n) therefore splits into the two
-// arrivals in proportion to the two operands of that logPlus:
-//   exp(LPM(t-1,n))                  = gamma_E(t,n) * exp(x1  - fE(t,n))     [= exp(fM + bM - Zb), bM = bE(t,n)+e(t,n)]
-//   E->E transition posterior (t,n)  = gamma_E(t,n) * exp(op2 - fE(t,n))
-// and the two factors are sigma(d) and 1 - sigma(d), d = min - max of the operands: the logistic value
-// the softplus lookup yields for four extra FMAs (dp_math.hpp, log_plus_finish_sigma). gamma_M of row
-// t-1 is thus accumulated one row late, with the sample of row t-1; gamma_M(T-1, .) = 0 (no successor).
-// Only bE(t, .) is needed per row, streamed through the LDS-DMA ring like in forward_sweep.
-//
-// Column sums stay in registers while the column is in the band. Band edges as in forward_sweep (no
-// per-row masks); a slot that has been handed on keeps receiving zeros, so the sums of the column that
-// left are written out at the NEXT window move (or at the end), not in the row loop.
-// Returns Zf; the two transition sums go to tb.trans.
-// ---------------------------------------------------------------------------------------------
-// Round 3 (the sweep is issue-bound): fewer fp64 operations per cell and no register moves at the
-// loop's back edge --
-//  * fM, fE, e are updated IN PLACE, in an order in which every old value has had its last use before its successor is
-//    defined (x1 and op2 first, then the neighbour exchange, then fM; e after the lookups are issued; fE from the
-//    polynomial): the allocator keeps each in one register across iterations. Two full ping-pong sets (as in
-//    forward_sweep) were tried first: 350 registers, ~70 AGPR moves per row;
-//  * gamma_E(t,n) is carried ONE row: it pairs with the same sample as gamma_M of the same row, which is produced one
-//    row late (see above), so each cell adds w = gamma_E(t-1) + gamma_E(t) shareM = one FMA, then aw += w, a1 += w x,
-//    a2 += w x^2 (4 operations instead of 6); the row loop is unrolled by two for these seven values alone; the last
-//    row's gamma_E is added after the loop;
-//  * one transition sum per cell: with awsum = the sum of all column weights, sum gamma_M = awsum - sum gamma_E and the
-//    E->E mass = awsum - 2 sum gamma_M, formed when the column sums are written out;
-//  * sigma to degree 3 (log_plus_finish_sigma3), the exponential from the 2^(k/128) table with the scale assembled
-//    from bits (exp_table128_vec), the emission with its constant folded.
-__device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const WaveCtx& w,
-                                                      const double* __restrict__ sig, const Emis* __restrict__ par,
-                                                      const double* __restrict__ ws, TrainBuffers tb, double Z,
-                                                      double m1, double e2, const SoftplusNode* s_tab,
+// Forward sweep of train() as the POSTERIOR CHAIN (round 3). With the backward values B(t, .) of every cell stored, the
+// forward recursion need not carry forward probabilities at all: the posterior itself satisfies a first-order recursion
+//   gamma_E(t,n) = gamma_M(t-1,n) + gamma_E(t-1,n) s(t,n),        gamma_M(t,n) = gamma_E(t-1,n-1) (1 - s(t,n-1)),
+//   s(t,n) = P(stay | E(t-1,n), whole signal) = exp( e2 + e(t,n) + bE(t,n) - bE(t-1,n) )
+// because bE(t-1,n) = logPlus(move, stay) (NT_aligner_api.cpp:191-203) makes the two ways on from an E cell sum to 1,
+// and an M cell has exactly one way on (e1 = 1, :200). Every quantity is a probability in [0, 1]: no scaling, no
+// underflow that matters (a posterior below 1e-308 is 0), whatever the read -- the forward-backward product in the
+// linear domain, tried first, needs e^(several thousand) of range WITHIN a row as soon as the basecalls disagree with
+// the signal (profiles/r03/linear_domain_on_imperfect_reads.txt). ONE exponential per cell (the reference: three exp
+// and two log1p), no logPlus, no Z in the loop; every row's posteriors sum to 1 by construction.
+// What it gives up: a forward value of Z. The reference's check |Zf - Zb| / size <= 1e-8 compares two roundings of the
+// same number; here the backward value is THE Z and the check is that the chain delivers all its mass to the end cell
+// (T-1, N-1) -- which fails exactly when the backward values are not those of a consistent lattice (inf/NaN samples).
+// Statistics as in NT_aligner_api.cpp:462-561; the transition expectations (:641-725) are the same for every path
+// (N-1 moves, T-1-2(N-1) extensions) and written as such.
+__device__ __forceinline__ void set_emis_chain(EmisV<CPL>& p, int j, const Emis& e, double e2) {
+  // ln P(x) + e2 = (ln K + e2) - u^2, u = x c - mu c, c = 1/(stdev sqrt 2): two fused operations per cell
+  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: -inf
+  const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;
+  p.inv_stdev[j] = none ? 0.0 : c;
+  p.mean[j] = none ? 0.0 : e.mean * c;
+  p.neg_log_stdev[j] = none ? NEG_INF : (e.neg_log_stdev - dynmath::HALF_LOG_2PI) + e2;
+}
+
+__device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
+                                                      const Emis* __restrict__ par, const double* __restrict__ ws,
+                                                      TrainBuffers tb, double Zb, double e2, const SoftplusNode* s_tab,
                                                       unsigned ring_base) {
   const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
@@ -885,32 +870,61 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
   RowCursor cur_dma;
 
   int lo = band_mid(1, ratio) - bw;  // band of row 1
-  double fM[CPL], fE[CPL], e[CPL];
-  double gEa[CPL], gEb[CPL];  // gamma_E of the previous row / of this row, roles alternating
+  double gE[CPL], gM[CPL];            // posteriors of the previous row, updated in place
+  double bA[CPL], bB[CPL];            // bE of the previous / of this row, roles alternating
   double aw[CPL], a1[CPL], a2[CPL];
   EmisV<CPL> p;
-  double sumE = 0.0, awsum = 0.0;
-  const double x0 = sg[0];
+  double awsum = 0.0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int nj = lo + pmod(lane * CPL + j - lo);
-    set_emis<ARITH_FOLDED>(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0));
-    fE[j] = (nj == 0) ? 0.0 : NEG_INF;
-    fM[j] = NEG_INF;
-    gEa[j] = 0.0;
+    set_emis_chain(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0), e2);
+    gE[j] = (nj == 0) ? 1.0 : 0.0;  // all mass in E(0, 0)
+    gM[j] = 0.0;
     aw[j] = a1[j] = a2[j] = 0.0;
   }
-  emission_vec<ARITH_FOLDED>(x0, p, e);  // e(1, n)
-  // ring prologue: rows 1 .. RING_D (row r lives in ring slot r % RING_D); rows past T repeat the -inf row T
+  // ring: rows 0 .. RING_D-1, row 0 into registers, then row RING_D (row r lives in ring slot r % RING_D; rows past T
+  // repeat the all -inf row T)
   const double* __restrict__ dma_src = ws + lane * 2;
-  for (int r = 1; r <= RING_D; ++r)
+  for (int r = 0; r < RING_D; ++r)
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
+  wait_vmcnt<RING_WAIT>();
+  ring_read_row(ring_base, lane, bA);
+  ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(RING_D, T)) * P, ring_base);
 
-  // one lattice row t; xp = sample of row t-1, xn = sample of row t+1; g_prev = gamma_E(t-1, .), g_out = gamma_E(t, .)
-  auto row = [&](int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
-    double fEl[CPL], bcur[CPL], x1[CPL], op2[CPL], sgm[CPL], aE[CPL];
-    bool m_smaller[CPL];  // the arrival from M is the smaller operand of the logPlus (kept as lane masks, not as values)
-    // a slot holds column lo + (slot - lo) mod P: recomputed in the rare block below instead of carried in 7 registers
+  const double one = dynmath::vreg_const(1.0);
+  // one lattice row t; x = the sample the row scores (sig[t-1]); b_prev = bE(t-1, .), b_out = bE(t, .)
+  auto row = [&](int t, double x, const double (&b_prev)[CPL], double (&b_out)[CPL]) {
+    double c[CPL], sp[CPL], st[CPL], mv[CPL], mvl[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) c[j] = dynmath::fma_(x, p.inv_stdev[j], -p.mean[j]);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) c[j] = dynmath::fma_(-c[j], c[j], p.neg_log_stdev[j]);  // e2 + e(t, n)
+    wait_vmcnt<RING_WAIT>();
+    ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, b_out);
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) c[j] = c[j] + (b_out[j] - b_prev[j]);  // (-inf) - (-inf): NaN, which the exponential maps to 0
+    dynmath::exp_table128_vec<CPL>(c, sp, etab);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) sp[j] = dynmath::min_hw(sp[j], one);  // the stay probability, <= 1 whatever the last bits say
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) st[j] = gE[j] * sp[j];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) mv[j] = gE[j] - st[j];
+    from_left(mv, mvl);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) gE[j] = gM[j] + st[j];
+    const double x2 = x * x;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      gM[j] = mvl[j];
+      const double wgt = gE[j] + mvl[j];
+      aw[j] += wgt;
+      a1[j] = dynmath::fma_(wgt, x, a1[j]);
+      a2[j] = dynmath::fma_(wgt, x2, a2[j]);
+    }
+    // the band of row t+1
     const int next_lo = band_mid(t + 1, ratio) - bw;
     if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
       const Emis none = load_emis(pr, 0, 0);
@@ -928,556 +942,63 @@ __device__ __forceinline__ double forward_train_sweep(const ReadDesc& rd, const 
           awsum += aw[j];
           aw[j] = a1[j] = a2[j] = 0.0;
         }
-        // column lo is in the band for the last time in this row (see forward_sweep): from the next row on its slot
-        // belongs to column lo + P; column lo + W enters the band with the next row
-        if (nj == lo) set_emis<ARITH_FOLDED>(p, j, none);
-        if (nj == lo + W) set_emis<ARITH_FOLDED>(p, j, entering);
+        // column lo is in the band for the last time in row t: from the next row on its slot belongs to column lo + P
+        // (no mass can be left there: its bE in row t+1 is -inf); column lo + W enters the band with the next row
+        if (nj == lo) set_emis_chain(p, j, none, e2);
+        if (nj == lo + W) set_emis_chain(p, j, entering, e2);
       }
       lo = next_lo;
     }
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) x1[j] = fM[j] + e[j];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) op2[j] = (fE[j] + e[j]) + e2;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) m_smaller[j] = op2[j] >= x1[j];
-    from_left(fE, fEl);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) fM[j] = (fEl[j] + e[j]) + m1;
-    SoftplusLookup<CPL> L;
-    log_plus_issue<CPL>(x1, op2, L, s_tab);
-    emission_vec<ARITH_FOLDED>(xn, p, e);
-    // the polynomial (and the exponential below) in two groups of cells: the temporaries of all seven at once push the
-    // row past 256 VGPRs and hipcc then parks values in AGPRs (~70 moves per row instead of ~50)
-    dynmath::log_plus_finish_sigma3<CPL, 0, 4>(L, fE, sgm);
-    __builtin_amdgcn_sched_barrier(0);
-    dynmath::log_plus_finish_sigma3<CPL, 4, CPL>(L, fE, sgm);
-    __builtin_amdgcn_sched_barrier(0);
-    // bE(t, .) from the ring, as late as possible (fewer live values through the lookup and the polynomial); its slot
-    // is then refilled with row t + RING_D
-    wait_vmcnt<RING_WAIT>();
-    ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, bcur);
-    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) aE[j] = (fE[j] + bcur[j]) - Z;
-    dynmath::exp_table128_vec<CPL, 0, 4>(aE, g_out, etab);
-    __builtin_amdgcn_sched_barrier(0);
-    dynmath::exp_table128_vec<CPL, 4, CPL>(aE, g_out, etab);
-    __builtin_amdgcn_sched_barrier(0);
-    const double xp2 = xp * xp;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      // sgm = share of the SMALLER operand; the arrival from M is x1. gamma_M(t-1,n) = gamma_E(t,n) * shareM, and cell
-      // (t-1,n) contributes gamma_E(t-1,n) + gamma_M(t-1,n) with the sample of row t-1
-      const double shareM = m_smaller[j] ? sgm[j] : 1.0 - sgm[j];
-      const double wgt = dynmath::fma_(g_out[j], shareM, g_prev[j]);
-      aw[j] += wgt;
-      a1[j] = dynmath::fma_(wgt, xp, a1[j]);
-      a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
-      sumE += g_out[j];
-    }
   };
 
-  double xt = x0, xp = 0.0;  // samples of rows t and t-1
   bool odd = false;
   for (int tb0 = 1; tb0 < T; tb0 += 64) {
-    const int idx = tb0 + lane;
-    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
+    const int idx = tb0 - 1 + lane;  // row t scores sample t - 1
+    const double xs = sg[min(idx, T - 2)];
     asm volatile("" ::"v"(xs));  // the load's wait belongs here, not into the row loop (see forward_sweep)
     const int iend = min(64, T - tb0);
     int i = 0;
 #pragma unroll 1
     for (; i + 1 < iend; i += 2) {
-      const double xa = readlane_f64(xs, i), xb = readlane_f64(xs, i + 1);
-      row(tb0 + i, xa, xp, gEa, gEb);
-      row(tb0 + i + 1, xb, xt, gEb, gEa);
-      xp = xa;
-      xt = xb;
+      row(tb0 + i, readlane_f64(xs, i), bA, bB);
+      row(tb0 + i + 1, readlane_f64(xs, i + 1), bB, bA);
     }
-    if (i < iend) {  // odd tail (last block of a read only): the roles of the two gamma_E sets stay swapped
-      const double xa = readlane_f64(xs, i);
-      row(tb0 + i, xa, xp, gEa, gEb);
-      xp = xt;
-      xt = xa;
+    if (i < iend) {  // odd tail (last block of a read only)
+      row(tb0 + i, readlane_f64(xs, i), bA, bB);
       odd = true;
     }
   }
+  (void)odd;
   wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
-  // gamma_E of the last row (xp now holds that row's sample; gamma_M(T-1, .) = 0: no successor)
-  {
-    const double xl2 = xp * xp;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const double g = odd ? gEb[j] : gEa[j];
-      aw[j] += g;
-      a1[j] = dynmath::fma_(g, xp, a1[j]);
-      a2[j] = dynmath::fma_(g, xl2, a2[j]);
-    }
-  }
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int nj = lo + pmod(lane * CPL + j - lo);
-    const int c = (nj == lo - 1 + P) ? lo - 1 : nj;  // the slot handed on at the last move still holds that column's sums
-    if (c >= 1 && c < N) {
-      cw[c - 1] = aw[j];
-      cs1[c - 1] = a1[j];
-      cs2[c - 1] = a2[j];
-    }
-    awsum += aw[j];
-  }
-  // wave reduction. Every cell's gamma_E and gamma_M are in awsum; gamma_E = (E->E mass) + gamma_M per cell, so
-  // sum gamma_M = awsum - sum gamma_E and the E->E mass = sum gamma_E - sum gamma_M
-  for (int off = 32; off >= 1; off >>= 1) {
-    sumE += __shfl_xor(sumE, off);
-    awsum += __shfl_xor(awsum, off);
-  }
-  if (lane == 0) {
-    const double sumM = awsum - sumE;
-    tb.trans[2 * rd.read] = sumM;
-    tb.trans[2 * rd.read + 1] = sumE - sumM;
-  }
-  const int nf = band_mid(T - 1, ratio);
-  const int sf = pmod(nf);
-  double zf = 0.0;
-#pragma unroll
-  for (int j = 0; j < CPL; ++j)
-    if (j == sf % CPL) zf = fE[j];
-  return readlane_f64(zf, sf / CPL);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Training in the LINEAR domain (round 3). No integer decision is taken in train(): its outputs are sums of
-// posteriors, compared with the reference at 1e-9. The forward-backward recursions therefore run on probabilities
-// instead of log-probabilities -- one multiply-add per transition instead of a 19-operation logPlus, posteriors as
-// products instead of exp(fE + bE - Z) -- with the classic remedy against underflow, applied exactly:
-//   * every stored or carried row is value x 2^K with an INTEGER exponent K per row (multiplying by a power of two is
-//     exact, so the arithmetic is that of the unscaled recursion wherever nothing underflows); a row is rescaled when
-//     its largest value leaves [2^-150, 2^150] (checked per row with lane-local maxima and one ballot each way);
-//   * the emission probability is K_n exp(-z^2/2) with the exponential of exp_table128_vec; when a sample is so far
-//     from EVERY k-mer of the band that all exponents are below -300 (garbage signal, spikes) the row's exponents are
-//     shifted by a multiple of ln 2 first and the shift joins the row's integer exponent -- ratios between cells stay
-//     exact down to e^-700 below the best cell, as far as any posterior matters;
-//   * Z = ln(value) + K ln 2, one logarithm per sweep.
-// The backward sweep stores B(t, .) at scale 2^Kb(t) and writes Kb(t) (as a double) into a band slot that is out of
-// band in row t, so that it reaches the forward sweep through the same LDS-DMA ring as the row itself.
-// Reference: NT_aligner_api.cpp:110-207 (recursions), :462-561 and :641-725 (statistics).
-// ---------------------------------------------------------------------------------------------
-constexpr double INV_SQRT_2PI = 0x1.9884533d43651p-2;  // 1/sqrt(2 pi)
-constexpr double LIN_MASS_TOL = 1e-8;  // |sum of weights / (T-1) - 1| the linear-domain sweeps must keep (they keep 1e-12)
-// The exponent of a stored row rides in a band slot that is OUT of the band in that row: the first slot above the band
-// whose register index is CPL-1, so that it travels in the row's own 8-byte store of register 6 (a separate store to an
-// address the row store also writes can overtake it: non-temporal and ordinary stores are not ordered with each other).
-__device__ __forceinline__ int exponent_slot(int lo, int W) {
-  const int s0 = pmod(lo + W);
-  int off = (CPL - 1) - (s0 % CPL);  // 0 .. CPL-1; P is a multiple of CPL, so slot % CPL survives the wrap
-  if (off >= P - W) off = 0;          // bands wider than P - CPL: any free slot (see store_exponent_row)
-  return pmod(lo + W + off);
-}
-
-// Constants of a column for the linear-domain emission: ln P(x) = ln K - u^2, u = x c - mu c with c = 1/(stdev sqrt 2)
-// -- two fused operations per cell (the subtraction, division-by-stdev, square, halving and the factor K of the
-// textbook form are five). mu c is rounded once, 1.6e-15 absolute in u for the models at hand; forward and backward
-// sweep use the same value, which is what the posteriors need.
-// Where the exponent of the row with band start lo lives: register CPL-1 of lane `lane` (the common case), or an
-// arbitrary slot (lane < 0; bands wider than P - CPL only). Recomputed when the band moves, not per row: the two
-// modulo operations are ~25 scalar instructions.
-struct KSlot {
-  int lane, slot;
-};
-__device__ __forceinline__ KSlot kslot_of(int lo, int W) {
-  const int s = exponent_slot(lo, W);
-  return KSlot{s % CPL == CPL - 1 ? s / CPL : -1, s};
-}
-
-__device__ __forceinline__ void set_emis_lin(EmisV<CPL>& p, int j, const Emis& e) {
-  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: u = -inf, probability 0
-  const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;  // / sqrt 2
-  p.inv_stdev[j] = none ? 0.0 : c;
-  p.mean[j] = none ? __builtin_huge_val() : e.mean * c;
-  p.neg_log_stdev[j] = none ? 0.0 : e.neg_log_stdev - 0x1.d67f1c864beb5p-1;  // ln K = -ln stdev - ln sqrt(2 pi)
-}
-
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-  return v;
-}
-
-__device__ __forceinline__ double pow2_f64(int k) { return __hiloint2double((1023 + k) << 20, 0); }  // |k| < 1023
-__device__ __forceinline__ int exponent_f64(double v) { return ((__double2hiint(v) >> 20) & 0x7ff) - 1023; }
-
-// P^(x; cell) = K_n exp(-z^2/2) 2^(-kshift) for the lane's cells; kshift (<= 0, wave-uniform) is 0 unless every cell of
-// the wave sits below e^-300. Exponents are kept as (integer-valued) doubles: one sample 4e4 standard deviations away
-// costs 2^-1.4e9, a read may hold a million of them, and the sum stays below 2^53.
-__device__ __forceinline__ double emission_prob_vec(double x, const EmisV<CPL>& p, double (&out)[CPL], const double* etab) {
-  double a[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(x, p.inv_stdev[j], -p.mean[j]);
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-a[j], a[j], p.neg_log_stdev[j]);
-  // guard: some cell above e^-300? (columns without a k-mer have the exponent -inf and do not count)
-  double best = a[0];
-#pragma unroll
-  for (int j = 1; j < CPL; ++j) best = dynmath::max_hw(best, a[j]);
-  double kshift = 0.0;
-  if (__builtin_expect(!__any(best > -300.0), 0)) {
-    const double amax = wave_max_f64(best);
-    if (!(amax > -1e9)) {  // a sample further out than that (or inf / NaN): the row is dead here, Z = -inf, and the
-#pragma unroll         // read is done again in the log domain, which answers as the reference does
-      for (int j = 0; j < CPL; ++j) out[j] = 0.0;
-      return 0.0;
-    }
-    {  // shift by a whole number of ln 2 (two-step, exact to ~1e-13)
-      const double kf = floor(amax * 0x1.71547652b82fep+0);
-      kshift = kf;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-kf, 0x1.62e42fee00000p-1, a[j]);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) a[j] = dynmath::fma_(-kf, 0x1.a39ef35793c76p-33, a[j]);
-    }
-  }
-  dynmath::exp_table128_vec<CPL>(a, out, etab);
-  return kshift;
-}
-
-// Rows are scaled by exact powers of two so that the largest value of a row is PARKED NEAR THE TOP of the fp64 range, in
-// 2^900 .. 2^1000: nothing in a row exceeds its maximum, so everything down to 2^-1074 -- e^1370 below the maximum --
-// stays representable. What this range has to cover is how far the forward (backward) value of the cell the path goes
-// through lies below the row's largest: more than e^350 for three of four cfg5 reads (park = -500 loses their mass),
-// under e^700 for all of them (park = 0 loses none). A read that needs more is caught by its weight sum and redone in
-// the log domain (k_read_queue). rescale_exponent() returns the exponent to divide the row by, 0 in the common case.
-struct LinPark {
-  double hi, lo;  // 2^(park + 50), 2^(park - 50): the row maximum stays between them
-  int park;
-  __device__ __forceinline__ explicit LinPark(int p) : hi(pow2_f64(p + 50)), lo(pow2_f64(p - 50)), park(p) {}
-};
-// The norm of a row is the largest of BOTH its vectors: at a level change the forward mass of a row sits in fM alone
-// (fE is 2^60 and more below it, and back up one row later), and nothing bounds bM / bE from above when e2 is small.
-__device__ __forceinline__ int rescale_exponent(const LinPark& lp, const double (&v)[CPL], const double (&u)[CPL]) {
-  double mx = dynmath::max_hw(v[0], u[0]);
-#pragma unroll
-  for (int j = 1; j < CPL; ++j) mx = dynmath::max_hw(mx, dynmath::max_hw(v[j], u[j]));
-  const bool too_big = __any(mx > lp.hi), none_big_enough = !__any(mx > lp.lo);
-  if (__builtin_expect(too_big || none_big_enough, 0)) {
-    const double m = wave_max_f64(mx);
-    if (m > 0.0 && m < __builtin_huge_val()) {
-      const int k = exponent_f64(m) - lp.park;  // the maximum lands in [2^park, 2^(park+1))
-      return k < -1000 ? -1000 : k;            // (a denormal maximum: one exact power of two at a time)
-    }
-  }
-  return 0;
-}
-
-// Backward sweep of train(), linear domain. B(t,n) = P(sig[t] | n) [ m1 BM'(t+1,n+1) + e2 BE(t+1,n) ] in the notation of
-// backward_sweep: BM(t,n) = BE(t+1,n) P(t+1,n); BE(t,n) = m1 BM(t+1,n+1) P(t+1,n+1) + e2 BM(t,n).
-// Returns ln Zb; *zhat / *Kb0 = the stored value and exponent of cell (0,0).
-__device__ __forceinline__ double backward_train_lin(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
-                                                     const Emis* __restrict__ par, double* __restrict__ ws, double m1, double e2,
-                                                     int park, const SoftplusNode* s_tab, double* zhat, double* Kb0) {
-  const LinPark lp(park);
-  const int lane = w.lane;
-  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
-  const double ratio = rd.ratio;
-  const double* __restrict__ sg = sig + rd.sig_off;
-  const Emis* __restrict__ pr = par + rd.par_off;
-  const double* __restrict__ etab = exp128_tab(s_tab);
-  double* __restrict__ out = ws;
-  RowCursor cur;
-
-  bool bad_sample = false;
-  int lo = band_mid(T - 1, ratio) - bw;
-  const int n_init = lo + bw;
-  int n[CPL];
-  double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], pe[CPL];
-  EmisV<CPL> p;
-  double K = 0.0, ks_pending = 0.0;
-  KSlot kslot{-1, 0};
-  // one row with its exponent in the exponent slot (the value that slot would carry is 0: out of band)
-  auto store_row_k = [&](size_t rt, const KSlot& ks, double kbits, const double (&x)[CPL], auto nt) {
-    double y[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) y[j] = x[j];
-    if (__builtin_expect(ks.lane >= 0, 1)) {
-      y[CPL - 1] = (lane == ks.lane) ? kbits : x[CPL - 1];
-    } else {  // very wide bands only
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) y[j] = (lane * CPL + j == ks.slot) ? kbits : x[j];
-    }
-    store_row_f64<decltype(nt)::value>(out + rt, lane, y);
-  };
-  {
-    const size_t rT = (size_t)cur.at(w, T) * P, rT1 = (size_t)cur.at(w, T - 1) * P;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const int slot = lane * CPL + j;
-      n[j] = lo + pmod(slot - lo);
-      set_emis_lin(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
-      bE[j] = (n[j] == n_init) ? 1.0 : 0.0;
-      bM[j] = 0.0;
-    }
-    kslot = kslot_of(lo, W);
-    store_row_k(rT1, kslot, 0.0, bE, std::false_type{});
-    store_row_f64<false>(out + rT, lane, bM);  // all zero: rows past the lattice, streamed by the ring's tail
-  }
-
-  for (int thi = T - 2; thi >= 0; thi -= 64) {
-    const int base = thi - 63;
-    const int idx = base + lane;
-    const double xs = (idx >= 0) ? sg[idx] : 0.0;
-    bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
-    const int ilo = base < 0 ? -base : 0;
-    ks_pending = emission_prob_vec(readlane_f64(xs, 63), p, pe, etab);  // P(thi+1, n) from sig[thi]
-    auto row = [&](auto rescale, int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
-      const int t = base + i;
-      double Y[CPL], Yr[CPL];
-      K += ks_pending;  // the emission factors of this row carry 2^ks
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) Y[j] = bM_in[j] * pe[j];
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) bM_out[j] = bE_in[j] * pe[j];
-      from_right(Y, Yr);
-      const int new_lo = band_mid(t, ratio) - bw;
-      if (__builtin_expect(new_lo != lo, 0)) {  // wave-uniform: the window moved down by one column (see backward_sweep)
-        const int leaving = lo + P - 1;
-        const int top = lo + W - 1;
-        const Emis fresh = load_emis(pr, new_lo, N);
-        const Emis none = load_emis(pr, 0, 0);
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          if (n[j] == leaving) {
-            n[j] = new_lo;
-            set_emis_lin(p, j, fresh);
-          }
-          if (n[j] == top) {
-            bM_out[j] = 0.0;
-            set_emis_lin(p, j, none);
-          }
-        }
-        lo = new_lo;
-        kslot = kslot_of(lo, W);
-      }
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) bE_out[j] = dynmath::fma_(Yr[j], m1, bM_out[j] * e2);
-      // emission factors of the NEXT row (sample t-1); at i == 0 the value computed here is thrown away (see backward_sweep)
-      ks_pending = emission_prob_vec(readlane_f64(xs, i > 0 ? i - 1 : 0), p, pe, etab);
-      // (every second row: two rows grow the values by at most K^2 (m1 + e2)^2, far inside the 2^24 between the top
-      // of the parking window and the end of the range; a row that overflows or collapses before its check loses mass
-      // and the read is redone. Every fourth row was measured too: no faster.)
-      const int k = decltype(rescale)::value ? rescale_exponent(lp, bE_out, bM_out) : 0;
-      if (__builtin_expect(k != 0, 0)) {
-        const double f = pow2_f64(-k);
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          bE_out[j] *= f;
-          bM_out[j] *= f;
-        }
-        K += k;
-      }
-      const size_t rt = (size_t)cur.at(w, t) * P;
-      store_row_k(rt, kslot, K, bE_out, std::true_type{});
-    };
-    int i = 63;
-#pragma unroll 1
-    for (; i - 1 >= ilo; i -= 2) {
-      row(std::false_type{}, i, bE, bM, bE2, bM2);
-      row(std::true_type{}, i - 1, bE2, bM2, bE, bM);
-    }
-    if (i >= ilo) {
-      row(std::true_type{}, i, bE, bM, bE2, bM2);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        bE[j] = bE2[j];
-        bM[j] = bM2[j];
-      }
-    }
-  }
-  const bool any_bad = __any(bad_sample);
-  const double z0 = readlane_f64(bE[0], 0);  // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
-  *zhat = z0;
-  *Kb0 = K;
-  return any_bad ? NEG_INF : log(z0) + (double)K * 0x1.62e42fefa39efp-1;
-}
-
-// Forward sweep of train() with the Baum-Welch statistics, linear domain (see forward_train_sweep for the statistics):
-//   fM(t,n) = fE(t-1,n-1) P(t,n) m1;  x1 = fM(t-1,n) P(t,n);  fE(t,n) = x1 + e2 fE(t-1,n) P(t,n)
-//   gamma_E(t,n) = fE(t,n) B(t,n) / Z;  gamma_M(t-1,n) = x1 B(t,n) / Z        (bM(t-1,n) = B(t,n) P(t,n))
-__device__ __forceinline__ double forward_train_lin(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
-                                                    const Emis* __restrict__ par, const double* __restrict__ ws, TrainBuffers tb,
-                                                    double zhat, double Kb0, double m1, double e2, int park,
-                                                    const SoftplusNode* s_tab, unsigned ring_base, double* total_weight) {
-  const LinPark lp(park);
-  const int lane = w.lane;
-  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
-  const double ratio = rd.ratio;
-  const double* __restrict__ sg = sig + rd.sig_off;
-  const Emis* __restrict__ pr = par + rd.par_off;
-  double* __restrict__ cw = tb.col_w + rd.par_off;
-  double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
-  double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
-  const double* __restrict__ etab = exp128_tab(s_tab);
-  RowCursor cur_dma;
-  const double inv_z = 1.0 / zhat;
-
-  int lo = band_mid(1, ratio) - bw;  // band of row 1
-  double fM[CPL], fE[CPL], pe[CPL];
-  double gEa[CPL], gEb[CPL];
-  double aw[CPL], a1[CPL], a2[CPL];
-  EmisV<CPL> p;
-  double awsum = 0.0;
-  double K = 0.0;
-  KSlot kslot = kslot_of(lo, W);
-  const double x0 = sg[0];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int nj = lo + pmod(lane * CPL + j - lo);
-    set_emis_lin(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0));
-    fE[j] = (nj == 0) ? 1.0 : 0.0;
-    fM[j] = 0.0;
-    gEa[j] = 0.0;
-    aw[j] = a1[j] = a2[j] = 0.0;
-  }
-  double ks_pending = emission_prob_vec(x0, p, pe, etab);  // P(1, n)
-  const double* __restrict__ dma_src = ws + lane * 2;
-  for (int r = 1; r <= RING_D; ++r)
-    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
-
-  auto row = [&](auto rescale, int t, double xn, double xp, const double (&g_prev)[CPL], double (&g_out)[CPL]) {
-    double fEl[CPL], bcur[CPL], x1[CPL], q[CPL];
-    const KSlot ks_t = kslot;  // of the band of row t
-    const int next_lo = band_mid(t + 1, ratio) - bw;
-    K += ks_pending;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) x1[j] = fM[j] * pe[j];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) q[j] = fE[j] * pe[j];
-    from_left(fE, fEl);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) fM[j] = (fEl[j] * pe[j]) * m1;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) fE[j] = dynmath::fma_(q[j], e2, x1[j]);
-    if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
-      const Emis none = load_emis(pr, 0, 0);
-      const Emis entering = load_emis(pr, lo + W, N);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int nj = lo + pmod(lane * CPL + j - lo);
-        if (nj == lo - 1 + P) {  // handed on at the PREVIOUS move: nothing but zeros since
-          if (lo - 1 >= 1 && lo - 1 < N) {
-            cw[lo - 2] = aw[j];
-            cs1[lo - 2] = a1[j];
-            cs2[lo - 2] = a2[j];
-          }
-          awsum += aw[j];
-          aw[j] = a1[j] = a2[j] = 0.0;
-        }
-        if (nj == lo) set_emis_lin(p, j, none);
-        if (nj == lo + W) set_emis_lin(p, j, entering);
-      }
-      lo = next_lo;
-      kslot = kslot_of(lo, W);
-    }
-    ks_pending = emission_prob_vec(xn, p, pe, etab);  // P(t+1, .)
-    // B(t, .) and its exponent from the ring; the slot is then refilled with row t + RING_D
-    wait_vmcnt<RING_WAIT>();
-    const unsigned slot_addr = ring_base + (t % RING_D) * ROW_BYTES;
-    ring_read_row(slot_addr, lane, bcur);
-    double Kb;  // the row's exponent: register CPL-1 of one lane of the row just read
-    if (__builtin_expect(ks_t.lane >= 0, 1)) {
-      Kb = readlane_f64(bcur[CPL - 1], ks_t.lane);
-    } else {
-      double kb_d;
-      const unsigned kaddr = slot_addr + (unsigned)row_pos(ks_t.slot) * 8u;
-      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kb_d) : "v"(kaddr) : "memory");
-      Kb = readlane_f64(kb_d, 0);
-    }
-    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, slot_addr);
-    // posteriors: fE x B / Z = fE^ x (B^ / zhat) x 2^(K + Kb - Kb0); with both rows parked near 2^950 the power of two
-    // alone is ~2^-950 and B^ / zhat ~ 1: the quotient first, then the exponent, per cell
-    const int ex = max(-4000, min(4000, (int)((K - Kb0) + Kb)));  // (the conversion saturates)
-    const double xp2 = xp * xp;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const double g = __builtin_amdgcn_ldexp(bcur[j] * inv_z, ex);
-      g_out[j] = fE[j] * g;                                       // gamma_E(t, n)
-      const double wgt = dynmath::fma_(x1[j], g, g_prev[j]);      // + gamma_M(t-1, n): both carry the sample of row t-1
-      aw[j] += wgt;
-      a1[j] = dynmath::fma_(wgt, xp, a1[j]);
-      a2[j] = dynmath::fma_(wgt, xp2, a2[j]);
-    }
-    const int k = decltype(rescale)::value ? rescale_exponent(lp, fE, fM) : 0;
-    if (__builtin_expect(k != 0, 0)) {
-      const double f = pow2_f64(-k);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        fE[j] *= f;
-        fM[j] *= f;
-      }
-      K += k;
-    }
-  };
-
-  double xt = x0, xp = 0.0;
-  bool odd = false;
-  for (int tb0 = 1; tb0 < T; tb0 += 64) {
-    const int idx = tb0 + lane;
-    const double xs = (idx < T - 1) ? sg[idx] : 0.0;
-    asm volatile("" ::"v"(xs));
-    const int iend = min(64, T - tb0);
-    int i = 0;
-#pragma unroll 1
-    for (; i + 1 < iend; i += 2) {
-      const double xa = readlane_f64(xs, i), xb = readlane_f64(xs, i + 1);
-      row(std::false_type{}, tb0 + i, xa, xp, gEa, gEb);
-      row(std::true_type{}, tb0 + i + 1, xb, xt, gEb, gEa);
-      xp = xa;
-      xt = xb;
-    }
-    if (i < iend) {
-      const double xa = readlane_f64(xs, i);
-      row(std::true_type{}, tb0 + i, xa, xp, gEa, gEb);
-      xp = xt;
-      xt = xa;
-      odd = true;
-    }
-  }
-  wait_vmcnt<0>();
-  {
-    const double xl2 = xp * xp;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      const double g = odd ? gEb[j] : gEa[j];
-      aw[j] += g;
-      a1[j] = dynmath::fma_(g, xp, a1[j]);
-      a2[j] = dynmath::fma_(g, xl2, a2[j]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    const int nj = lo + pmod(lane * CPL + j - lo);
-    const int c = (nj == lo - 1 + P) ? lo - 1 : nj;
-    if (c >= 1 && c < N) {
-      cw[c - 1] = aw[j];
-      cs1[c - 1] = a1[j];
-      cs2[c - 1] = a2[j];
+    const int cidx = (nj == lo - 1 + P) ? lo - 1 : nj;  // the slot handed on at the last move still holds that column's sums
+    if (cidx >= 1 && cidx < N) {
+      cw[cidx - 1] = aw[j];
+      cs1[cidx - 1] = a1[j];
+      cs2[cidx - 1] = a2[j];
     }
     awsum += aw[j];
   }
   for (int off = 32; off >= 1; off >>= 1) awsum += __shfl_xor(awsum, off);
   // expected transition counts: EVERY path from (0,0) to (T-1,N-1) takes N-1 moves E->M, each followed by the forced
-  // M->E, and spends its other T-1 - 2(N-1) steps on E->E -- the expectations are these constants whatever the
-  // posteriors are (the log-domain sweep sums them and lands within 1e-9 of the same numbers)
+  // M->E, and spends its other T-1 - 2(N-1) steps on E->E
   if (lane == 0) {
     tb.trans[2 * rd.read] = (double)(N - 1);
     tb.trans[2 * rd.read + 1] = (double)(T - 1) - 2.0 * (double)(N - 1);
   }
-  *total_weight = awsum;
+  // all of the mass must have arrived in E(T-1, N-1), and every sample must have carried weight 1
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);
-  double zf = 0.0;
+  double gf = 0.0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j)
-    if (j == sf % CPL) zf = fE[j];
-  return log(readlane_f64(zf, sf / CPL)) + (double)K * 0x1.62e42fefa39efp-1;
+    if (j == sf % CPL) gf = gE[j];
+  gf = readlane_f64(gf, sf / CPL);
+  const double S = (double)(T - 1);
+  const bool ok = fabs(gf - 1.0) <= 1e-6 && fabs(awsum - S) <= 1e-6 * S;  // (NaN fails)
+  return ok ? Zb : NEG_INF;
 }
 
 // ---- read queue and page pool -------------------------------------------------------------------------
@@ -1495,7 +1016,7 @@ __device__ __forceinline__ void ctl_store(uint32_t* p, uint32_t v) {
 // Every wait below is bounded: a wave that has waited for seconds (a lost lock, a page count that never
 // recovers) raises the abort word, which drains the queue -- the grid always terminates, and the host
 // reports the launch as failed instead of hanging the device.
-constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5, CTL_LOG_REDO = 6;
+constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5;
 constexpr int LOCK_SPINS_MAX = 1 << 24;   // x ~0.3 us
 constexpr int PAGE_WAITS_MAX = 1 << 18;   // x ~30 us
 
@@ -1688,31 +1209,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
     } else {
       if constexpr (JOB == JOB_TRAIN) {
-#ifndef DYN_TRAIN_LOG_DOMAIN
-        // linear domain first. Its one weakness is the range of fp64 WITHIN a row (e^1300 below the row's largest value):
-        // a row whose path cell lies further down loses posterior mass, and the loss shows -- every signal sample carries
-        // total weight 1, so the weights of the read sum to T - 1, and Z agrees both ways. A read that fails either check
-        // is done again in the log domain, which has no such limit (and decides whether Z really disagrees).
-        double lin_zhat = 0.0, total = 0.0, lin_Kb0 = 0.0;
-        Zb = backward_train_lin(rd, w, sig, par, q.pool.ws, q.m1_lin, q.e2_lin, q.lin_park, s_tab, &lin_zhat, &lin_Kb0);
-        t2 = __builtin_amdgcn_s_memtime();
-        Zf = forward_train_lin(rd, w, sig, par, q.pool.ws, q.tr, lin_zhat, lin_Kb0, q.m1_lin, q.e2_lin, q.lin_park, s_tab, ring_base, &total);
-        const double S = (double)(rd.T - 1);
-        const bool lin_ok = z_ok(rd, Zf, Zb) && fabs(total - S) <= LIN_MASS_TOL * S;  // (NaN fails)
-#ifndef DYN_TRAIN_NO_FALLBACK
-        if (__builtin_expect(!lin_ok, 0)) {
-          Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
-          Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
-          if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_LOG_REDO], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#else
-        if (!lin_ok) Zf = NEG_INF;
-#endif
-#else
+        // backward sweep in the log domain (the emission's constant folded), then the posterior chain
         Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
-        Zf = forward_train_sweep(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.m1, q.e2, s_tab, ring_base);
-#endif
+        Zf = forward_train_chain(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.e2, s_tab, ring_base);
       } else {
         Zb = backward_sweep<LATTICE, ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();

@@ -88,7 +88,7 @@ struct PagePool {
   uint32_t* free_list;  // stack of free page numbers
   // ctl (32-bit words): [0] lock of the free-page stack, [1] queue head (next read), [2] free pages on the
   // stack, [3] abort (a wave gave up waiting: the queue drains, the host reports the launch as failed),
-  // [4] reads whose pages are in place, [5] waves waiting for pages, [6] training reads redone in the log domain.
+  // [4] reads whose pages are in place, [5] waves waiting for pages.
   // ctl + QUEUE_STATS (64-bit words): wave-cycles spent in backward, forward, traceback, waiting for pages,
   // lifetime (all summed over the waves of the launch), longest lifetime.
   uint32_t* ctl;
@@ -112,8 +112,6 @@ struct QueueArgs {
   TraceBuffers tb;
   TrainBuffers tr;
   double m1, e2;          // log transition probabilities (NT_aligner_api.cpp:84-86)
-  double m1_lin, e2_lin;  // the probabilities themselves (linear-domain training sweeps)
-  int lin_park;           // log2 of where those sweeps keep the row maximum (950; DYN_LIN_PARK lowers it for tests)
   const dynmath::SoftplusNode* sp_tab;
   int z_fail_status;
 };

@@ -163,7 +163,7 @@ typedef struct dyn_timing {
   uint32_t n_static;     /* reads whose pages were reserved by the host (first round) */
   uint32_t n_waves;      /* persistent waves launched */
   uint32_t reads_strict; /* reads that went through the strict kernels (dyn_aligner_set_strict) */
-  uint32_t reads_log_redo; /* training reads whose linear-domain sweeps lost range and were redone in the log domain */
+  uint32_t reserved;
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,

@@ -31,16 +31,6 @@ void eval_logplus_table(const double* x, const double* y, double* out, long n) {
   }
 }
 // logPlus + the logistic share sigma(lo - hi) from the same table lookup (training pass)
-void eval_logplus_sigma(const double* x, const double* y, double* out, double* sig, long n) {
-  for (long i = 0; i + 7 <= n; i += 7) {
-    double a[7], b[7], o[7], s[7];
-    for (int j = 0; j < 7; ++j) { a[j] = x[i + j]; b[j] = y[i + j]; }
-    dynmath::SoftplusLookup<7> L;
-    dynmath::log_plus_issue<7>(a, b, L, TAB.data());
-    dynmath::log_plus_finish_sigma<7>(L, o, s);
-    for (int j = 0; j < 7; ++j) { out[i + j] = o[j]; sig[i + j] = s[j]; }
-  }
-}
 void eval_softplus_table(const double* d, double* out, long n) {
   for (long i = 0; i + 7 <= n; i += 7) {
     double a[7], g[7];
@@ -197,34 +187,6 @@ def test_table_logplus_special_values_and_oracle(mathlib, oracle_built):
     ref = np.array([L.nto_log_plus(p, q) for p, q in zip(a, b)])
     assert np.abs(o - ref).max() <= 2 * np.spacing(np.abs(ref)).max()
     assert np.mean(o == ref) > 0.95
-
-
-def test_logplus_sigma_share(mathlib):
-    """log_plus_finish_sigma: same logPlus as log_plus_finish, plus sigma = exp(lo - logPlus) to ~1e-15
-    relative (it replaces two of the three exponentials per cell of the training pass)."""
-    rng = np.random.default_rng(6)
-    x = rng.uniform(-3000, 50, 7000)
-    y = x + np.concatenate([rng.uniform(-45, 45, 6000), rng.standard_normal(1000) * 1e-3])
-    out, sig, ref = np.empty_like(x), np.empty_like(x), np.empty_like(x)
-    mathlib.eval_logplus_sigma(x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp), sig.ctypes.data_as(dp), C.c_long(len(x)))
-    mathlib.eval_logplus_table(x.ctypes.data_as(dp), y.ctypes.data_as(dp), ref.ctypes.data_as(dp), C.c_long(len(x)))
-    assert np.array_equal(out, ref)
-    mp.mp.dps = 40
-    worst = 0.0
-    for a, b, s in zip(x, y, sig):
-        d = mp.mpf(float(min(a, b))) - mp.mpf(float(max(a, b)))
-        t = mp.exp(d) / (1 + mp.exp(d))
-        if d > -40:
-            worst = max(worst, float(abs(mp.mpf(float(s)) - t) / t))
-        else:
-            assert s == 0.0
-    assert worst < 2e-14, worst
-    inf = np.inf
-    xs = np.array([-inf, 3.0, -inf, -5.0, 0.0, -2000.0, 7.0])
-    ys = np.array([-inf, -inf, -7.5, -5.0, -41.0, 2000.0, 7.0])
-    o7, s7 = np.empty(7), np.empty(7)
-    mathlib.eval_logplus_sigma(xs.ctypes.data_as(dp), ys.ctypes.data_as(dp), o7.ctypes.data_as(dp), s7.ctypes.data_as(dp), C.c_long(7))
-    assert list(s7[:3]) == [0.0, 0.0, 0.0] and s7[3] == 0.5 and s7[4] == 0.0 and s7[5] == 0.0 and s7[6] == 0.5
 
 
 def test_exp_table128_vec_accuracy_and_exact_zero(mathlib):
