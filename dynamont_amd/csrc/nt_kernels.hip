@@ -419,7 +419,8 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
         emission_vec<ARITH>(xnext, p, e);
       }
-      if constexpr (ARITH != ARITH_STRICT) log_plus_finish<CPL>(L, bE_out);
+      if constexpr (ARITH == ARITH_FOLDED) dynmath::log_plus_finish3<CPL>(L, bE_out);  // train(): no decision hangs on it
+      else if constexpr (ARITH != ARITH_STRICT) log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
       // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
       if (STORE) store_row_f64<true>(out + rt, lane, bE_out);
