@@ -177,16 +177,21 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
 //  ARITH_DEFAULT  dp_math.hpp: 5-operation emission, table softplus (<= 1 ulp from glibc)
 //  ARITH_STRICT   dp_math_strict.hpp: the reference's expressions operation by operation, glibc's exp / log1p bit for
 //                 bit; the slot that normally carries 1/stdev then carries stdev itself (true IEEE division)
-//  ARITH_FOLDED   training only: -0.5 log 2pi folded into the per-slot constant (4 operations instead of 5). The sums of
-//                 the training pass are compared at 1e-9 and its Z values go through the 1e-8-per-cell check; no integer
-//                 decision hangs on the last bit there, unlike in the align sweeps
+//  ARITH_FOLDED   train() only (its backward sweep; the forward sweep is the posterior chain): emission ln K - u^2 in two
+//                 fused operations, softplus polynomial of degree 3. No integer decision hangs on the last bits there,
+//                 unlike in the align sweeps: train()'s outputs are sums of posteriors
 constexpr int ARITH_DEFAULT = 0, ARITH_STRICT = 1, ARITH_FOLDED = 2;
 
 template <int ARITH>
 __device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
   p.set(j, e);
   if (ARITH == ARITH_STRICT) p.inv_stdev[j] = e.stdev;
-  if (ARITH == ARITH_FOLDED) p.neg_log_stdev[j] = e.neg_log_stdev - dynmath::HALF_LOG_2PI;
+  if (ARITH == ARITH_FOLDED) {  // train(): ln P = ln K - u^2, u = x c - mu c, c = 1/(stdev sqrt 2) -- two fused operations
+    const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;
+    p.inv_stdev[j] = c;
+    p.mean[j] = e.mean * c;
+    p.neg_log_stdev[j] = e.neg_log_stdev - dynmath::HALF_LOG_2PI;
+  }
 }
 
 template <int ARITH>
@@ -194,15 +199,11 @@ __device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, doub
   if constexpr (ARITH == ARITH_STRICT) {
     dynmath::log_normal_pdf_strict_vec<CPL>(x, p, out);
   } else if constexpr (ARITH == ARITH_FOLDED) {
-    double z[CPL];
+    double u[CPL];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) z[j] = x - p.mean[j];
+    for (int j = 0; j < CPL; ++j) u[j] = dynmath::fma_(x, p.inv_stdev[j], -p.mean[j]);
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) z[j] = z[j] * p.inv_stdev[j];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) z[j] = z[j] * z[j];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) out[j] = dynmath::fma_(z[j], -0.5, p.neg_log_stdev[j]);
+    for (int j = 0; j < CPL; ++j) out[j] = dynmath::fma_(-u[j], u[j], p.neg_log_stdev[j]);
   } else {
     log_normal_pdf_vec<CPL>(x, p, out);
   }
@@ -847,12 +848,8 @@ __device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, cons
 // Statistics as in NT_aligner_api.cpp:462-561; the transition expectations (:641-725) are the same for every path
 // (N-1 moves, T-1-2(N-1) extensions) and written as such.
 __device__ __forceinline__ void set_emis_chain(EmisV<CPL>& p, int j, const Emis& e, double e2) {
-  // ln P(x) + e2 = (ln K + e2) - u^2, u = x c - mu c, c = 1/(stdev sqrt 2): two fused operations per cell
-  const bool none = e.neg_log_stdev == NEG_INF;  // column without a k-mer: -inf
-  const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;
-  p.inv_stdev[j] = none ? 0.0 : c;
-  p.mean[j] = none ? 0.0 : e.mean * c;
-  p.neg_log_stdev[j] = none ? NEG_INF : (e.neg_log_stdev - dynmath::HALF_LOG_2PI) + e2;
+  set_emis<ARITH_FOLDED>(p, j, e);  // the backward sweep's constants: both sweeps score a cell with the same bits
+  p.neg_log_stdev[j] += e2;         // (-inf for a column without a k-mer)
 }
 
 __device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
