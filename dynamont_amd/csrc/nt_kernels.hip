@@ -424,7 +424,17 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       else if constexpr (ARITH != ARITH_STRICT) log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
       // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
-      if (STORE) store_row_f64<true>(out + rt, lane, bE_out);
+      if constexpr (STORE && ARITH == ARITH_FOLDED) {
+        // train(): what its forward sweep (the posterior chain) needs of row t is ln P(stay | E(t,n)) = the stay operand
+        // of the logPlus minus its result -- stored instead of bE, so that the chain reads a row and takes its
+        // exponential ((-inf) - (-inf) = NaN for a cell nothing can reach: exponential 0)
+        double ls[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) ls[j] = x2[j] - bE_out[j];
+        store_row_f64<true>(out + rt, lane, ls);
+      } else if (STORE) {
+        store_row_f64<true>(out + rt, lane, bE_out);
+      }
     };
     int i = 63;
 #pragma unroll 1
@@ -832,35 +842,30 @@ __device__ __forceinline__ void mpost(const ReadDesc& rd, const WaveCtx& w, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward sweep of train() as the POSTERIOR CHAIN (round 3). With the backward values B(t, .) of every cell stored, the
+// Forward sweep of train() as the POSTERIOR CHAIN (round 3). With the backward values B(t, .) of every cell known, the
 // forward recursion need not carry forward probabilities at all: the posterior itself satisfies a first-order recursion
 //   gamma_E(t,n) = gamma_M(t-1,n) + gamma_E(t-1,n) s(t,n),        gamma_M(t,n) = gamma_E(t-1,n-1) (1 - s(t,n-1)),
 //   s(t,n) = P(stay | E(t-1,n), whole signal) = exp( e2 + e(t,n) + bE(t,n) - bE(t-1,n) )
 // because bE(t-1,n) = logPlus(move, stay) (NT_aligner_api.cpp:191-203) makes the two ways on from an E cell sum to 1,
-// and an M cell has exactly one way on (e1 = 1, :200). Every quantity is a probability in [0, 1]: no scaling, no
-// underflow that matters (a posterior below 1e-308 is 0), whatever the read -- the forward-backward product in the
-// linear domain, tried first, needs e^(several thousand) of range WITHIN a row as soon as the basecalls disagree with
-// the signal (profiles/r03/linear_domain_on_imperfect_reads.txt). ONE exponential per cell (the reference: three exp
-// and two log1p), no logPlus, no Z in the loop; every row's posteriors sum to 1 by construction.
+// and an M cell has exactly one way on (e1 = 1, :200). The exponent is the stay operand of that logPlus minus its
+// result: the backward sweep has both in registers and stores THE DIFFERENCE as row t-1 of the lattice (8 bytes per
+// cell, as bE would be). The chain reads a row, takes one exponential per cell and moves mass: every quantity is a
+// probability in [0, 1], every row sums to 1 by construction, nothing is scaled and nothing can run out of range,
+// whatever the read -- the forward-backward product in the linear domain, tried first, needs e^(several thousand) of
+// range WITHIN a row as soon as the basecalls disagree with the signal
+// (profiles/r03/linear_domain_on_imperfect_reads.txt). The reference: three exp and two log1p per cell in this sweep.
 // What it gives up: a forward value of Z. The reference's check |Zf - Zb| / size <= 1e-8 compares two roundings of the
 // same number; here the backward value is THE Z and the check is that the chain delivers all its mass to the end cell
-// (T-1, N-1) -- which fails exactly when the backward values are not those of a consistent lattice (inf/NaN samples).
-// Statistics as in NT_aligner_api.cpp:462-561; the transition expectations (:641-725) are the same for every path
-// (N-1 moves, T-1-2(N-1) extensions) and written as such.
-__device__ __forceinline__ void set_emis_chain(EmisV<CPL>& p, int j, const Emis& e, double e2) {
-  set_emis<ARITH_FOLDED>(p, j, e);  // the backward sweep's constants: both sweeps score a cell with the same bits
-  p.neg_log_stdev[j] += e2;         // (-inf for a column without a k-mer)
-}
-
+// (T-1, N-1) and every sample has carried weight 1 -- which fails exactly when the backward values are not those of a
+// consistent lattice (inf / NaN samples). Statistics as in NT_aligner_api.cpp:462-561; the transition expectations
+// (:641-725) are the same for every path (N-1 moves, T-1-2(N-1) extensions) and written as such.
 __device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const WaveCtx& w, const double* __restrict__ sig,
-                                                      const Emis* __restrict__ par, const double* __restrict__ ws,
-                                                      TrainBuffers tb, double Zb, double e2, const SoftplusNode* s_tab,
-                                                      unsigned ring_base) {
+                                                      const double* __restrict__ ws, TrainBuffers tb, double Zb,
+                                                      const SoftplusNode* s_tab, unsigned ring_base) {
   const int lane = w.lane;
-  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
+  const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
-  const Emis* __restrict__ pr = par + rd.par_off;
   double* __restrict__ cw = tb.col_w + rd.par_off;
   double* __restrict__ cs1 = tb.col_s1 + rd.par_off;
   double* __restrict__ cs2 = tb.col_s2 + rd.par_off;
@@ -869,43 +874,31 @@ __device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const 
 
   int lo = band_mid(1, ratio) - bw;  // band of row 1
   double gE[CPL], gM[CPL];            // posteriors of the previous row, updated in place
-  double bA[CPL], bB[CPL];            // bE of the previous / of this row, roles alternating
   double aw[CPL], a1[CPL], a2[CPL];
-  EmisV<CPL> p;
   double awsum = 0.0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int nj = lo + pmod(lane * CPL + j - lo);
-    set_emis_chain(p, j, load_emis(pr, nj, (nj <= lo + W - 1) ? N : 0), e2);
     gE[j] = (nj == 0) ? 1.0 : 0.0;  // all mass in E(0, 0)
     gM[j] = 0.0;
     aw[j] = a1[j] = a2[j] = 0.0;
   }
-  // ring: rows 0 .. RING_D-1, row 0 into registers, then row RING_D (row r lives in ring slot r % RING_D; rows past T
-  // repeat the all -inf row T)
+  // ring: row t of the chain reads lattice row t-1 (= ln of the stay probabilities out of row t-1), which lives in ring
+  // slot (t-1) % RING_D; rows past T repeat row T
   const double* __restrict__ dma_src = ws + lane * 2;
   for (int r = 0; r < RING_D; ++r)
     ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
-  wait_vmcnt<RING_WAIT>();
-  ring_read_row(ring_base, lane, bA);
-  ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(RING_D, T)) * P, ring_base);
 
   const double one = dynmath::vreg_const(1.0);
-  // one lattice row t; x = the sample the row scores (sig[t-1]); b_prev = bE(t-1, .), b_out = bE(t, .)
-  auto row = [&](int t, double x, const double (&b_prev)[CPL], double (&b_out)[CPL]) {
-    double c[CPL], sp[CPL], st[CPL], mv[CPL], mvl[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) c[j] = dynmath::fma_(x, p.inv_stdev[j], -p.mean[j]);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) c[j] = dynmath::fma_(-c[j], c[j], p.neg_log_stdev[j]);  // e2 + e(t, n)
+  auto row = [&](int t, double x) {  // x = the sample row t scores (sig[t-1])
+    double ls[CPL], sp[CPL], st[CPL], mv[CPL], mvl[CPL];
     wait_vmcnt<RING_WAIT>();
-    ring_read_row(ring_base + (t % RING_D) * ROW_BYTES, lane, b_out);
-    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + RING_D, T)) * P, ring_base + (t % RING_D) * ROW_BYTES);
+    const unsigned slot_addr = ring_base + ((t - 1) % RING_D) * ROW_BYTES;
+    ring_read_row(slot_addr, lane, ls);
+    ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t - 1 + RING_D, T)) * P, slot_addr);
+    dynmath::exp_table128_vec<CPL>(ls, sp, etab);  // NaN, -inf: 0
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) c[j] = c[j] + (b_out[j] - b_prev[j]);  // (-inf) - (-inf): NaN, which the exponential maps to 0
-    dynmath::exp_table128_vec<CPL>(c, sp, etab);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) sp[j] = dynmath::min_hw(sp[j], one);  // the stay probability, <= 1 whatever the last bits say
+    for (int j = 0; j < CPL; ++j) sp[j] = dynmath::min_hw(sp[j], one);  // <= 1 whatever the last bits say (NaN: 1, times a mass of 0)
 #pragma unroll
     for (int j = 0; j < CPL; ++j) st[j] = gE[j] * sp[j];
 #pragma unroll
@@ -925,12 +918,11 @@ __device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const 
     // the band of row t+1
     const int next_lo = band_mid(t + 1, ratio) - bw;
     if (__builtin_expect(next_lo != lo, 0)) {  // wave-uniform: the window moves up by one column between rows t and t+1
-      const Emis none = load_emis(pr, 0, 0);
-      const Emis entering = load_emis(pr, lo + W, N);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         const int nj = lo + pmod(lane * CPL + j - lo);
-        // the slot handed on at the PREVIOUS move (column lo-1) has received nothing but zeros since
+        // the slot handed on at the PREVIOUS move (column lo-1) has received nothing but zeros since: the column it
+        // now stands for is far above the band, no mass can be there
         if (nj == lo - 1 + P) {
           if (lo - 1 >= 1 && lo - 1 < N) {
             cw[lo - 2] = aw[j];
@@ -940,33 +932,19 @@ __device__ __forceinline__ double forward_train_chain(const ReadDesc& rd, const 
           awsum += aw[j];
           aw[j] = a1[j] = a2[j] = 0.0;
         }
-        // column lo is in the band for the last time in row t: from the next row on its slot belongs to column lo + P
-        // (no mass can be left there: its bE in row t+1 is -inf); column lo + W enters the band with the next row
-        if (nj == lo) set_emis_chain(p, j, none, e2);
-        if (nj == lo + W) set_emis_chain(p, j, entering, e2);
       }
       lo = next_lo;
     }
   };
 
-  bool odd = false;
   for (int tb0 = 1; tb0 < T; tb0 += 64) {
     const int idx = tb0 - 1 + lane;  // row t scores sample t - 1
     const double xs = sg[min(idx, T - 2)];
     asm volatile("" ::"v"(xs));  // the load's wait belongs here, not into the row loop (see forward_sweep)
     const int iend = min(64, T - tb0);
-    int i = 0;
 #pragma unroll 1
-    for (; i + 1 < iend; i += 2) {
-      row(tb0 + i, readlane_f64(xs, i), bA, bB);
-      row(tb0 + i + 1, readlane_f64(xs, i + 1), bB, bA);
-    }
-    if (i < iend) {  // odd tail (last block of a read only)
-      row(tb0 + i, readlane_f64(xs, i), bA, bB);
-      odd = true;
-    }
+    for (int i = 0; i < iend; ++i) row(tb0 + i, readlane_f64(xs, i));
   }
-  (void)odd;
   wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
@@ -1210,7 +1188,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         // backward sweep in the log domain (the emission's constant folded), then the posterior chain
         Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
-        Zf = forward_train_chain(rd, w, sig, par, q.pool.ws, q.tr, Zb, q.e2, s_tab, ring_base);
+        Zf = forward_train_chain(rd, w, sig, q.pool.ws, q.tr, Zb, s_tab, ring_base);
       } else {
         Zb = backward_sweep<LATTICE, ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
