@@ -4,8 +4,8 @@
 The oracle (= the reference's arithmetic, NT_aligner_api.cpp:110-207 and :462-561) works in log space: for a 20 k-sample
 read its forward/backward values are ~ -4e4, whose fp64 spacing is 7e-12, so every one of the T additions along a path
 rounds the PROBABILITY by ~7e-12 relative -- the posteriors it sums carry 1e-9 .. 1e-8 of rounding noise. The product's
-training sweeps work in the linear domain with exact power-of-two scaling (relative rounding 1e-16 per row). When the
-two disagree at 5e-9 this restatement, 2 000 times finer than either, says which one moved.
+forward sweep is the posterior chain (one exponential of a difference formed in registers per cell; mass conserved by
+construction). When the two disagree at 5e-9 this restatement, 2 000 times finer than either, says which one moved.
 
     python tests/extended_precision_train.py            # cfg5 reads 0 and 100: oracle vs extended precision
     python tests/extended_precision_train.py --gpu FILE  # + the product's weights saved by --save on the GPU box

@@ -210,8 +210,8 @@ def test_table_logplus_special_values_and_oracle(mathlib, oracle_built):
 
 def test_exp_table128_vec_accuracy_and_exact_zero(mathlib):
     """2.5e-12 relative (degree-3 polynomial on |r| <= ln2/256) down to the smallest normal number, gradual underflow below it (like exp itself: half a unit of
-    the denormal spacing), exactly 0 from -745.2 on and for -inf / NaN -- a cell the linear-domain sweeps cannot
-    represent must vanish, not keep 1e-304."""
+    the denormal spacing), exactly 0 from -745.2 on and for -inf / NaN -- the posterior chain's stay probability of a cell
+    nothing can reach (its stored exponent is (-inf) - (-inf)) must be 0, not 1e-304."""
     rng = np.random.default_rng(5)
     d = np.concatenate([-rng.uniform(0, 60, 3500), -rng.uniform(600, 708, 1400), rng.uniform(-1e-9, 1e-9, 700), rng.uniform(0, 5, 686),
                         -rng.uniform(708, 746, 700), [0.0, -745.0, -745.2, -999.0, -1e9, 1e-300, -1e-300, -0.5, -np.inf, np.nan, -746.0, -750.0, -751.0, -1e300]])

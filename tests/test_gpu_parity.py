@@ -701,8 +701,8 @@ def test_cfg5_share_full_size_train(models, al9):
         assert np.abs(m - s1[touched] / w[touched]).max() <= 1e-9
         a = int(res.em_offsets[i])
         # 1e-7, not 1e-9: the oracle (= the reference's arithmetic) adds ~20 k log-space terms of magnitude 4e4 per
-        # path, each rounding the probability by 7e-12 -- its weights carry up to 6e-9 of noise, the linear-domain
-        # sweeps 2e-12 (tests/extended_precision_train.py adjudicates in 80-bit; profiles/r03/train_precision.txt)
+        # path, each rounding the probability by 7e-12 -- its weights carry up to 6e-9 of noise, the posterior chain
+        # 4e-11 (tests/extended_precision_train.py adjudicates in 80-bit; profiles/r03/train_precision.txt)
         assert np.allclose(res.em_weight[a:a + len(code)], w[touched], rtol=1e-7, atol=1e-12)
 
 
