@@ -61,7 +61,12 @@ enum dyn_read_status {
   DYN_READ_SIGNAL_SHORT = 3,     /* "Signal too short compared to sequence"  aligner.cpp:159-163 */
   DYN_READ_INVALID_NT = 4,       /* "Invalid nucleotide: X"                  aligner.cpp:180-196 */
   DYN_READ_Z_MISMATCH = 5,       /* "Alignment failed: alignment scores do not match"  NT_aligner_api.cpp:288-291 */
-  DYN_READ_TRAIN_Z_MISMATCH = 6, /* "Training failed: alignment scores do not match"   NT_aligner_api.cpp:622-625 */
+  DYN_READ_TRAIN_Z_MISMATCH = 6, /* "Training failed: alignment scores do not match"   NT_aligner_api.cpp:622-625.
+                                  * train() here has ONE Z (the backward sweep's); what it checks instead of |Zf - Zb| is
+                                  * that Z is finite and that the posterior chain delivers all its mass to the end cell
+                                  * and weight 1 per sample. Same outcome for inf / NaN samples; a sample ~1e6 model
+                                  * standard deviations out (|Z| ~ 1e12), where the reference's two roundings of Z
+                                  * disagree and it refuses the read, trains here. DESIGN.md section 3. */
   DYN_READ_INTERNAL = 7,         /* traceback left the lattice (cannot happen once the Z check passed) */
   DYN_READ_NTK_MISMATCH = 9,     /* "NTK alignment failed: alignment scores do not match"  NTK_aligner_api.cpp:911-917:
                                     what every read that passes validation gets from a handle created with mode
