@@ -128,3 +128,32 @@ def test_train_sample_at_the_edge_of_double_precision(models):
     al = Aligner(path, "rna004", device=0)
     assert _check(al, Oracle(path, 1), base + reads, "far") == 5
     al.close()
+
+
+def test_train_long_dna_reads(models):
+    """cfg3-shaped reads through train(): 8 DNA r10.4.1 reads of 40 k - 100 k samples (the lattice of one read spans
+    hundreds of pages, the band moves every ~12 rows); every read conserves its mass, two are compared with the oracle."""
+    import multiprocessing as mp
+    from test_gpu_parity import model_for, _orc_init, _orc_train
+    path = model_for(models, "dna_r10_400bps")
+    _, mean, sd = synth.read_model_file(path)
+    reads = synth.make_reads(303, 8, "dna_r10_400bps", mean, sd, (3200, 8000))
+    al = Aligner(path, "dna_r10_400bps", device=0)
+    tr = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
+    assert (tr.status == 0).all()
+    assert max(len(r.signal) for r in reads) > 80000
+    for i, r in enumerate(reads):
+        a, c = int(tr.em_offsets[i]), int(tr.em_count[i])
+        assert abs(tr.em_weight[a:a + c].sum() - len(r.signal)) <= 1e-9 * len(r.signal), i
+    picks = [int(np.argmax([len(r.signal) for r in reads])), 0]
+    with mp.get_context("fork").Pool(2, initializer=_orc_init, initargs=(path, synth.PORES["dna_r10_400bps"][0])) as pool:
+        want = pool.map(_orc_train, [(reads[i].signal, reads[i].sequence) for i in picks], chunksize=1)
+    for i, (Z, m1, e2, w, s1, s2) in zip(picks, want):
+        assert abs(tr.Z[i] - Z) <= 1e-9 * abs(Z)
+        assert abs(tr.transitions[3 * i] - m1) <= 1e-8 and abs(tr.transitions[3 * i + 2] - e2) <= 1e-8
+        code, m, s = tr.sparse(i)
+        touched = np.nonzero(w > 0)[0]
+        assert np.array_equal(code, touched)
+        a = int(tr.em_offsets[i])
+        assert np.allclose(tr.em_weight[a:a + len(code)], w[touched], rtol=3e-7, atol=1e-12)
+    al.close()
