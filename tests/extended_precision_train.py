@@ -88,6 +88,67 @@ def train_weights_extended(signal, kmers, mean, stdev, m1, e1, e2, bw=200):
     return Zb, w[1:]
 
 
+def chain_weights_quantised(signal, kmers, mean, stdev, m1, e1, e2, store_dtype, bw=200):
+    """The product's forward sweep (posterior chain) emulated on the CPU with the backward sweep's ln P(stay) rounded to
+    ``store_dtype`` (np.float64 = what the product stores, np.float32 = the half-size lattice DESIGN.md section 10
+    mentions): backward values in long double, the chain itself in fp64. Returns the weight per lattice column."""
+    sig = np.asarray(signal, dtype=LD)
+    T, N = len(sig) + 1, len(kmers) + 1
+    mu = np.asarray(mean, dtype=LD)[kmers]
+    sd = np.asarray(stdev, dtype=LD)[kmers]
+    lognorm = -np.log(sd) - LD(0.5) * np.log(LD(2) * LD(np.pi))
+    lm1, le2 = np.log(LD(m1)), np.log(LD(e2))
+    ratio = np.float64(N) / np.float64(T)
+    mid = (np.arange(T, dtype=np.float64) * ratio).astype(np.int64)
+    n_start = np.maximum(mid - bw, 0)
+    n_end = np.minimum(mid + bw + 1, N)
+
+    def score(t_sig, lo, hi):
+        z = (sig[t_sig] - mu[lo - 1:hi - 1]) / sd[lo - 1:hi - 1]
+        return LD(-0.5) * z * z + lognorm[lo - 1:hi - 1]
+
+    stay = [None] * T  # ln P(stay | E(t, n)) over the full width, as stored
+    Mn = np.full(N + 1, NEG, dtype=LD)
+    En = np.full(N + 1, NEG, dtype=LD)
+    En[N - 1] = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for t in range(T - 2, -1, -1):
+            lo, hi = int(n_start[t]), int(n_end[t])
+            Mc = np.full(N + 1, NEG, dtype=LD)
+            Ec = np.full(N + 1, NEG, dtype=LD)
+            ext = np.full(hi - lo, NEG, dtype=LD)
+            C = np.full(hi - lo, NEG, dtype=LD)
+            hi1 = min(hi, N - 1)
+            if hi1 > lo:
+                ext[:hi1 - lo] = Mn[lo + 1:hi1 + 1] + score(t, lo + 1, hi1 + 1) + lm1
+            lo1 = max(lo, 1)
+            if hi > lo1:
+                sc = score(t, lo1, hi)
+                Mc[lo1:hi] = En[lo1:hi] + sc
+                C[lo1 - lo:] = En[lo1:hi] + sc + le2
+                ext[lo1 - lo:] = np.logaddexp(ext[lo1 - lo:], C[lo1 - lo:])
+            Ec[lo:hi] = ext
+            row = np.full(N + 1, -np.inf)
+            d = (C - ext).astype(np.float64)
+            d[np.isnan(d)] = -np.inf
+            row[lo:hi] = d.astype(store_dtype).astype(np.float64)
+            stay[t] = row
+            Mn, En = Mc, Ec
+        gE = np.zeros(N + 1)
+        gM = np.zeros(N + 1)
+        gE[0] = 1.0
+        w = np.zeros(N + 1)
+        for t in range(1, T):
+            sp = np.minimum(np.exp(stay[t - 1]), 1.0)
+            st = gE * sp
+            mv = gE - st
+            gE = gM + st
+            gM = np.zeros(N + 1)
+            gM[1:] = mv[:-1]
+            w += gE + gM
+    return w[1:N]
+
+
 def per_kmer(w_cols, kmers, K):
     out = np.zeros(K, dtype=LD)
     np.add.at(out, kmers, w_cols)
@@ -101,6 +162,8 @@ def main():
     ap.add_argument("--reads", default="0,100")
     ap.add_argument("--gpu", help="npz with w<i> = the product's per-k-mer weights of read i (written by --save)")
     ap.add_argument("--save", help="ON THE GPU BOX: run the product's train() on the reads and save their weights here")
+    ap.add_argument("--chain-storage", action="store_true",
+                    help="CPU emulation of the posterior chain with ln P(stay) stored as float64 and as float32")
     args = ap.parse_args()
     import tempfile
     d = tempfile.mkdtemp()
@@ -135,6 +198,10 @@ def main():
         rel = lambda a: float(np.max(np.abs(a[nz].astype(LD) - truth[nz]) / truth[nz]))
         line = "read %d (S %d): Z %.12f; oracle Z off by %.3g; oracle weights off by %.3g relative" % (
             i, len(r.signal), float(Z), float(t["Z"] - Z), rel(t["weight"]))
+        if args.chain_storage:
+            for dt in (np.float64, np.float32):
+                wq = per_kmer(chain_weights_quantised(r.signal, km, mean, sd, 0.031111753637096777, 1.0, 0.9688882463622581, dt), km, len(mean))
+                line += "; chain with %s rows off by %.3g" % (np.dtype(dt).name, rel(wq))
         if gpu is not None and ("w%d" % i) in gpu:
             line += "; product off by %.3g, product vs oracle %.3g" % (
                 rel(gpu["w%d" % i]), float(np.max(np.abs(gpu["w%d" % i][nz] - t["weight"][nz]) / t["weight"][nz])))
