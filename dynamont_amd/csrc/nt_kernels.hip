@@ -530,8 +530,12 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   RowState sa, sb;
   EmisV<CPL> p;
   double p_stdev[STRICT ? CPL : 1];  // STRICT instantiation: the divisor of the reference's emission, beside 1/stdev
+  // POST = false is align(calc_probabilities=false): Z both ways and their agreement, no decision taken -- the cheap
+  // arithmetic of train()'s backward sweep (two-operation emission, degree-3 softplus polynomial; Z moves by 1e-12
+  // relative, the bar is 1e-9)
   auto set_p = [&](int j, const Emis& e) {
-    p.set(j, e);
+    if constexpr (!POST) set_emis<ARITH_FOLDED>(p, j, e);
+    else p.set(j, e);
     if constexpr (STRICT) p_stdev[j] = e.stdev;
   };
   // emission of one sample against the lane's cells, in the flavour of the row it belongs to
@@ -552,7 +556,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
         return;
       }
     }
-    log_normal_pdf_vec<CPL>(x, p, out);
+    if constexpr (!POST) emission_vec<ARITH_FOLDED>(x, p, out);
+    else log_normal_pdf_vec<CPL>(x, p, out);
   };
   const double x0 = sg[0];
   const size_t r1 = POST ? (size_t)cur_out.at(w, 1) * P : 0;
@@ -620,8 +625,9 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     } else {
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(a1, a2, L, s_tab);
-      log_normal_pdf_vec<CPL>(xn, p, out.e);  // e(t+1, n): independent work under the LDS latency
-      log_plus_finish<CPL>(L, out.fE);
+      emission(false, xn, out.e);  // e(t+1, n): independent work under the LDS latency
+      if constexpr (!POST) dynmath::log_plus_finish3<CPL>(L, out.fE);
+      else log_plus_finish<CPL>(L, out.fE);
     }
     if (POST) {
       double LPM[CPL], LPE[CPL], alt[CPL];
@@ -1190,7 +1196,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         t2 = __builtin_amdgcn_s_memtime();
         Zf = forward_train_chain(rd, w, sig, q.pool.ws, q.tr, Zb, s_tab, ring_base);
       } else {
-        Zb = backward_sweep<LATTICE, ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+        Zb = backward_sweep<LATTICE, JOB == JOB_Z ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
         if (JOB == JOB_ALIGN) {
           Zf = forward_sweep<true, false, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);

@@ -83,7 +83,8 @@ def test_async_isolates_failed_reads_and_matches_oracle(models):
     rz = t.wait()
     assert np.array_equal(rz.status, res.status) and int(rz.n_segments.sum()) == 0
     ok = res.status == 0
-    assert np.array_equal(rz.Z[ok], res.Z[ok])
+    # (not bit-equal: Z-only jobs run the cheap arithmetic -- two-operation emission, degree-3 softplus polynomial)
+    assert np.allclose(rz.Z[ok], res.Z[ok], rtol=1e-11, atol=0)
     t.close()
     al.close()
 

@@ -134,6 +134,37 @@ def test_random_reads_against_oracle(models, pore, nb):
         assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
 
 
+@pytest.mark.parametrize("pore,nb", [("rna002", (30, 300)), ("rna004", (100, 700)), ("dna_r9", (20, 250))])
+def test_z_only_alignment_against_oracle(models, pore, nb):
+    """align(calc_probabilities=False), the reference's default call: Z and the check that both sweeps agree on it, no
+    segments. The sweeps run the cheap arithmetic here (no decision hangs on them): Z to 1e-9 relative like everywhere,
+    error texts like the reference, on ordinary, noise and outlier reads."""
+    path = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(path)
+    reads = synth.make_reads(777, 16, pore, mean, sd, nb)
+    rng = np.random.default_rng(10)
+    reads[1].signal[:] = rng.standard_normal(len(reads[1].signal))
+    reads[2].signal[40:50] += 25.0
+    reads[3].signal[len(reads[3].signal) // 2] = 3e3
+    reads[4] = synth.SynthRead(reads[4].signal[: 2 * (len(reads[4].sequence) - synth.PORES[pore][2] + 1) - 1], reads[4].sequence)  # too short
+    al = Aligner(path, pore, device=0)
+    orc = Oracle(path, synth.PORES[pore][0])
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], False)
+    n_ok = 0
+    for i, r in enumerate(reads):
+        try:
+            want = orc.align(r.signal, r.sequence, False)
+        except RuntimeError as e:
+            assert res.error(i) == str(e), i
+            continue
+        assert res.status[i] == 0, (i, res.error(i))
+        assert abs(res.Z[i] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"])), (i, res.Z[i], want["Z"])
+        assert res.read(i)["signal_positions"].size == 0
+        n_ok += 1
+    assert n_ok >= 14
+    al.close()
+
+
 @pytest.mark.parametrize("pore,nb", [("rna002", (60, 400)), ("rna004", (150, 700)), ("dna_r10_400bps", (300, 700))])
 def test_models_with_a_stdev_per_kmer(models, tmp_path, pore, nb):
     """The seeded synthetic models give every k-mer the same stdev; real ones do not (rna004: 0.05 .. 0.5). A model with
