@@ -248,19 +248,34 @@ def test_small_bands_and_tiny_reads_fuzz(models, pore, band):
     al = Aligner(path, pore, band=band, device=0)
     orc = Oracle(path, synth.PORES[pore][0], band)
     res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    zs = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], False)
+    tr = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
     ok = 0
     for i, r in enumerate(reads):
+        tag = (i, len(r.sequence), len(r.signal))
         try:
             want = orc.align(r.signal, r.sequence, True)
         except RuntimeError as e:
-            assert res.error(i) == str(e), (i, len(r.sequence), len(r.signal))
+            assert res.error(i) == str(e), tag
+            assert zs.error(i) == str(e), tag
             continue
-        assert res.status[i] == 0, (i, len(r.sequence), len(r.signal), res.error(i))
+        assert res.status[i] == 0, (tag, res.error(i))
         got = res.read(i)
-        assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), (i, len(r.sequence), len(r.signal))
-        assert np.array_equal(got["signal_positions"], want["signal_positions"]), (i, len(r.sequence), len(r.signal))
+        assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), tag
+        assert np.array_equal(got["signal_positions"], want["signal_positions"]), tag
         assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
         assert abs(got["Z"] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))
+        assert zs.status[i] == 0 and abs(zs.Z[i] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"])), tag
+        # the training sweeps (backward with the stored stay exponent, posterior chain) through the same band logic
+        wt = orc.train(r.signal, r.sequence)
+        assert tr.status[i] == 0, (tag, tr.error(i))
+        assert abs(tr.Z[i] - wt["Z"]) <= 1e-9 * max(1.0, abs(wt["Z"])), tag
+        assert abs(tr.transitions[3 * i] - wt["m1"]) <= 1e-8 and abs(tr.transitions[3 * i + 2] - wt["e2"]) <= 1e-8, tag
+        code, m, sdev = tr.sparse(i)
+        touched = np.nonzero(wt["weight"] > 0)[0]
+        assert np.array_equal(code, touched), tag
+        a = int(tr.em_offsets[i])
+        assert np.allclose(tr.em_weight[a:a + len(code)], wt["weight"][touched], rtol=1e-7, atol=1e-12), tag
         ok += 1
     assert ok >= 24
 
