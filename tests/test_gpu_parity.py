@@ -779,6 +779,12 @@ def test_page_starved_queues_equal_the_unconstrained_run(models, al9, monkeypatc
         a, c = base.read(i), got.read(i)
         assert np.array_equal(a["signal_positions"], c["signal_positions"]) and a["Z"] == c["Z"]
         assert np.array_equal(a["probabilities"], c["probabilities"])
+    # the training sweeps on the same starved pool: bit for bit the unconstrained statistics
+    tb, ts = al9.train_batch(sigs, seqs), small.train_batch(sigs, seqs)
+    assert (tb.status == 0).all() and (ts.status == 0).all()
+    assert np.array_equal(tb.Z, ts.Z) and np.array_equal(tb.em_offsets, ts.em_offsets)
+    assert np.array_equal(tb.em_code, ts.em_code) and np.array_equal(tb.em_weight, ts.em_weight)
+    assert np.array_equal(tb.em_sum, ts.em_sum) and np.array_equal(tb.em_sumsq, ts.em_sumsq)
     small.close()
 
 
