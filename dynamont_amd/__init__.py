@@ -6,6 +6,6 @@ the C ABI of include/dynamont_mi.h. No CPU or PyTorch compute path exists in thi
 """
 __version__ = "0.1.0"
 
-from ._dynamont import Aligner, MultiAligner, PoreType, pore_type  # noqa: E402,F401
+from ._dynamont import Aligner, MultiAligner, PoreType, pore_type, release_cached_memory  # noqa: E402,F401
 
-__all__ = ["Aligner", "MultiAligner", "PoreType", "pore_type", "__version__"]
+__all__ = ["Aligner", "MultiAligner", "PoreType", "pore_type", "release_cached_memory", "__version__"]

@@ -376,6 +376,11 @@ class AsyncBatch:
         self.close()
 
 
+def release_cached_memory() -> None:
+    """Free the lattice pools that destroyed aligners have parked for their successors (dyn_release_cached_memory)."""
+    N.lib().dyn_release_cached_memory()
+
+
 def pinned_empty(n: int, dtype) -> np.ndarray:
     """An uninitialised 1-D array in page-locked host memory (dyn_host_alloc): H2D/D2H of the asynchronous
     calls then run as plain DMA. The memory is released when the array (and every view of it) is gone."""

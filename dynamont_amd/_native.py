@@ -61,6 +61,7 @@ SIGNATURES = {
     "dyn_aligner_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_int,
                                      C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_aligner_destroy": (None, [C.c_void_p]),
+    "dyn_release_cached_memory": (None, []),
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -78,6 +78,84 @@ void BufCache::purge() {
   pin.clear();
 }
 
+// ---- parked lattice pools ---------------------------------------------------------------------------------
+// Allocating (and freeing) a lattice pool of ~100 GB costs seconds (hipMalloc / hipFree of that size: 1.3-2.5 s each
+// way on an MI355X). The reference's training loop builds a new Aligner for every batch (train.py:179,227), and so
+// does its counterpart here: with 1 024-read batches that was 2.7 s of allocation around 25 ms of kernels. A handle
+// that is destroyed therefore PARKS its three pool buffers, per device, and the next handle on that device takes them
+// over if they are large enough (the page count in use is still capped by the handle's own memory budget). At most
+// one set is parked per device; dyn_release_cached_memory() frees it. DYN_NO_POOL_CACHE=1 switches parking off.
+namespace {
+struct ParkedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+constexpr int PARK_DEVICES = 32, PARK_KINDS = 3;  // kinds: ws, lpe, bits
+std::mutex g_park_m;
+ParkedBuf g_park[PARK_DEVICES][PARK_KINDS];
+
+bool parking_enabled() {
+  static const bool on = std::getenv("DYN_NO_POOL_CACHE") == nullptr;
+  return on;
+}
+
+// the handle's buffer goes to the parking slot (the larger of the two stays, the other is freed)
+void park_pool_buffer(int device, int kind, DevBuf& b) {
+  if (!b.p) return;
+  if (!parking_enabled() || device < 0 || device >= PARK_DEVICES) {
+    b.release();
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_park_m);
+  ParkedBuf& slot = g_park[device][kind];
+  if (slot.p && slot.bytes >= b.bytes) {
+    (void)hipFree(b.p);
+  } else {
+    if (slot.p) (void)hipFree(slot.p);
+    slot.p = b.p;
+    slot.bytes = b.bytes;
+  }
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+// grow `b` to at least `want` bytes: a parked buffer that is large enough, else a fresh allocation (after the parked
+// one has been freed: its memory may be what the larger buffer needs)
+hipError_t ensure_pool_buffer(int device, int kind, DevBuf& b, size_t want, double headroom) {
+  if (want <= b.bytes) return hipSuccess;
+  if (parking_enabled() && device >= 0 && device < PARK_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_park_m);
+    ParkedBuf& slot = g_park[device][kind];
+    if (slot.p && slot.bytes >= want) {
+      b.release();
+      b.p = slot.p;
+      b.bytes = slot.bytes;
+      slot = ParkedBuf{};
+      return hipSuccess;
+    }
+    if (slot.p) {
+      (void)hipFree(slot.p);
+      slot = ParkedBuf{};
+    }
+  }
+  return b.ensure(want, headroom);
+}
+}  // namespace
+
+extern "C" void dyn_release_cached_memory(void) {
+  std::lock_guard<std::mutex> lk(g_park_m);
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (int d = 0; d < PARK_DEVICES; ++d)
+    for (int k = 0; k < PARK_KINDS; ++k)
+      if (g_park[d][k].p) {
+        (void)hipSetDevice(d);
+        (void)hipFree(g_park[d][k].p);
+        g_park[d][k] = ParkedBuf{};
+      }
+  if (have_cur) (void)hipSetDevice(cur);
+}
+
 hipError_t DevBuf::ensure(size_t want, double headroom) {
   if (want <= bytes) return hipSuccess;
   release();
@@ -405,9 +483,9 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     (void)hipDeviceSynchronize();
     a->d_model.release();
     a->d_sptab.release();
-    a->ws.release();
-    a->lpe.release();
-    a->bits.release();
+    park_pool_buffer(a->device, 0, a->ws);
+    park_pool_buffer(a->device, 1, a->lpe);
+    park_pool_buffer(a->device, 2, a->bits);
     a->free_list.release();
     a->ctl.release();
     a->h_rows.release();
@@ -971,11 +1049,11 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     if (grow) {  // growing releases the old buffer, which earlier work on the compute stream may still be using
       HIP_TRY(a, hipStreamSynchronize(a->stream));
       const double headroom = std::min(1.15, std::max(1.0, (double)cap_pages / (double)std::max<uint64_t>(1, target)));
-      HIP_TRY(a, a->ws.ensure(target * ws_pp, headroom));
-      if (calc && lpe_separate) HIP_TRY(a, a->lpe.ensure(target * lpe_pp, headroom));
-      if (calc) HIP_TRY(a, a->bits.ensure(target * bits_pp, headroom));
+      HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, target * ws_pp, headroom));
+      if (calc && lpe_separate) HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, target * lpe_pp, headroom));
+      if (calc) HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, target * bits_pp, headroom));
     }
-    uint64_t n_pages = a->ws.bytes / ws_pp;
+    uint64_t n_pages = std::min<uint64_t>(a->ws.bytes / ws_pp, cap_pages);  // (a buffer taken over from a parked pool may exceed this handle's budget)
     if (calc && lpe_separate) n_pages = std::min<uint64_t>(n_pages, a->lpe.bytes / lpe_pp);
     if (calc) n_pages = std::min<uint64_t>(n_pages, a->bits.bytes / bits_pp);
     n_pages = std::min<uint64_t>(n_pages, 0xfffffff0ull >> log_r);  // pool rows are 32-bit

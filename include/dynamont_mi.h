@@ -186,7 +186,12 @@ int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errca
  * reference fixes band = 400: segment.py:45, utils.py:161). device < 0 -> current HIP device. */
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap);
+/* The lattice pool of a destroyed handle (up to ~100 GB; allocating or freeing that much takes seconds) is PARKED per
+ * device and taken over by the next handle created on that device -- the reference's training loop builds a new
+ * Aligner for every batch (train.py:179,227). dyn_release_cached_memory() frees whatever is parked (all devices);
+ * DYN_NO_POOL_CACHE=1 in the environment switches the parking off. */
 void dyn_aligner_destroy(dyn_aligner* a);
+void dyn_release_cached_memory(void);
 int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
 /* Dense model table in k-mer-code order, (mean, stdev) interleaved, 2*num_kmers doubles. */
 int dyn_aligner_model(const dyn_aligner* a, double* out2n);

@@ -158,3 +158,40 @@ def test_multi_device_handle_equals_single_device(models):
     with pytest.raises(ValueError, match="Unknown pore type"):
         MultiAligner(models["syn9"], "nope", [0])
     al.close()
+
+
+def test_a_new_aligner_takes_over_the_parked_pool_of_its_predecessor(models):
+    """The reference's training loop builds an Aligner per batch. A destroyed handle parks its lattice pool; the next
+    handle on the device takes it over (no second multi-second allocation), gives the same results, still honours its
+    own memory budget, and release_cached_memory() lets go of what is parked."""
+    import time
+    import dynamont_amd
+    from dynamont_amd import synth
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(4711, 512, "rna004", mean, sd, (1500, 2000))
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    dynamont_amd.release_cached_memory()
+
+    def once(budget=None):
+        al = Aligner(models["syn9"], "rna004", device=0)
+        if budget:
+            al.set_mem_budget(budget)
+        t0 = time.time()
+        with al.batch(sigs, seqs) as b:
+            b.train()
+            res, tm = b.fetch_train(), b.timing()
+        dt = time.time() - t0
+        al.close()
+        return res, tm, dt
+
+    r1, t1, d1 = once()
+    r2, t2, d2 = once()
+    assert t2["pool_pages"] == t1["pool_pages"]
+    assert np.array_equal(r1.Z, r2.Z) and np.array_equal(r1.em_weight, r2.em_weight)
+    assert d2 < 0.6 * d1 + 0.2, (d1, d2)          # the second aligner did not allocate its pool again
+    # a handle with a small budget does not use more of a large parked pool than its budget allows
+    small_budget = 480 * 256 * 448 * 8
+    r3, t3, _ = once(small_budget)
+    assert t3["pool_pages"] < t1["pool_pages"] and t3["pool_pages"] * t3["page_rows"] * 448 * 8 <= small_budget, (t1, t3)
+    assert np.array_equal(r1.Z, r3.Z) and np.array_equal(r1.em_weight, r3.em_weight)
+    dynamont_amd.release_cached_memory()
