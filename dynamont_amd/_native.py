@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "rccl_comm.cpp",
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "rccl_comm.cpp", "model_format.cpp",
            "nt_kernels.hip"]
 HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
@@ -62,6 +62,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_aligner_destroy": (None, [C.c_void_p]),
     "dyn_release_cached_memory": (None, []),
+    "dyn_format_model": (C.c_uint64, [C.c_char_p, C.c_int, c_double_p, c_double_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -31,7 +31,7 @@ import numpy as np
 from dynamont_amd import Aligner, __version__
 from dynamont_amd.pod5_io import get_signal, iter_basecalls, open_pod5
 from dynamont_amd.segmentation.utils import (cnt_nts_ratios, get_model, hampel, kmer_of_code, read_kmer_model,
-                                             write_kmer_model)
+                                             write_kmer_model, write_kmer_model_arrays)
 
 WINDOW = 100
 
@@ -197,6 +197,10 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
     probe = Aligner(trained_model, pore, device="host")
     k, rna, K = probe.kmer_size, probe.rna, probe.num_kmers
     names, mean0, sd0 = _code_order(model, k, rna)
+    # the model file keeps the row order of the file it started from: row -> k-mer code, once
+    code_of_name = {name: c for c, name in enumerate(names)}
+    code_of_row = np.fromiter((code_of_name[name] for name in model), dtype=np.int64, count=len(model))
+    file_kmers = "".join(model).encode()
     table = ManagedTable(mean0, sd0)
     trans = {p: ManagedList([v]) for p, v in transition_params.items()}
     any_seen = False
@@ -270,10 +274,9 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                     new_mean, new_sd = table.mean()
                 else:
                     new_mean, new_sd = cur_mean, cur_sd
-                for c, name in enumerate(names):
-                    model[name] = [new_mean[c], new_sd[c]]
                 trained_model = join(outdir, f"trained_{e}_{cbatch}.model")
-                write_kmer_model(trained_model, model)
+                # write_kmer_model(trained_model, {name: [new_mean[c], new_sd[c]] ...}) (train.py:221-224), same bytes
+                write_kmer_model_arrays(trained_model, file_kmers, k, np.asarray(new_mean)[code_of_row], np.asarray(new_sd)[code_of_row])
                 pw.flush()
                 # rerun with the new model to compare Zs (train.py:226-242)
                 al2 = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)

@@ -262,6 +262,13 @@ int dyn_format_csv(const dyn_aligner* a, uint64_t n_reads, const dyn_align_out* 
  * front of `out`, in read order; row_begin/row_end are updated. Returns the total byte count. */
 uint64_t dyn_csv_compact(char* out, uint64_t n_reads, uint64_t* row_begin, uint64_t* row_end);
 
+/* The text of a k-mer model file as write_kmer_model produces it (src/dynamont/segmentation/utils.py:136-152: header
+ * "kmer\tlevel_mean\tlevel_stdv", then f"{kmer}\t{mean}\t{stdev}\n" per row; dynamont-train writes one per batch,
+ * train.py:221-224): kmers = n rows of k characters, file order; a float64 prints as Python's repr(). Returns the
+ * byte count; with out == NULL or cap too small nothing is written and the size to provide is returned. */
+uint64_t dyn_format_model(const char* kmers, int k, const double* mean, const double* stdev, uint64_t n,
+                          char* out, uint64_t cap);
+
 /* ---- the output half of dynamont-resquiggle (src/dynamont/segmentation/segment.py:69-107, the listener) ----
  *
  * A sink owns `<out>.csv.zst` (ONE zstd frame at `level`, like the reference's stream writer; header line written at

@@ -184,3 +184,24 @@ def test_queue_planner_properties_on_random_batches(native_lib):
         assert sorted(order.tolist()) == list(range(n)), trial
         assert lpt.value != 2 ** 64 - 1 and planned.value <= lpt.value, (trial, lpt.value, planned.value)
         assert planned.value >= int(rows[0])
+
+
+def test_model_file_text_matches_the_python_writer(tmp_path):
+    """dyn_format_model: the bytes of write_kmer_model (f"{kmer}\\t{mean}\\t{stdev}\\n" with numpy float64 values, i.e.
+    Python's repr of a float) for 5-mers and 9-mers -- magnitudes from 1e-12 to 1e22, zero, negative zero, the
+    fixed / scientific switch points, a denormal, the largest double, inf, nan."""
+    import numpy as np
+    from dynamont_amd import synth
+    from dynamont_amd.segmentation.utils import write_kmer_model, write_kmer_model_arrays
+    rng = np.random.default_rng(1)
+    for k in (5, 9):
+        names = synth.kmer_strings(k)
+        n = len(names)
+        mean = rng.standard_normal(n) * 10.0 ** rng.integers(-12, 22, n)
+        sd = np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-6, 3, n)
+        edge = [0.0, -0.0, 1e16, 1e-5, 0.0001, 123456789012345678.0, 1e15, 9999999999999998.0, 0.001, 1.0, 100.0, 1e22,
+                5e-324, 1.7976931348623157e308, np.inf, -np.inf, np.nan, 0.1, 1 / 3, 2.5e-5, 12345.678, 1e-4, 9.999e-5]
+        mean[:len(edge)] = edge
+        write_kmer_model(str(tmp_path / "py.model"), {names[i]: [mean[i], sd[i]] for i in range(n)})
+        write_kmer_model_arrays(str(tmp_path / "native.model"), "".join(names).encode(), k, mean, sd)
+        assert (tmp_path / "py.model").read_bytes() == (tmp_path / "native.model").read_bytes(), k
