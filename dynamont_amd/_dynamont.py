@@ -463,6 +463,17 @@ class Aligner:
 
     STRICT_MODES = {"off": 0, "start": 1, "all": 2}
 
+    def set_model(self, mean, stdev) -> None:
+        """Replace the model table (k-mer-code order, as model_table() returns it): the aligner then equals one built
+        from a model file with these values (dyn_aligner_set_model)."""
+        t = np.empty(2 * self.num_kmers)
+        t[0::2] = np.asarray(mean, dtype=np.float64)
+        t[1::2] = np.asarray(stdev, dtype=np.float64)
+        rc = self._L.dyn_aligner_set_model(self._h, _ptr(t, N.c_double_p))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        self._model = None  # model_table() reads it back
+
     def set_strict(self, mode) -> None:
         """dyn_aligner_set_strict: 0/"off" default arithmetic; 1/"start" reads whose first two k-mers are equal go
         through the kernels that reproduce the reference's libm bit for bit; 2/"all" every read."""

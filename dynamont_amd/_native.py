@@ -62,6 +62,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_aligner_destroy": (None, [C.c_void_p]),
     "dyn_release_cached_memory": (None, []),
+    "dyn_aligner_set_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_format_model": (C.c_uint64, [C.c_char_p, C.c_int, c_double_p, c_double_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),

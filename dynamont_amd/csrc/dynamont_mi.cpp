@@ -522,6 +522,23 @@ int dyn_aligner_model(const dyn_aligner* a, double* out2n) {
   return DYN_OK;
 }
 
+int dyn_aligner_set_model(dyn_aligner* a, const double* in2n) {
+  if (!a || !in2n) return DYN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(a->mu);
+  dynhost::PoreModel& m = a->model;
+  for (uint64_t i = 0; i < m.num_kmers; ++i) {
+    m.mean[i] = in2n[2 * i];
+    m.stdev[i] = in2n[2 * i + 1];
+    m.table[i] = dynmath::make_emis(m.mean[i], m.stdev[i], std::log(m.stdev[i]));  // as PoreModel::load does
+  }
+  if (!a->host_only) {
+    HIP_TRY(a, hipSetDevice(a->device));
+    HIP_TRY(a, hipDeviceSynchronize());  // nothing that reads the old table may still be running
+    HIP_TRY(a, hipMemcpy(a->d_model.p, m.table.data(), sizeof(dynmath::Emis) * m.table.size(), hipMemcpyHostToDevice));
+  }
+  return DYN_OK;
+}
+
 int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes) {
   if (!a) return DYN_ERR_INVALID_ARGUMENT;
   a->mem_budget = bytes;

@@ -204,6 +204,7 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
     table = ManagedTable(mean0, sd0)
     trans = {p: ManagedList([v]) for p, v in transition_params.items()}
     any_seen = False
+    al = None
     i = qskips = mismatches = 0
     with open(param_file, "w") as pw:
         pw.write("epoch,batch,read," + "".join(p + "," for p in transition_params) + "Zchange\n")
@@ -224,7 +225,10 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 print("============================", file=sys.stderr)
                 print(f"{datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}: Training epoch: {e}, reads: {i}, batch: {cbatch}\n{transition_params}", file=sys.stderr)
                 cbatch += 1
-                al = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
+                # train.py:179 builds an Aligner from the model file of the previous batch; the one kept here holds exactly
+                # those values (set_model below; a float64 survives the file's shortest decimal representation unchanged)
+                if al is None:
+                    al = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
                 cur_mean, cur_sd = al.model_table()
                 res = _train_items(al, items, aggregate == "pooled", raw=not host_preprocess)
                 preZ = {}
@@ -279,8 +283,8 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 write_kmer_model_arrays(trained_model, file_kmers, k, np.asarray(new_mean)[code_of_row], np.asarray(new_sd)[code_of_row])
                 pw.flush()
                 # rerun with the new model to compare Zs (train.py:226-242)
-                al2 = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
-                post = _z_items(al2, items, raw=not host_preprocess)
+                al.set_model(new_mean, new_sd)  # = Aligner(trained_model, ...) of train.py:227
+                post = _z_items(al, items, raw=not host_preprocess)
                 dZ = np.array([float(post.Z[j]) - z for j, z in preZ.items() if post.status[j] == 0])
                 print(f"Z changes: {dZ}", file=sys.stderr)
                 if comm is not None:

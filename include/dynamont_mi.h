@@ -195,6 +195,12 @@ void dyn_release_cached_memory(void);
 int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
 /* Dense model table in k-mer-code order, (mean, stdev) interleaved, 2*num_kmers doubles. */
 int dyn_aligner_model(const dyn_aligner* a, double* out2n);
+/* Replace the model table (same layout as dyn_aligner_model: k-mer-code order, (mean, stdev) interleaved). The handle
+ * then behaves like one created from a model file holding these values -- the reference's training loop writes such a
+ * file after every batch and builds a new Aligner from it (train.py:179,221-227); a float64 survives that round trip
+ * through its shortest decimal representation unchanged. Waits for the handle's device to be idle; no asynchronous
+ * ticket of the handle may be pending. */
+int dyn_aligner_set_model(dyn_aligner* a, const double* in2n);
 /* Upper limit on HBM used for lattice workspaces (bytes; 0 = 90 % of free memory). */
 int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
 /* Strict mode (opt-in; affects align with calc_probabilities only). The reference's traceback takes exact fp64

@@ -195,3 +195,38 @@ def test_a_new_aligner_takes_over_the_parked_pool_of_its_predecessor(models):
     assert t3["pool_pages"] < t1["pool_pages"] and t3["pool_pages"] * t3["page_rows"] * 448 * 8 <= small_budget, (t1, t3)
     assert np.array_equal(r1.Z, r3.Z) and np.array_equal(r1.em_weight, r3.em_weight)
     dynamont_amd.release_cached_memory()
+
+
+def test_set_model_equals_an_aligner_built_from_the_written_file(models, tmp_path):
+    """The training loop keeps one aligner and replaces its table (dyn_aligner_set_model) where the reference builds a new
+    Aligner from the model file it has just written: same table, same results, bit for bit."""
+    from dynamont_amd import synth
+    from dynamont_amd.segmentation.utils import read_kmer_model, write_kmer_model_arrays
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(99, 24, "rna004", mean, sd, (200, 600))
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    al = Aligner(models["syn9"], "rna004", device=0)
+    m0, s0 = al.model_table()
+    rng = np.random.default_rng(3)
+    m1, s1 = m0 + 0.05 * rng.standard_normal(len(m0)), s0 * np.exp(0.2 * rng.standard_normal(len(s0)))
+    # the file the training loop would write: row r of the model file holds the k-mer with code code_of_row[r]
+    names = synth.kmer_strings(9)
+    code_of_row = synth.code_order_table(np.arange(len(names), dtype=np.float64), np.zeros(len(names)), 9, True)[0]
+    # code_order_table maps file-order values into code order: out[code] = in[row]; invert it
+    row_of_code = code_of_row.astype(np.int64)
+    code_of_row = np.empty_like(row_of_code)
+    code_of_row[row_of_code] = np.arange(len(names))
+    path = str(tmp_path / "next.model")
+    write_kmer_model_arrays(path, "".join(names).encode(), 9, m1[code_of_row], s1[code_of_row])
+    fresh = Aligner(path, "rna004", device=0)
+    al.set_model(m1, s1)
+    fm, fs = fresh.model_table()
+    am, asd = al.model_table()
+    assert np.array_equal(fm, am) and np.array_equal(fs, asd)
+    a, b = al.align_batch(sigs, seqs, True), fresh.align_batch(sigs, seqs, True)
+    assert np.array_equal(a.Z, b.Z) and np.array_equal(a.signal_positions, b.signal_positions)
+    assert np.array_equal(a.probabilities, b.probabilities)
+    ta, tb = al.train_batch(sigs, seqs), fresh.train_batch(sigs, seqs)
+    assert np.array_equal(ta.Z, tb.Z) and np.array_equal(ta.em_weight, tb.em_weight) and np.array_equal(ta.em_mean, tb.em_mean)
+    al.close()
+    fresh.close()
