@@ -244,13 +244,17 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                     trans["e1"].add(float(t[1]))
                     trans["e2"].add(float(t[2]))
                     code, m, s = res.sparse(j)
-                    dm, ds = cur_mean.copy(), cur_sd.copy()
-                    dm[code] = m
-                    ds[code] = s
-                    if dm[0] < 0.5:  # "skip weird trainings": polyA k-mer mean collapsed (train.py:198-199)
+                    # the read's dense model: the current one with the touched k-mers replaced (train.py:190-197); only the
+                    # window mean needs all of it, the "weird training" test below needs k-mer 0
+                    at0 = np.nonzero(code == 0)[0]
+                    mean0_read = float(m[at0[0]]) if len(at0) else float(cur_mean[0])
+                    if mean0_read < 0.5:  # "skip weird trainings": polyA k-mer mean collapsed (train.py:198-199)
                         continue
                     any_seen = True
                     if aggregate == "window-mean":
+                        dm, ds = cur_mean.copy(), cur_sd.copy()
+                        dm[code] = m
+                        ds[code] = s
                         table.add(dm, ds)
                 print(f"Zs: {list(preZ.values())}", file=sys.stderr)
                 if comm is not None:  # reads trained so far and pooled transition estimate over all ranks
