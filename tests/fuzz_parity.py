@@ -4,7 +4,9 @@
 
 3 000 random short reads (k .. 400 bases, dwell 0.5 .. 10) over the five pore types and four random band widths each
 against the oracle: integer columns identical, posteriors within 1e-6, Z within 1e-9 relative, failures with the
-reference's message. Round 2, final arithmetic and row loops: 0 mismatches (profiles/r02/fuzz_parity_3000_reads.txt)."""
+reference's message; round 3 also train() (Z, transitions, per-k-mer weights at 1e-7 relative, weights summing to the
+sample count) and align(calc=false) on the same reads. Round 2: 0 mismatches (profiles/r02/fuzz_parity_3000_reads.txt);
+round 3, final build: profiles/r03/fuzz_parity_3000_reads.txt."""
 import os, sys, tempfile, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +14,7 @@ from dynamont_amd import Aligner, synth
 from oracle.pyoracle import Oracle
 d = tempfile.mkdtemp()
 rng = np.random.default_rng(20261004)
-tot = bad = err = 0
+tot = bad = err = bad_train = bad_z = 0
 for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
     k = synth.PORES[pore][2]
     path = synth.write_model(os.path.join(d, f"{pore}.model"), k)
@@ -25,6 +27,8 @@ for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
         al = Aligner(path, pore, band=band, device=0)
         orc = Oracle(path, synth.PORES[pore][0], band)
         res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+        zs = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], False)
+        tr = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
         for i, r in enumerate(reads):
             try:
                 want = orc.align(r.signal, r.sequence, True)
@@ -40,5 +44,21 @@ for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
             if not ok:
                 bad += 1
                 print("MISMATCH", pore, band, i, len(r.sequence), len(r.signal), flush=True)
-        print(pore, band, "done", tot, bad, err, flush=True)
-print("TOTAL reads compared", tot, "mismatching", bad, "expected errors reproduced", err)
+            if not (zs.status[i] == 0 and abs(zs.Z[i] - want["Z"]) <= 1e-9 * max(1.0, abs(want["Z"]))):
+                bad_z += 1
+                print("Z-ONLY MISMATCH", pore, band, i, flush=True)
+            wt = orc.train(r.signal, r.sequence, dense=False)
+            code, m, _ = tr.sparse(i)
+            a = int(tr.em_offsets[i])
+            touched = np.nonzero(wt["weight"] > 0)[0]
+            okt = tr.status[i] == 0 and abs(tr.Z[i] - wt["Z"]) <= 1e-9 * max(1.0, abs(wt["Z"])) and np.array_equal(code, touched)
+            if okt:
+                gw = tr.em_weight[a:a + len(code)]
+                okt = np.allclose(gw, wt["weight"][touched], rtol=1e-7, atol=1e-12) and abs(gw.sum() - len(r.signal)) <= 1e-9 * len(r.signal)
+                okt = okt and abs(tr.transitions[3 * i] - wt["m1"]) <= 1e-8 and abs(tr.transitions[3 * i + 2] - wt["e2"]) <= 1e-8
+            if not okt:
+                bad_train += 1
+                print("TRAIN MISMATCH", pore, band, i, len(r.sequence), len(r.signal), flush=True)
+        print(pore, band, "done", tot, bad, bad_z, bad_train, err, flush=True)
+        al.close()
+print("TOTAL reads compared", tot, "align mismatching", bad, "Z-only mismatching", bad_z, "train mismatching", bad_train, "expected errors reproduced", err)
