@@ -461,7 +461,7 @@ class Aligner:
     def set_mem_budget(self, nbytes: int) -> None:
         self._L.dyn_aligner_set_mem_budget(self._h, int(nbytes))
 
-    STRICT_MODES = {"off": 0, "start": 1, "all": 2}
+    STRICT_MODES = {"off": 0, "ties": 1, "start": 1, "all": 2}  # "start": round 3's name of mode 1
 
     def set_model(self, mean, stdev) -> None:
         """Replace the model table (k-mer-code order, as model_table() returns it): the aligner then equals one built
@@ -475,12 +475,19 @@ class Aligner:
         self._model = None  # model_table() reads it back
 
     def set_strict(self, mode) -> None:
-        """dyn_aligner_set_strict: 0/"off" default arithmetic; 1/"start" reads whose first two k-mers are equal go
-        through the kernels that reproduce the reference's libm bit for bit; 2/"all" every read."""
+        """dyn_aligner_set_strict: 0/"off" plain arithmetic; 1/"ties" (the default of a new handle) reads that carry a
+        structural tie -- two neighbouring columns with the same emission parameters -- go through the kernels that
+        reproduce the reference's sums bit for bit; 2/"all" every read."""
         m = self.STRICT_MODES[mode] if isinstance(mode, str) else int(mode)
         rc = self._L.dyn_aligner_set_strict(self._h, m)
         if rc != N.DYN_OK:
-            raise ValueError("strict mode must be 0 (off), 1 (start) or 2 (all)")
+            raise ValueError(self.last_error() or "strict mode must be 0 (off), 1 (ties) or 2 (all)")
+
+    def tie_rows(self, kmers, signal_len: int) -> int:
+        """dyn_tie_rows: 0 = the read carries no structural tie; else the forward rows mode "ties" runs bit for bit
+        (0xffffffff = all)."""
+        km = np.ascontiguousarray(kmers, dtype=np.int32)
+        return int(self._L.dyn_tie_rows(self._h, _ptr(km, N.c_i32_p), len(km), int(signal_len)))
 
     def model_table(self):
         """(mean, stdev) in k-mer-code order."""

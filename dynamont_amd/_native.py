@@ -52,7 +52,9 @@ class DynTiming(C.Structure):
                 ("cells", C.c_uint64), ("samples", C.c_uint64), ("reads_ok", C.c_uint64),
                 ("launches", C.c_uint32), ("lp_inplace", C.c_uint32), ("pool_pages", C.c_uint32),
                 ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32),
-                ("reads_strict", C.c_uint32), ("reserved", C.c_uint32)]
+                ("reads_strict", C.c_uint32), ("reserved", C.c_uint32),
+                ("ms_backward_strict", C.c_double), ("ms_forward_strict", C.c_double), ("cert_fallbacks", C.c_uint64),
+                ("cert_rows", C.c_uint64)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)
@@ -68,6 +70,7 @@ SIGNATURES = {
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
+    "dyn_tie_rows": (C.c_uint32, [C.c_void_p, c_i32_p, C.c_uint64, C.c_uint64]),
     "dyn_aligner_last_error": (C.c_char_p, [C.c_void_p]),
     "dyn_read_strerror": (C.c_int, [C.c_int, C.c_char, C.c_char_p, C.c_uint64]),
     "dyn_segment_capacity": (C.c_uint64, [C.c_void_p, C.c_uint64, c_u64_p]),

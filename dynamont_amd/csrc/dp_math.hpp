@@ -266,6 +266,7 @@ DYN_HD int low_word(double m) {
 template <int M>
 struct SoftplusLookup {
   double hi[M], r[M], g0[M], s[M];
+  double diff[M];  // x - y as rounded: only the certified logPlus (dp_math_strict.hpp) reads it again, for its fallback
 };
 
 // d = lo - hi = -|x - y| (a correctly rounded difference has the same magnitude either way round);
@@ -286,9 +287,9 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
   for (int j = 0; j < M; ++j) asm volatile("" : "+v"(L.hi[j]));
 #endif
 #pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = x[j] - y[j];
+  for (int j = 0; j < M; ++j) L.diff[j] = x[j] - y[j];
 #pragma unroll
-  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(-__builtin_fabs(d[j]), -(double)SP_RANGE);  // also NaN -> -40
+  for (int j = 0; j < M; ++j) d[j] = __builtin_fmax(-__builtin_fabs(L.diff[j]), -(double)SP_RANGE);  // also NaN -> -40
 #pragma unroll
   for (int j = 0; j < M; ++j) m[j] = fma_(d[j], neg_steps, magic);
 #pragma unroll

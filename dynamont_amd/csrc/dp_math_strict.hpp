@@ -314,6 +314,15 @@ DYN_HD double log_plus_strict(double x, double y, const uint64_t* __restrict__ t
   return o[0];
 }
 
+// The same from hi = max(x, y) and diff = x - y (as rounded): lo - hi = -|diff|, a correctly rounded difference having
+// the same magnitude either way round. diff = NaN is (-inf) - (-inf): the reference returns -inf, as does hi + anything.
+DYN_HD double log_plus_strict_from(double hi, double diff, const uint64_t* __restrict__ tab) {
+  double d[1] = {max_hw(-__builtin_fabs(diff), NEG_INF)}, e[1], g[1];  // max_hw: a NaN operand loses
+  exp_strict_vec<1>(d, e, tab);
+  log1p_strict_vec<1>(e, g);
+  return hi + g[0];
+}
+
 // aligner.cpp:287-292, operation by operation. In strict mode EmisV::inv_stdev carries STDEV itself.
 template <int M>
 DYN_HD void log_normal_pdf_strict_vec(double x, const EmisV<M>& p, double (&out)[M]) {
@@ -333,6 +342,131 @@ DYN_HD void log_normal_pdf_strict_vec(double x, const EmisV<M>& p, double (&out)
 DYN_HD double log_normal_pdf_strict(double x, const Emis& p) {
   const double z = (x - p.mean) / p.stdev;
   return (((-0.5 * z) * z) + p.neg_log_stdev) - HALF_LOG_2PI;
+}
+
+// =====================================================================================================================
+// CERTIFIED arithmetic (round 4): the reference's bits at close to the default arithmetic's price.
+//
+// Restating glibc operation by operation (above) costs ~130 instructions per logPlus and three IEEE divisions per
+// cell. Almost none of that is needed to know the reference's RESULT:
+//
+//  * logPlus = hi + g, g = log1p(exp(d)) in (0, ln 2]. hi is a log-probability of magnitude 1e2 .. 1e5, so the sum is
+//    rounded to ulp(hi) ~ 1e-14 .. 1e-11 while glibc's g and the table softplus of dp_math.hpp agree to ~1e-16. Let
+//    g~ be the table value and delta = g~ 2^-50 + 2^-57. If RN(hi + (g~ - delta)) == RN(hi + (g~ + delta)) then, rounding
+//    being monotonic, EVERY g in that interval gives the same sum -- glibc's included: the sum is certified to be the
+//    reference's bit for bit without evaluating glibc's algorithm. Five fp64 operations per cell. Where the two sums
+//    differ (a rounding boundary of hi's grid falls inside the interval: probability ~ 8 g / |hi| per cell) the cell is
+//    AMBIGUOUS and its register (64 cells) is recomputed with the restated glibc algorithm, M = 1.
+//    Why glibc's g lies in the interval: glibc's exp is within 0.511 ulp (e_exp.c, "worst-case error 0.511 ULP"
+//    for the FMA build: 0.509), fdlibm's log1p within 1 ulp (s_log1p.c: "error < 1 ulp"), and d log1p(e)/de x e
+//    <= log1p(e): |g_glibc - g| <= 1.511 x 2^-52 g. The table value: node rounded to nearest from an 80-bit
+//    evaluation (<= 0.5003 x 2^-52 g, nodes within e^(1/256) of g), final FMA rounding (<= 0.5 x 2^-52 g), polynomial
+//    roundings and truncation (<= 0.01 x 2^-52 g): |g~ - g| <= 1.01 x 2^-52 g. Together 2.52 x 2^-52 g; the interval is
+//    4 x 2^-52 g~ wide on each side, minus the rounding of its own end points (0.5 x 2^-52 g each). Below d = -40 the
+//    table returns exactly 0 where glibc returns exp(d) <= 4.25e-18 < 2^-57: the absolute term.
+//    tests/test_dp_math_strict.py measures max |g~ - g_glibc| / g on 1e8 arguments (observed: 1.0 x 2^-52) and checks on
+//    as many (hi, lo) pairs that a certified sum never differs from the reference expression.
+//  * the emission's division by stdev: 1/stdev is a per-k-mer constant, correctly rounded on the host (y = RN(1/b)).
+//    q0 = a y; r0 = a - q0 b; q1 = q0 + r0 y; r1 = a - q1 b; q2 = q1 + r1 y (one multiplication, four FMAs). q1 is
+//    within 1/2 + 2^-52 ulp of a/b (faithful); Markstein's theorem (Markstein 1990; Muller et al., Handbook of
+//    Floating-Point Arithmetic, Thm. 4.9) then makes q2 = RN(a/b) for every a, provided the significand of b is not
+//    all ones (checked per model at load, dyn_aligner_set_strict refuses such a model) and nothing over- or underflows
+//    (|a| = |x - mean| <= 1e300 is enforced by the sweeps; a is 0 or >= 2^-53 |x|).
+// =====================================================================================================================
+constexpr double CERT_LO = 1.0 - 0x1p-50, CERT_HI = 1.0 + 0x1p-50, CERT_ABS = 0x1p-57;
+
+// a / b, correctly rounded, given y = RN(1/b) (see above)
+DYN_HD double div_by_const(double a, double b, double y) {
+  double q = a * y;
+  double r = fma_(-q, b, a);
+  q = fma_(r, y, q);
+  r = fma_(-q, b, a);
+  return fma_(r, y, q);
+}
+
+// is the significand of b all ones? (the one case Markstein's theorem excludes)
+inline bool div_by_const_excluded(double b) { return (bits_of(b) & 0x000fffffffffffffull) == 0x000fffffffffffffull; }
+
+// aligner.cpp:287-292 bit for bit without a division instruction: needs BOTH stdev and 1/stdev per cell
+template <int M>
+DYN_HD void log_normal_pdf_cert_vec(double x, const EmisV<M>& p, const double (&stdev)[M], double (&out)[M]) {
+  double a[M], q[M], r[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) a[j] = x - p.mean[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = a[j] * p.inv_stdev[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(-q[j], stdev[j], a[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], p.inv_stdev[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(-q[j], stdev[j], a[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], p.inv_stdev[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = (-0.5 * q[j]) * q[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = q[j] + p.neg_log_stdev[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = q[j] - HALF_LOG_2PI;
+}
+
+DYN_HD double log_normal_pdf_cert(double x, const Emis& p) {
+  const double z = div_by_const(x - p.mean, p.stdev, p.inv_stdev);
+  return (((-0.5 * z) * z) + p.neg_log_stdev) - HALF_LOG_2PI;
+}
+
+// Second half of a certified logPlus (first half: log_plus_issue of dp_math.hpp, unchanged). lo[j] == hi_[j] certifies
+// out[j] = lo[j] as the reference's sum; the caller recomputes the others with log_plus_strict.
+template <int M>
+DYN_HD void log_plus_finish_cert(const SoftplusLookup<M>& L, double (&lo)[M], double (&hi_)[M]) {
+  double u[M], w[M], p[M], q[M];
+  const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
+  const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);
+  const double cabs = vreg_const(CERT_ABS), clo = sreg_const(CERT_LO), chi = sreg_const(CERT_HI);
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = 1.0 - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) u[j] = L.s[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) w[j] = w[j] - L.s[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(u[j], m10, c120);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = q[j] * w[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(u[j], m4, c24);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(q[j], L.r[j], p[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], w[j] * (1.0 / 6.0));
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], 0.5);
+#pragma unroll
+  for (int j = 0; j < M; ++j) u[j] = u[j] * L.r[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], u[j], L.s[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], L.r[j], L.g0[j]);  // the table softplus g~ (log_plus_finish adds hi here)
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(p[j], clo, -cabs);
+#pragma unroll
+  for (int j = 0; j < M; ++j) p[j] = fma_(p[j], chi, cabs);
+#pragma unroll
+  for (int j = 0; j < M; ++j) lo[j] = L.hi[j] + q[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) hi_[j] = L.hi[j] + p[j];
+}
+
+// host form (tests, CPU replay): the certified logPlus with its fallback; *ambiguous counts the fallbacks
+inline double log_plus_cert(double x, double y, const SoftplusNode* sp_tab, const uint64_t* exp_tab, long* ambiguous) {
+  double a[1] = {x}, b[1] = {y}, lo[1], hi_[1];
+  SoftplusLookup<1> L;
+  log_plus_issue<1>(a, b, L, sp_tab);
+  log_plus_finish_cert<1>(L, lo, hi_);
+  if (lo[0] == hi_[0]) return lo[0];
+  if (ambiguous) ++*ambiguous;
+  return log_plus_strict_from(L.hi[0], L.diff[0], exp_tab);  // what the kernels' fallback calls
 }
 
 }  // namespace dynmath

@@ -399,6 +399,15 @@ int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errca
   }
 }
 
+// The certified emission forms (x - mean) / stdev from stdev and RN(1 / stdev); the one divisor that construction cannot
+// serve is a significand of all ones (dp_math_strict.hpp) -- no decimal of a model file parses to one. A handle whose
+// table holds one runs the plain kernels (strict mode 0) and refuses dyn_aligner_set_strict(1 | 2).
+static bool model_allows_strict(const dynhost::PoreModel& m) {
+  for (double sd : m.stdev)
+    if (dynmath::div_by_const_excluded(sd)) return false;
+  return true;
+}
+
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap) {
   *out = nullptr;
@@ -413,6 +422,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   a->ntk = ntk;
   try {
     a->model.load(model_path ? model_path : "", pore, band);
+    if (!model_allows_strict(a->model)) a->strict_mode = 0;
   } catch (const std::invalid_argument& e) {
     copy_msg(err, errcap, e.what());
     delete a;
@@ -531,6 +541,7 @@ int dyn_aligner_set_model(dyn_aligner* a, const double* in2n) {
     m.stdev[i] = in2n[2 * i + 1];
     m.table[i] = dynmath::make_emis(m.mean[i], m.stdev[i], std::log(m.stdev[i]));  // as PoreModel::load does
   }
+  if (a->strict_mode != 0 && !model_allows_strict(m)) a->strict_mode = 0;
   if (!a->host_only) {
     HIP_TRY(a, hipSetDevice(a->device));
     HIP_TRY(a, hipDeviceSynchronize());  // nothing that reads the old table may still be running
@@ -547,8 +558,52 @@ int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes) {
 
 int dyn_aligner_set_strict(dyn_aligner* a, int mode) {
   if (!a || mode < 0 || mode > 2) return DYN_ERR_INVALID_ARGUMENT;
+  if (mode != 0 && !model_allows_strict(a->model)) {
+    a->last_error = "strict mode: a model stdev with an all-ones significand has no division-free exact quotient";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
   a->strict_mode = mode;
   return DYN_OK;
+}
+
+}  // extern "C"
+
+namespace dyneng {
+
+// Which reads need the reference's arithmetic bit for bit, and for how many forward rows (dyn_aligner_set_strict, mode 1).
+// A STRUCTURAL TIE: two neighbouring lattice columns with the same emission parameters (equal k-mers -- the polyA pad
+// followed by A, any homopolymer of k+1 bases -- or distinct k-mers whose table entries coincide). Moving the border
+// between their segments leaves the exact score unchanged, so the traceback's comparison vE == vM_prev + LPE
+// (NT_aligner_api.cpp:445-448) is a tie in exact arithmetic wherever the path crosses them, decided by the last bits of
+// the reference's sums. Columns are compared by their (mean, stdev) bits, not by k-mer code.
+// Returns 0 for a read without such a pair; otherwise the number of forward rows that must be exact: up to the row in
+// which the LAST tied pair has left the band for good (no decision is taken on a column outside the band), UINT32_MAX
+// when that is the whole read. Z enters every posterior, so a flagged read's backward sweep is exact in full.
+uint32_t tie_rows(const dynhost::PoreModel& m, const int32_t* km, uint64_t kc, uint64_t S) {
+  int64_t last = -1;
+  for (uint64_t j = 0; j + 1 < kc; ++j) {
+    const int32_t a = km[j], b = km[j + 1];
+    if (a == b || (m.mean[a] == m.mean[b] && m.stdev[a] == m.stdev[b])) last = (int64_t)j;
+  }
+  if (last < 0) return 0;
+  const uint64_t T = S + 1, N = kc + 1;
+  const uint64_t bw = std::min<uint64_t>(m.half_band, N / 2);
+  // k-mers last, last+1 are lattice columns last+1, last+2. Row t's band starts at size_t(t N/T) - bw (NT_aligner_api.cpp:
+  // 100-104): column n is below every later band once t N/T >= n + bw + 1.
+  const uint64_t n = (uint64_t)last + 2;
+  const double ratio = (double)N / (double)T;
+  const double t_out = std::ceil((double)(n + bw + 1) / ratio) + 1.0;
+  if (!(t_out < (double)(T - 1))) return 0xffffffffu;
+  return (uint32_t)t_out;
+}
+
+}  // namespace dyneng
+
+extern "C" {
+
+uint32_t dyn_tie_rows(const dyn_aligner* a, const int32_t* kmers, uint64_t n_kmers, uint64_t signal_len) {
+  if (!a || (!kmers && n_kmers)) return 0;
+  return dyneng::tie_rows(a->model, kmers, n_kmers, signal_len);
 }
 
 const char* dyn_aligner_last_error(const dyn_aligner* a) { return a ? a->last_error.c_str() : ""; }
@@ -945,29 +1000,34 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     a->last_error = "Training is not implemented for this aligner";
     return DYN_ERR_RUNTIME;
   }
-  // Strict reads (align(calc=true) only, opt-in through dyn_aligner_set_strict) take the sweeps that reproduce the
-  // reference's libm bit for bit (dp_math_strict.hpp). Mode 2: every read, every row (3.4x the time: 137 vs 40 ms per
-  // cfg2 launch). Mode 1: reads whose first two k-mers are equal (the symmetric read-start tie, NT_aligner_api.cpp:
-  // 445-448) -- for those the backward sweep and the first STRICT_START_ROWS rows of the forward sweep: the Viterbi
-  // values of a row depend on forward values of earlier rows only, so every decision up to that row is the
-  // reference's own; later decisions have the ordinary >= 1e-6 margins. They run in the SAME launch as the others (a
-  // per-read flag, kernel variant k_read_queue<JOB, true>).
+  // Strict reads (align(calc=true) only; dyn_aligner_set_strict) take the sweeps whose every sum is certified to be the
+  // reference's bit for bit (dp_math_strict.hpp). Mode 2: every read, every row. Mode 1 (the default): the reads that carry
+  // a structural tie (tie_rows above) -- their backward sweep in full and their forward sweep up to the row in which the
+  // last tied column pair has left the band: the Viterbi values of a row depend on forward values of earlier rows only,
+  // so every decision up to that row is the reference's own; later decisions have the ordinary >= 1e-6 margins. Strict
+  // reads run in the SAME launch as the others (a per-read flag, kernel variant k_read_queue<JOB, true>).
   // Queue order: most expensive reads first, so that the tail of the launch is made of the cheapest ones.
-  constexpr uint32_t STRICT_START_ROWS = 1024;
-  const uint64_t STRICT_COST_NUM = a->strict_mode == 2 ? 17 : 23, STRICT_COST_DEN = a->strict_mode == 2 ? 5 : 10;  // measured: 3.4x / 2.3x
+  // Cost of a certified row relative to a default one (ISA instruction counts of the row loops, confirmed on the device:
+  // profiles/r04/strict_mode_cost.json): backward 1.3, forward 1.4; a read spends 0.4 / 0.6 of its time in the two sweeps.
   const int32_t* km = b->kmers();
-  std::vector<uint8_t> is_strict(b->n, 0);
+  std::vector<uint32_t> strict_rows(b->n, 0);
   std::vector<uint32_t> order;
   uint64_t n_strict = 0;
   for (uint64_t i = 0; i < b->n; ++i) {
     const HostRead& r = b->reads[i];
     if (r.status != DYN_READ_OK) continue;
     if (a->ntk) continue;  // no read reaches the device; its status is set below
-    is_strict[i] = calc && (a->strict_mode == 2 || (a->strict_mode == 1 && r.kc >= 2 && km[r.flat_off] == km[r.flat_off + 1]));
-    n_strict += is_strict[i];
+    if (calc && a->strict_mode == 2) strict_rows[i] = 0xffffffffu;
+    else if (calc && a->strict_mode == 1) strict_rows[i] = tie_rows(a->model, km + r.flat_off, r.kc, r.S);
+    n_strict += strict_rows[i] != 0;
     order.push_back((uint32_t)i);
   }
-  auto cost_rows = [&](uint32_t i) { return is_strict[i] ? (b->reads[i].S + 1) * STRICT_COST_NUM / STRICT_COST_DEN : b->reads[i].S + 1; };
+  auto is_strict = [&](uint32_t i) { return strict_rows[i] != 0; };
+  auto cost_rows_strict = [&](uint32_t i) -> uint64_t {
+    const uint64_t T = b->reads[i].S + 1, fr = std::min<uint64_t>(T, strict_rows[i]);
+    return (T * 100 + T * 12 + fr * 24) / 100;  // 0.4 T x 1.3 + 0.6 (T + 0.4 fr) = T (1 + 0.12) + 0.24 fr
+  };
+  auto cost_rows = [&](uint32_t i) { return is_strict(i) ? cost_rows_strict(i) : b->reads[i].S + 1; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost_rows(x) > cost_rows(y); });
 
   if (calc) {
@@ -1120,8 +1180,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     d.path_off = rows_total;
     d.n_pages = lattice ? pages_of(r.S) : 0;
     d.first_page = dynk::NO_PAGE;
-    d.flags = !is_strict[i] ? 0u : a->strict_mode == 2 ? dynk::READ_STRICT : dynk::READ_STRICT_START;
-    d.strict_rows = STRICT_START_ROWS;
+    d.flags = !is_strict(i) ? 0u : strict_rows[i] == 0xffffffffu ? dynk::READ_STRICT : dynk::READ_STRICT_START;
+    d.strict_rows = strict_rows[i];
     if (reserving && k < n_slots && (!lattice || (uint64_t)used_pages + d.n_pages <= pool.n_pages)) {
       d.first_page = lattice ? used_pages : 0;
       used_pages += d.n_pages;
@@ -1209,6 +1269,8 @@ int collect_timing(dyn_batch* b) {
   dyn_timing& tm = b->timing;
   tm.ms_backward = tm.ms_forward = tm.ms_trace = tm.ms_total = tm.ms_dp = 0.0;
   tm.wave_wait_share = tm.wave_occupancy = 0.0;
+  tm.ms_backward_strict = tm.ms_forward_strict = 0.0;
+  tm.cert_fallbacks = tm.cert_rows = 0;
   if (!b->n_chunks) return DYN_OK;
   hipEvent_t* ev = b->events.data();
   float ms01 = 0, ms12 = 0;
@@ -1229,6 +1291,10 @@ int collect_timing(dyn_batch* b) {
     tm.ms_forward = ms01 * (double)s[1] / life;
     tm.ms_trace = ms01 * (double)s[2] / life + ms12;
     tm.wave_wait_share = (double)s[3] / life;
+    tm.ms_backward_strict = ms01 * (double)s[6] / life;
+    tm.ms_forward_strict = ms01 * (double)s[7] / life;
+    tm.cert_fallbacks = s[8];
+    tm.cert_rows = s[9];
     if (s[5] && tm.n_waves) tm.wave_occupancy = life / ((double)s[5] * tm.n_waves);
   } else {
     tm.ms_trace = ms12;

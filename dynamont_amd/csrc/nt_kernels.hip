@@ -175,8 +175,10 @@ __device__ __forceinline__ Emis load_emis(const Emis* __restrict__ pr, int n, in
 
 // Arithmetic flavours of the sweeps.
 //  ARITH_DEFAULT  dp_math.hpp: 5-operation emission, table softplus (<= 1 ulp from glibc)
-//  ARITH_STRICT   dp_math_strict.hpp: the reference's expressions operation by operation, glibc's exp / log1p bit for
-//                 bit; the slot that normally carries 1/stdev then carries stdev itself (true IEEE division)
+//  ARITH_STRICT   dp_math_strict.hpp, "certified arithmetic": the reference's bits. The emission's quotient is formed exactly
+//                 from 1/stdev and stdev (one multiplication, four FMAs, no division); a logPlus is the table softplus plus
+//                 a rounding certificate (5 operations), and only the registers that hold an AMBIGUOUS sum -- one whose
+//                 rounding could depend on the last bits of glibc's log1p(exp()) -- are recomputed with the restated glibc
 //  ARITH_FOLDED   train() only (its backward sweep; the forward sweep is the posterior chain): emission ln K - u^2 in two
 //                 fused operations, softplus polynomial of degree 3. No integer decision hangs on the last bits there,
 //                 unlike in the align sweeps: train()'s outputs are sums of posteriors
@@ -185,7 +187,6 @@ constexpr int ARITH_DEFAULT = 0, ARITH_STRICT = 1, ARITH_FOLDED = 2;
 template <int ARITH>
 __device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
   p.set(j, e);
-  if (ARITH == ARITH_STRICT) p.inv_stdev[j] = e.stdev;
   if (ARITH == ARITH_FOLDED) {  // train(): ln P = ln K - u^2, u = x c - mu c, c = 1/(stdev sqrt 2) -- two fused operations
     const double c = e.inv_stdev * 0x1.6a09e667f3bcdp-1;
     p.inv_stdev[j] = c;
@@ -194,10 +195,12 @@ __device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
   }
 }
 
-template <int ARITH>
-__device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, double (&out)[CPL]) {
+// stdev: ARITH_STRICT only (the divisor of the reference's quotient, beside its reciprocal in p)
+template <int ARITH, int NS>
+__device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, const double (&stdev)[NS], double (&out)[CPL]) {
   if constexpr (ARITH == ARITH_STRICT) {
-    dynmath::log_normal_pdf_strict_vec<CPL>(x, p, out);
+    static_assert(NS == CPL, "strict emission needs every cell's stdev");
+    dynmath::log_normal_pdf_cert_vec<CPL>(x, p, stdev, out);
   } else if constexpr (ARITH == ARITH_FOLDED) {
     double u[CPL];
 #pragma unroll
@@ -206,6 +209,38 @@ __device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, doub
     for (int j = 0; j < CPL; ++j) out[j] = dynmath::fma_(-u[j], u[j], p.neg_log_stdev[j]);
   } else {
     log_normal_pdf_vec<CPL>(x, p, out);
+  }
+}
+
+// Second half of a certified logPlus (dp_math_strict.hpp): out = the reference's sum bit for bit. The registers in which
+// some lane's certificate failed (a rounding boundary inside the interval: ~1e-4 of the cells of a 20 k-sample read,
+// profiles/r04/cert_ambiguity.json) are recomputed with the restated glibc -- for all 64 lanes of that register: where the
+// certificate held, the restated value IS the certified one.
+__device__ __forceinline__ void log_plus_finish_certified(const SoftplusLookup<CPL>& L, double (&out)[CPL], const uint64_t* exp_tab,
+                                                          uint32_t& fallbacks) {
+  double hi[CPL];
+  dynmath::log_plus_finish_cert<CPL>(L, out, hi);
+  unsigned amb = 0;  // wave-uniform: bit j = some lane's certificate failed in register j
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) amb |= __any(out[j] != hi[j]) ? 1u << j : 0u;
+  if (__builtin_expect(amb != 0, 0)) {
+    // ONE copy of the restated glibc (M = 1) for whichever registers need it: the operands are picked by the uniform
+    // register number (a select chain: ~30 instructions per pass, next to ~130 of the restatement itself). Unrolled by
+    // register, the seven copies cost the hot loop 100 spilled VGPRs.
+#pragma unroll 1
+    for (int j = 0; j < CPL; ++j) {
+      if (!((amb >> j) & 1u)) continue;
+      ++fallbacks;
+      double hj = L.hi[0], dj = L.diff[0];
+#pragma unroll
+      for (int k = 1; k < CPL; ++k) {
+        hj = (j == k) ? L.hi[k] : hj;
+        dj = (j == k) ? L.diff[k] : dj;
+      }
+      const double v = dynmath::log_plus_strict_from(hj, dj, exp_tab);
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) out[k] = (j == k) ? v : out[k];
+    }
   }
 }
 
@@ -326,8 +361,9 @@ template <bool STORE, int ARITH>
 __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveCtx& w,
                                                  const double* __restrict__ sig,
                                                  const Emis* __restrict__ par, double* __restrict__ ws,
-                                                 double m1, double e2, const SoftplusNode* s_tab) {
+                                                 double m1, double e2, const SoftplusNode* s_tab, uint32_t* fallbacks = nullptr) {
   const int lane = w.lane;
+  uint32_t nfb = 0;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
   const double ratio = rd.ratio;
   const double* __restrict__ sg = sig + rd.sig_off;
@@ -341,6 +377,14 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
   int n[CPL];
   double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], e[CPL];
   EmisV<CPL> p;
+  double p_stdev[ARITH == ARITH_STRICT ? CPL : 1];  // certified arithmetic: the divisor itself, beside its reciprocal
+  auto set_p = [&](int j, const Emis& em) {
+    set_emis<ARITH>(p, j, em);
+    if constexpr (ARITH == ARITH_STRICT) p_stdev[j] = em.stdev;
+  };
+  // the exact quotient of the certified emission must not overflow (dp_math_strict.hpp); such a sample makes the reference's
+  // z*z infinite, every cell of its row -inf and Z = -inf: the same verdict as an infinite sample
+  constexpr double SAMPLE_MAX = ARITH == ARITH_STRICT ? 1e300 : 1.7976931348623157e308;
   {
     // one row past the lattice, all -inf: bM(T-1, .) = bE(T, .) + e has no successor. It lets the
     // forward sweep stream row t+1 for every t without a last-row special case in its row loop.
@@ -349,7 +393,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     for (int j = 0; j < CPL; ++j) {
       const int slot = lane * CPL + j;
       n[j] = lo + pmod(slot - lo);
-      set_emis<ARITH>(p, j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
+      set_p(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));  // columns above the band: no k-mer yet
       bE[j] = (n[j] == n_init) ? 0.0 : NEG_INF;
       bM[j] = NEG_INF;
     }
@@ -363,9 +407,9 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     const int base = thi - 63;
     const int idx = base + lane;
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
-    bad_sample |= !(fabs(xs) <= 1.7976931348623157e308);  // inf or NaN
+    bad_sample |= !(fabs(xs) <= SAMPLE_MAX);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
-    emission_vec<ARITH>(readlane_f64(xs, 63), p, e);  // e(thi+1, n) from sig[thi]
+    emission_vec<ARITH>(readlane_f64(xs, 63), p, p_stdev, e);  // e(thi+1, n) from sig[thi]
     // one lattice row: reads (bE_in, bM_in) = row t+1, writes (bE_out, bM_out) = row t; the loop is unrolled by two and
     // ping-pongs between the two pairs (see forward_sweep: no register moves at the loop's back edge)
     auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
@@ -389,7 +433,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         for (int j = 0; j < CPL; ++j) {
           if (n[j] == leaving) {
             n[j] = new_lo;
-            set_emis<ARITH>(p, j, fresh);
+            set_p(j, fresh);
           }
           // Upper band edge: bM(t, top) = A must not see the in-band cell (t+1, top); Y keeps it for
           // the diagonal into (t, top-1). From row t on the slot carries the "no k-mer" parameters, so
@@ -399,7 +443,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
           // e = -inf before anything reads it.
           if (n[j] == top) {
             bM_out[j] = NEG_INF;
-            set_emis<ARITH>(p, j, none);
+            set_p(j, none);
           }
         }
         lo = new_lo;
@@ -409,8 +453,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x2[j] = bM_out[j] + e2;
       SoftplusLookup<CPL> L;
-      if constexpr (ARITH == ARITH_STRICT) dynmath::log_plus_strict_vec<CPL>(x1, x2, bE_out, strict_tab(s_tab));
-      else log_plus_issue<CPL>(x1, x2, L, s_tab);
+      log_plus_issue<CPL>(x1, x2, L, s_tab);
       // while the LDS lookups are in flight: emission of the NEXT row, e(t, n) = logN(sig[t-1]; .)
       // (rows are consumed top-down; at i == 0 the next block's sample is not loaded yet: the value computed
       //  here is thrown away and that one emission is computed after the block switch above. Unconditional on
@@ -418,10 +461,11 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       //  in every row)
       {
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
-        emission_vec<ARITH>(xnext, p, e);
+        emission_vec<ARITH>(xnext, p, p_stdev, e);
       }
       if constexpr (ARITH == ARITH_FOLDED) dynmath::log_plus_finish3<CPL>(L, bE_out);  // train(): no decision hangs on it
-      else if constexpr (ARITH != ARITH_STRICT) log_plus_finish<CPL>(L, bE_out);
+      else if constexpr (ARITH == ARITH_STRICT) log_plus_finish_certified(L, bE_out, strict_tab(s_tab), nfb);
+      else log_plus_finish<CPL>(L, bE_out);
       const size_t rt = STORE ? (size_t)cur.at(w, t) * P : 0;
       // streamed once, read back by the forward sweep ~100 MB later: non-temporal (-2 %)
       if constexpr (STORE && ARITH == ARITH_FOLDED) {
@@ -457,6 +501,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
   // samples are flagged here and reported through the same Z check (NaN samples, for which the
   // reference's behaviour is undefined, fail the same way).
   const bool any_bad = __any(bad_sample);
+  if (ARITH == ARITH_STRICT && fallbacks) *fallbacks += nfb;
   // lattice column 0 sits in slot 0 at row 0 (lo = -bw)
   return any_bad ? NEG_INF : readlane_f64(bE[0], 0);
 }
@@ -489,9 +534,11 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
                                                 const double* __restrict__ sig, const Emis* __restrict__ par,
                                                 const double* __restrict__ ws_rd, float* __restrict__ lp_out,
                                                 uint64_t* __restrict__ bits, double Z, double m1, double e2,
-                                                const SoftplusNode* s_tab, unsigned ring_base, int strict_rows = 0) {
-  // STRICT instantiation: rows t <= strict_rows are computed with the bit-for-bit arithmetic, later rows with the default
-  // one (strict_rows = INT_MAX: the whole sweep). The Viterbi values of a row depend on forward values of rows <= t only,
+                                                const SoftplusNode* s_tab, unsigned ring_base, int strict_rows = 0,
+                                                uint32_t* fallbacks = nullptr) {
+  uint32_t nfb = 0;
+  // STRICT instantiation: rows t <= strict_rows are computed with the certified (bit-for-bit) arithmetic, later rows with the
+  // default one (strict_rows = INT_MAX: the whole sweep). The Viterbi values of a row depend on forward values of rows <= t only,
   // so with a strict backward sweep every decision up to row strict_rows is the reference's own.
   const int lane = w.lane;
   const int T = (int)rd.T, N = (int)rd.N, bw = (int)rd.bw, W = 2 * bw + 1;
@@ -542,21 +589,11 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   auto emission = [&](bool strict_row, double x, double (&out)[CPL]) {
     if constexpr (STRICT) {
       if (strict_row) {
-        double z[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) z[j] = x - p.mean[j];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) z[j] = z[j] / p_stdev[j];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) z[j] = (-0.5 * z[j]) * z[j];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) z[j] = z[j] + p.neg_log_stdev[j];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) out[j] = z[j] - dynmath::HALF_LOG_2PI;
+        dynmath::log_normal_pdf_cert_vec<CPL>(x, p, p_stdev, out);
         return;
       }
     }
-    if constexpr (!POST) emission_vec<ARITH_FOLDED>(x, p, out);
+    if constexpr (!POST) emission_vec<ARITH_FOLDED>(x, p, p_stdev, out);
     else log_normal_pdf_vec<CPL>(x, p, out);
   };
   const double x0 = sg[0];
@@ -581,7 +618,9 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   }
 
   // one lattice row: reads the state `in` (row t-1), writes `out` (row t)
-  auto row = [&](auto check_move, int t, double xn, const RowState& in, RowState& out) {
+  // strict_tag: a row of a STRICT block (certified arithmetic, its look-ahead emission included)
+  auto row = [&](auto check_move, auto strict_tag, int t, double xn, const RowState& in, RowState& out) {
+    constexpr bool STRICT_ROW = STRICT && decltype(strict_tag)::value;
     double fEl[CPL], vEl[CPL];
     if (POST) {
       // bE(t+1, .) from the ring; its slot is then refilled with row t+1+RING_D (clamped to the
@@ -619,9 +658,11 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     for (int j = 0; j < CPL; ++j) a1[j] = in.fM[j] + in.e[j];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) a2[j] = (in.fE[j] + in.e[j]) + e2;
-    if (STRICT && t <= strict_rows) {  // wave-uniform
-      dynmath::log_plus_strict_vec<CPL>(a1, a2, out.fE, strict_tab(s_tab));
-      emission(t + 1 <= strict_rows, xn, out.e);  // e(t+1, .) belongs to row t+1
+    if constexpr (STRICT_ROW) {
+      SoftplusLookup<CPL> L;
+      log_plus_issue<CPL>(a1, a2, L, s_tab);
+      emission(true, xn, out.e);  // e(t+1, .): exact, whichever flavour row t+1 runs in
+      log_plus_finish_certified(L, out.fE, strict_tab(s_tab), nfb);
     } else {
       SoftplusLookup<CPL> L;
       log_plus_issue<CPL>(a1, a2, L, s_tab);
@@ -701,17 +742,32 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     asm volatile("" ::"v"(xs));
     const int iend = min(64, T - tb);
     int i = 0;
+    // whole 64-row blocks are strict or not (rows past strict_rows inside a strict block cost a little and harm nothing):
+    // two row loops, each with one arithmetic, instead of a branch and both arithmetics' registers in every row
+    if (STRICT && tb <= strict_rows) {
 #pragma unroll 1
-    for (; i + 1 < iend; i += 2) {
-      row(std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-      row(std::true_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
-    }
-    if (i < iend) {  // odd tail (last block of a read only): one more row, then the roles are swapped back
-      row(std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-      sa = sb;
+      for (; i + 1 < iend; i += 2) {
+        row(std::true_type{}, std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+        row(std::true_type{}, std::true_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
+      }
+      if (i < iend) {
+        row(std::true_type{}, std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+        sa = sb;
+      }
+    } else {
+#pragma unroll 1
+      for (; i + 1 < iend; i += 2) {
+        row(std::true_type{}, std::false_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+        row(std::true_type{}, std::false_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
+      }
+      if (i < iend) {  // odd tail (last block of a read only): one more row, then the roles are swapped back
+        row(std::true_type{}, std::false_type{}, tb + i, readlane_f64(xs, i), sa, sb);
+        sa = sb;
+      }
     }
   }
   const double (&fE)[CPL] = sa.fE;
+  if (STRICT && fallbacks) *fallbacks += nfb;
   if (POST) wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring
   const int nf = band_mid(T - 1, ratio);
   const int sf = pmod(nf);
@@ -1132,7 +1188,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
   const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[wave][0][0];
   lds_u64_t* sb = (lds_u64_t*)&s_ring[wave][0][0];  // traceback staging: the ring is idle by then
 
-  uint64_t cyc_b = 0, cyc_f = 0, cyc_t = 0, cyc_w = 0;
+  uint64_t cyc_b = 0, cyc_f = 0, cyc_t = 0, cyc_w = 0, cyc_bs = 0, cyc_fs = 0, rows_cert = 0;
+  uint32_t n_fallback = 0;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
   uint32_t* ctl = q.pool.ctl;
   uint32_t have = 0;  // pages in this wave's table
@@ -1183,12 +1240,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     }
     if (MIXED && strict) {
       const int strict_rows = (rd.flags & READ_STRICT) ? 0x7fffffff : (int)rd.strict_rows;
-      Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
+      Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab, &n_fallback);
       t2 = __builtin_amdgcn_s_memtime();
+      rows_cert += (uint64_t)rd.T + (uint64_t)min((int)rd.T, strict_rows);
       if (JOB == JOB_ALIGN_INPLACE)
-        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
+        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows, &n_fallback);
       else
-        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows);
+        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows, &n_fallback);
     } else {
       if constexpr (JOB == JOB_TRAIN) {
         // backward sweep in the log domain (the emission's constant folded), then the posterior chain
@@ -1210,6 +1268,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     cyc_b += t2 - t1;
     const uint64_t t3 = __builtin_amdgcn_s_memtime();
     cyc_f += t3 - t2;
+    if (MIXED && strict) {
+      cyc_bs += t2 - t1;
+      cyc_fs += t3 - t2;
+    }
 
     int status = z_ok(rd, Zf, Zb) ? 0 : q.z_fail_status;
     uint32_t n_seg = 0;
@@ -1249,6 +1311,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
     atomicAdd(&stats[4], life);
     atomicMax(&stats[5], life);
+    if (MIXED) {
+      atomicAdd(&stats[6], (unsigned long long)cyc_bs);
+      atomicAdd(&stats[7], (unsigned long long)cyc_fs);
+      atomicAdd(&stats[8], (unsigned long long)n_fallback);
+      atomicAdd(&stats[9], (unsigned long long)rows_cert);
+    }
   }
 }
 

@@ -90,14 +90,15 @@ struct PagePool {
   // stack, [3] abort (a wave gave up waiting: the queue drains, the host reports the launch as failed),
   // [4] reads whose pages are in place, [5] waves waiting for pages.
   // ctl + QUEUE_STATS (64-bit words): wave-cycles spent in backward, forward, traceback, waiting for pages,
-  // lifetime (all summed over the waves of the launch), longest lifetime.
+  // lifetime (all summed over the waves of the launch), longest lifetime; then the strict reads apart: their backward and
+  // forward wave-cycles, registers recomputed by the certified logPlus' fallback, rows run in the certified arithmetic.
   uint32_t* ctl;
   int log_rows;         // rows per page = 1 << log_rows
   uint32_t n_pages;
 };
 constexpr int QUEUE_CTL_WORDS = 32;   // 32-bit words reserved for ctl (stats start at word 8, 8-byte aligned)
 constexpr int QUEUE_STATS = 8;        // first stats word (as uint32 index)
-constexpr int QUEUE_N_STATS = 6;
+constexpr int QUEUE_N_STATS = 10;
 
 enum QueueJob { JOB_Z = 0, JOB_ALIGN = 1, JOB_ALIGN_INPLACE = 2, JOB_TRAIN = 3 };
 

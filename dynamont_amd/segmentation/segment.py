@@ -52,9 +52,10 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
     p.add_argument("--depth", type=int, default=3, help="batches inside the asynchronous engine at once")
-    p.add_argument("--strict-ties", type=str, default="off", choices=["off", "start", "all"],
-                   help="reproduce the reference's libm bit for bit (dyn_aligner_set_strict): 'start' for reads whose first "
-                        "two k-mers are equal (read-start structural ties), 'all' for every read; ~3.4x the time for those reads")
+    p.add_argument("--strict-ties", type=str, default="ties", choices=["off", "ties", "start", "all"],
+                   help="reproduce the reference's sums bit for bit (dyn_aligner_set_strict): 'ties' (default; 'start' is its "
+                        "old name) for reads with a structural tie -- two neighbouring columns with the same emission "
+                        "parameters, e.g. polyA pad + A --, 'all' for every read (1.3-1.4x), 'off' for none")
     p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same bytes)")
     p.add_argument("--parallel-zstd-frames", action="store_true",
                    help="write the CSV as consecutive independent zstd frames (readers must read across frames: "
@@ -401,7 +402,7 @@ class _NativePipeline:
 
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
-            host_preprocess: bool = False, depth: int = 3, strict_ties: str = "off") -> None:
+            host_preprocess: bool = False, depth: int = 3, strict_ties: str = "ties") -> None:
     """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
     on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
     the writer (reads are independent; the gather is the only exchange)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 3
+#define DYN_ABI_VERSION 4
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -169,6 +169,12 @@ typedef struct dyn_timing {
   uint32_t n_waves;      /* persistent waves launched */
   uint32_t reads_strict; /* reads that went through the strict kernels (dyn_aligner_set_strict) */
   uint32_t reserved;
+  /* (ABI 4) the strict reads of the launch apart: their share of ms_backward / ms_forward, and how often a register of 64
+   * sums had to be recomputed with the restated glibc because a certificate could not decide it */
+  double ms_backward_strict;
+  double ms_forward_strict;
+  uint64_t cert_fallbacks;
+  uint64_t cert_rows;    /* lattice rows computed in the certified arithmetic (both sweeps) */
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
@@ -203,20 +209,29 @@ int dyn_aligner_model(const dyn_aligner* a, double* out2n);
 int dyn_aligner_set_model(dyn_aligner* a, const double* in2n);
 /* Upper limit on HBM used for lattice workspaces (bytes; 0 = 90 % of free memory). */
 int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
-/* Strict mode (opt-in; affects align with calc_probabilities only). The reference's traceback takes exact fp64
- * comparisons (NT_aligner_api.cpp:445-448); where the first two lattice columns carry the same k-mer (every RNA read
- * that starts with the polyA pad + A, any read starting with a homopolymer of k+1 bases) such a comparison is a tie in
- * exact arithmetic and the reference's choice rests on the last bits of glibc's exp/log1p inside logPlus
- * (aligner.cpp:276-285). The default kernels use a table softplus that is <= 1 ulp away from those and reproduce
- * 997 of 1 000 such reads (tests/golden/g10_ties.npz lists the three); the strict kernels restate glibc 2.35's
- * x86-64 exp (FMA variant) and fdlibm log1p and the reference's emission expression bit for bit.
- *   mode 0: off (default)
- *   mode 1: reads whose first two k-mers are equal take the strict backward sweep (Z becomes bit-identical) and the
- *           strict arithmetic for the first 1 024 rows of the forward sweep -- the Viterbi values of a row depend on
- *           forward values of earlier rows only, so every decision up to there is the reference's own; 2.3x the time
- *           of such a read
- *   mode 2: every read, every row of both sweeps; 3.4x */
+/* Strict mode (affects align with calc_probabilities only). The reference's traceback takes exact fp64 comparisons
+ * (NT_aligner_api.cpp:445-448). Where two neighbouring lattice columns carry the same emission parameters (every RNA
+ * read that starts with the polyA pad + A, any homopolymer of k+1 bases, distinct k-mers with coinciding table entries)
+ * moving the border between their segments leaves the exact score unchanged: such a comparison is a tie in exact
+ * arithmetic and the reference's choice rests on the last bits of glibc's exp/log1p inside logPlus (aligner.cpp:
+ * 276-285). The plain kernels use a table softplus that is <= 1 ulp away from those and reproduce 3 397 of the 3 400
+ * such reads of tests/golden/g10_ties.npz. The strict kernels reproduce the reference's sums bit for bit at 1.3-1.4x
+ * the price of a row ("certified arithmetic", dynamont_amd/csrc/dp_math_strict.hpp): the emission's quotient formed
+ * exactly from stdev and 1/stdev, each logPlus from the table softplus plus a certificate that its rounded sum cannot
+ * depend on the last bits of the softplus, and glibc 2.35's x86-64 exp (FMA variant) / fdlibm log1p restated operation
+ * by operation for the ~1e-4 of the sums the certificate cannot decide.
+ *   mode 0: off
+ *   mode 1: (DEFAULT) every read with such a pair of columns (dyn_tie_rows != 0) takes the strict backward sweep (Z
+ *           becomes bit-identical) and the strict arithmetic for the forward rows up to the one in which the last tied
+ *           pair has left the band -- the Viterbi values of a row depend on forward values of earlier rows only, so every
+ *           decision up to there is the reference's own, and no decision is taken on a column outside the band
+ *   mode 2: every read, every row of both sweeps
+ * Returns DYN_ERR_INVALID_ARGUMENT for an unknown mode, and for modes 1/2 on a model holding a stdev whose significand
+ * is all ones (no division-free exact quotient exists for that one divisor; no decimal parses to it). */
 int dyn_aligner_set_strict(dyn_aligner* a, int mode);
+/* The rule of mode 1 for one read, given its k-mer codes (dyn_validate_batch) and signal length: 0 = no structural tie;
+ * otherwise the number of forward rows that run in the strict arithmetic (UINT32_MAX: all of them). Host only. */
+uint32_t dyn_tie_rows(const dyn_aligner* a, const int32_t* kmers, uint64_t n_kmers, uint64_t signal_len);
 /* Message of the last failing call on this handle (thread-unsafe like the handle itself). */
 const char* dyn_aligner_last_error(const dyn_aligner* a);
 /* Reference exception text for a per-read status (bad_char fills "Invalid nucleotide: X"). */

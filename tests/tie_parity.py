@@ -14,7 +14,9 @@ Modes of the shim: 0 = libm (must reproduce the oracle exactly), 1 = the product
 (1/(stdev sqrt 2) folded into the constant), 4 = the product's logPlus with the reference's emission,
 5 = the product's emission with the difference folded into an FMA (z = fma(x, 1/stdev, -mean/stdev), one operation
 fewer), 6 = the STRICT arithmetic (dp_math_strict.hpp: glibc's exp and log1p restated bit for bit, the reference's
-emission expression). Measured on 1 000 reads: 0 / 3 / 11 / 17 / 3 / 14 / 0 reads differ.
+emission expression), 7 = the CERTIFIED arithmetic of round 4 (table softplus + rounding certificate, the restated glibc
+only for ambiguous sums; division-free exact emission) -- what the kernels run for flagged reads.
+Measured on 1 000 reads: 0 / 3 / 11 / 17 / 3 / 14 / 0 / 0 reads differ.
 """
 from __future__ import annotations
 
@@ -40,6 +42,8 @@ SHIM = r'''
 #include <vector>
 static std::vector<dynmath::SoftplusNode> TAB;
 static int g_mode = 1;
+static long g_calls = 0, g_ambiguous = 0;
+extern "C" void replay_counts(long* out) { out[0] = g_calls; out[1] = g_ambiguous; g_calls = g_ambiguous = 0; }
 extern "C" void replay_mode(int m) {
   g_mode = m;
   if (TAB.empty()) { TAB.resize(dynmath::SP_NODES); dynmath::softplus_build_table(TAB.data()); }
@@ -52,6 +56,7 @@ extern "C" double nto_hook_pdf(double x, double mean, double sd) {
   switch (g_mode) {
     case 0: case 4: return libm_pdf(x, mean, sd);
     case 6: return dynmath::log_normal_pdf_strict(x, dynmath::make_emis(mean, sd, std::log(sd)));
+    case 7: return dynmath::log_normal_pdf_cert(x, dynmath::make_emis(mean, sd, std::log(sd)));
     case 2: { const double z = (x - mean) * (1.0 / sd); return dynmath::fma_(-0.5 * z, z, -std::log(sd) - dynmath::HALF_LOG_2PI); }
     case 3: { const double k = (double)(1.0L / ((long double)sd * 1.41421356237309504880168872420969808L));
               const double y = (x - mean) * k; return dynmath::fma_(-y, y, -std::log(sd) - dynmath::HALF_LOG_2PI); }
@@ -68,6 +73,7 @@ extern "C" double nto_hook_log_plus(double x, double y) {
     return x + std::log1p(std::exp(y - x));
   }
   if (g_mode == 6) return dynmath::log_plus_strict(x, y, dynmath::strict_exp_table());
+  if (g_mode == 7) { ++g_calls; return dynmath::log_plus_cert(x, y, TAB.data(), dynmath::strict_exp_table(), &g_ambiguous); }
   double a[1] = {x}, b[1] = {y}, o[1];
   dynmath::SoftplusLookup<1> L;
   dynmath::log_plus_issue<1>(a, b, L, TAB.data());
@@ -104,6 +110,12 @@ class Replay(pyoracle.Oracle):
 
     def set_mode(self, mode: int):
         self.lib.replay_mode(int(mode))
+
+    def counts(self):
+        """mode 7: (logPlus calls, ambiguous ones) since the last call"""
+        out = (C.c_long * 2)()
+        self.lib.replay_counts(out)
+        return int(out[0]), int(out[1])
 
 
 def tie_reads(n: int, mean, sd, pore: str = "rna002", seed: int = 5000):
@@ -211,7 +223,7 @@ if __name__ == "__main__":
     for mode, name in ((0, "libm primitives (sanity: the oracle itself)"), (1, "product arithmetic (dp_math.hpp)"),
                        (4, "reference emission + product logPlus"), (2, "4-operation emission of rounds 1-2 + product logPlus"),
                        (3, "3-operation emission + product logPlus"), (5, "z = fma(x, 1/sd, -mean/sd), reference tail + product logPlus"),
-                       (6, "strict arithmetic (dp_math_strict.hpp)")):
+                       (6, "strict arithmetic (dp_math_strict.hpp)"), (7, "certified arithmetic (table softplus + certificate)")):
         rp.set_mode(mode)
         bad = differing_reads(rp, reads, want)
         print(f"{name:55s}: {len(bad):3d} of {sum(w is not None for w in want)} reads with borders differing from the reference")

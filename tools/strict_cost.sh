@@ -4,7 +4,7 @@
 out=gpurun_out/${1:-strict}
 mkdir -p $out
 for w in cfg2 cfg4_share; do
-  for m in off start all; do
+  for m in off ties all; do
     python bench.py --steps 6 --warmup 2 --no-cpu-baseline --workload $w --strict $m > $out/strict_cost_${w}_$m.json 2> $out/strict_cost_${w}_$m.err || exit 1
   done
 done
