@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--strict", default="ties", choices=["off", "ties", "start", "all"],
                     help="dyn_aligner_set_strict; 'ties' is what a new handle does (reads with a structural tie run bit for "
                          "bit) and what the bench line is quoted in; 'off' / 'all' are experiments, not bench lines")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e_cli` record (N = 1: the whole CLI on a synthetic .pod5 + basecall file)")
+    ap.add_argument("--e2e-reads", type=int, default=32768, help="reads of the e2e_cli dataset (a multiple of 4 096: that many distinct reads, repeated)")
+    ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
                     help="align = the headline metric; train = Baum-Welch statistics pass (config 5 shape, secondary)")
     return ap.parse_args()
@@ -104,13 +107,68 @@ def load_traffic():
     return None
 
 
+def run_e2e_cli(n_reads: int, workdir: str, strict: str) -> dict:
+    """north_star's "throughput on synthetic pod5+bam": the dynamont-resquiggle counterpart end to end, in this process.
+    A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
+    dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
+    Timed: model load, BAM parse, pod5 open + VBZ decode, pA calibration + normalisation + Hampel on the device, the
+    DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool is the
+    one the bench's own handle has just parked (a fresh process allocates it: ~1 s on clean VRAM)."""
+    from dynamont_amd import synth
+    from dynamont_amd.segmentation import segment as seg
+    d = os.path.join(workdir, "e2e")
+    os.makedirs(d, exist_ok=True)
+    model = synth.write_model(os.path.join(d, "syn9.model"), 9, seed=7, stdev=0.15)
+    _, mean, sd = synth.read_model_file(model)
+    distinct = max(1, min(n_reads, 4096))
+    rep = max(1, n_reads // distinct)
+    t0 = time.perf_counter()
+    reads = synth.make_reads(5, distinct, "rna004", mean, sd, 2000)
+    raw, bam, _ = synth.write_dataset(os.path.join(d, "in"), "ds", reads, "rna004", seed=1, container="pod5", replicate=rep, basecalls="bam")
+    samples = sum(len(r.signal) for r in reads) * rep
+    del reads
+    t_gen = time.perf_counter() - t0
+    out = os.path.join(d, "out.csv")
+    t0 = time.perf_counter()
+    seg.main(["-r", os.path.join(d, "in"), "-b", bam, "-o", out, "--mode", "basic", "-p", "rna004", "--model_path", model,
+              "--batch-reads", "1024", "--strict-ties", strict])
+    dt = time.perf_counter() - t0
+    err = out + ".errors" if os.path.exists(out + ".errors") else None
+    rec = {"value": round(samples / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "reads": distinct * rep,
+           "reads_per_s": round(distinct * rep / dt, 1), "samples": samples,
+           "input": f"{os.path.basename(raw)} ({os.path.getsize(raw) / 1e6:.0f} MB, VBZ) + {os.path.basename(bam)} ({os.path.getsize(bam) / 1e6:.1f} MB); "
+                    f"{distinct} distinct synthetic rna004 reads x {rep}, written by synth.write_dataset in {t_gen:.1f} s (not timed)",
+           "output": f"out.csv.zst, {os.path.getsize(out + '.zst') / 1e6:.1f} MB" if os.path.exists(out + ".zst") else None,
+           "error_lines": sum(1 for _ in open(err)) if err else 0, "strict_mode": strict,
+           "timed": "segment.main: model load, BAM parse, pod5 VBZ decode, device preprocessing, DP, CSV format, zstd, write",
+           "not_timed": "interpreter start-up, lattice pool allocation (the bench handle's parked pool is taken over)"}
+    return rec
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (never exec: see the GPU box's rules; nothing in this process has touched the GPU or imported torch yet), hand its
+    output through and return its exit code."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): the line would not be an N = {args.gpus} measurement")
     n_gpus = world
     workload = args.workload or ("cfg5_share" if args.mode == "train" else ("cfg2" if n_gpus == 1 else "cfg4_share"))
 
@@ -148,6 +206,8 @@ def main():
     backend = os.environ.get("DYN_BENCH_BACKEND", "nccl")
     if os.environ.get("DYN_BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif torch.cuda.device_count() < n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but only {torch.cuda.device_count()} device(s) visible; refusing to measure fewer GPUs than asked for")
     torch.cuda.set_device(local_rank)
     use_dist = n_gpus > 1 or bool(os.environ.get("DYN_BENCH_FORCE_DIST"))
     if use_dist:
@@ -326,6 +386,36 @@ def main():
                 best = tm0 if best is None or tm0["ms_total"] < best["ms_total"] else best
             resident = best
 
+    # ---- what bit-exactness costs: the same steps on the plain arithmetic (strict mode off), outside the headline region
+    plain = None
+    if args.mode == "align" and args.strict != "off" and not args.no_plain:
+        keep = (collections.Counter(kern), collections.Counter(launches), done_steps[0])
+        al.set_strict("off")
+        p_steps = min(6, args.steps)
+        run(args.warmup + args.steps, 1, False)
+        sync()
+        tp = time.perf_counter()
+        run(args.warmup + args.steps + 1, p_steps, True)
+        sync()
+        p_el = time.perf_counter() - tp
+        p_samples = sum(samples_of[s % n_batches] for s in range(args.warmup + args.steps + 1, args.warmup + args.steps + 1 + p_steps))
+        if use_dist:
+            t = torch.tensor([p_el, -float(p_samples)], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
+            p_el = float(t[0].item())
+            p_samples *= n_gpus
+        p_launch = max(1, launches["launches"] - keep[1]["launches"])
+        plain = {"strict_mode": "off", "steps": p_steps, "value": round(p_samples / p_el / 1e6, 3), "unit": "Msamp/s",
+                 "ms_per_step": round(p_el * 1e3 / p_steps, 3),
+                 "avg_launch_ms": round((kern["ms_dp"] - keep[0]["ms_dp"]) / p_launch, 3),
+                 "note": "the table softplus alone: equal to the reference on every read without a structural tie, and on "
+                         "3 397 of the 3 400 tie-bearing reads of tests/golden/g10_ties.npz"}
+        al.set_strict(args.strict)
+        kern.clear(); kern.update(keep[0])
+        launches.clear(); launches.update(keep[1])
+        done_steps[0] = keep[2]
+
+    line = None
     if rank == 0:
         steps = max(1, done_steps[0])
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -353,6 +443,9 @@ def main():
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": tbytes,
+            # NOT a counter of this run: the committed rocprofv3 --pmc passes over the same command (plain arithmetic: the
+            # certified rows move the same bytes), quoted only for the workload and layout they were measured on
+            "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, round %s)" % traffic.get("round")) if tbytes else None,
             "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
             "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": n_launch,
             "avg_launch_ms": round(ms_dp, 3),
@@ -403,8 +496,17 @@ def main():
             line["cpu_baseline"] = json.load(open(cpu_out))
         elif n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = None
+        if plain is not None:
+            line["plain_arithmetic"] = plain
+        assert line["n_gpus"] == args.gpus
+    al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
+    if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
+        try:
+            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, {"start": "ties"}.get(args.strict, args.strict))
+        except Exception as e:  # the headline stands on its own
+            line["e2e_cli"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
         print(json.dumps(line))
-    al.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -164,16 +164,18 @@ def _bgzf_block(payload: bytes) -> bytes:
 def write_bam(path: str, records) -> None:
     """Minimal uBAM writer (tests / synthetic datasets): floats as 'f' (single precision, as dorado
     writes sm/sd/qs), ints as 'i', strings as 'Z'."""
-    enc = {c: i for i, c in enumerate(_SEQ_DECODE)}
+    enc_lut = np.full(256, 15, dtype=np.uint8)  # anything outside the 16 IUPAC codes is stored as N
+    for i, c in enumerate(_SEQ_DECODE):
+        enc_lut[ord(c)] = i
     out = bytearray(b"BAM\x01")
     text = b"@HD\tVN:1.6\tSO:unknown\n"
     out += struct.pack("<i", len(text)) + text + struct.pack("<i", 0)
     for name, seq, tags in records:
         nm = name.encode() + b"\0"
-        codes = [enc.get(c.upper(), 15) for c in seq]
+        codes = enc_lut[np.frombuffer(seq.upper().encode("latin-1"), dtype=np.uint8)]
         if len(codes) % 2:
-            codes.append(0)
-        packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+            codes = np.append(codes, np.uint8(0))
+        packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
         tagb = bytearray()
         for k, v in tags.items():
             if isinstance(v, int):

@@ -580,10 +580,12 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   // POST = false is align(calc_probabilities=false): Z both ways and their agreement, no decision taken -- the cheap
   // arithmetic of train()'s backward sweep (two-operation emission, degree-3 softplus polynomial; Z moves by 1e-12
   // relative, the bar is 1e-9)
-  auto set_p = [&](int j, const Emis& e) {
+  // with_stdev: the certified rows' emission also needs the divisor itself; rows past the strict ones must not keep it
+  // alive (14 more registers in a loop that has none to spare: 44 AGPR moves per row pair)
+  auto set_p = [&](int j, const Emis& e, auto with_stdev) {
     if constexpr (!POST) set_emis<ARITH_FOLDED>(p, j, e);
     else p.set(j, e);
-    if constexpr (STRICT) p_stdev[j] = e.stdev;
+    if constexpr (STRICT && decltype(with_stdev)::value) p_stdev[j] = e.stdev;
   };
   // emission of one sample against the lane's cells, in the flavour of the row it belongs to
   auto emission = [&](bool strict_row, double x, double (&out)[CPL]) {
@@ -602,7 +604,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   for (int j = 0; j < CPL; ++j) {
     const int slot = lane * CPL + j;
     n[j] = lo + pmod(slot - lo);
-    set_p(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0));
+    set_p(j, load_emis(pr, n[j], (n[j] <= lo + W - 1) ? N : 0), std::true_type{});
     sa.fE[j] = (n[j] == 0) ? 0.0 : NEG_INF;  // E[bandwidth+1] = 0 (NT_aligner_api.cpp:120)
     sa.fM[j] = NEG_INF;
     sa.vE[j] = sa.fE[j];                     // E[bandwidth+1] = 0 (NT_aligner_api.cpp:336)
@@ -645,8 +647,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
           // and fE/vE(t-1, lo) stay where this row and the right neighbour (fEl/vEl) still read them.
           const bool leaves = n[j] == lo;
           n[j] = leaves ? lo + P : n[j];
-          if (leaves) set_p(j, none);
-          if (n[j] == lo + W) set_p(j, entering);  // first band row of this column is t+1
+          if (leaves) set_p(j, none, strict_tag);
+          if (n[j] == lo + W) set_p(j, entering, strict_tag);  // first band row of this column is t+1
         }
         lo = next_lo;
       }
@@ -733,7 +735,8 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     }
   };
 
-  for (int tb = 1; tb < T; tb += 64) {
+  // one 64-row block of samples; strict_tag: the block's rows run in the certified arithmetic
+  auto block = [&](auto strict_tag, int tb) {
     const int idx = tb + lane;  // sig[t] is the sample of lattice row t+1
     const double xs = (idx < T - 1) ? sg[idx] : 0.0;
     // The block's samples must have ARRIVED before the row loop starts: hipcc otherwise places the
@@ -742,30 +745,25 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
     asm volatile("" ::"v"(xs));
     const int iend = min(64, T - tb);
     int i = 0;
-    // whole 64-row blocks are strict or not (rows past strict_rows inside a strict block cost a little and harm nothing):
-    // two row loops, each with one arithmetic, instead of a branch and both arithmetics' registers in every row
-    if (STRICT && tb <= strict_rows) {
 #pragma unroll 1
-      for (; i + 1 < iend; i += 2) {
-        row(std::true_type{}, std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-        row(std::true_type{}, std::true_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
-      }
-      if (i < iend) {
-        row(std::true_type{}, std::true_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-        sa = sb;
-      }
-    } else {
-#pragma unroll 1
-      for (; i + 1 < iend; i += 2) {
-        row(std::true_type{}, std::false_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-        row(std::true_type{}, std::false_type{}, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
-      }
-      if (i < iend) {  // odd tail (last block of a read only): one more row, then the roles are swapped back
-        row(std::true_type{}, std::false_type{}, tb + i, readlane_f64(xs, i), sa, sb);
-        sa = sb;
-      }
+    for (; i + 1 < iend; i += 2) {
+      row(std::true_type{}, strict_tag, tb + i, readlane_f64(xs, i), sa, sb);
+      row(std::true_type{}, strict_tag, tb + i + 1, readlane_f64(xs, i + 1), sb, sa);
     }
+    if (i < iend) {  // odd tail (last block of a read only): one more row, then the roles are swapped back
+      row(std::true_type{}, strict_tag, tb + i, readlane_f64(xs, i), sa, sb);
+      sa = sb;
+    }
+  };
+  // Whole 64-row blocks are strict or not (rows past strict_rows inside a strict block cost a little and harm nothing), and
+  // the strict blocks are a PREFIX: two loops one after the other, each with one arithmetic -- the second one never sees
+  // the certified emission's extra operands (p_stdev is dead there). Same-box A/B against one loop that picks the
+  // arithmetic per block: launch 51.3 vs 52.8 ms on cfg2 with 26 % tie reads.
+  int tb = 1;
+  if constexpr (STRICT) {
+    for (; tb < T && tb <= strict_rows; tb += 64) block(std::true_type{}, tb);
   }
+  for (; tb < T; tb += 64) block(std::false_type{}, tb);
   const double (&fE)[CPL] = sa.fE;
   if (STRICT && fallbacks) *fallbacks += nfb;
   if (POST) wait_vmcnt<0>();  // the clamped tail DMAs still target this wave's LDS ring

@@ -387,14 +387,21 @@ def write_pod5(path: str, read_ids: list[str], adcs: list[np.ndarray], cal_offse
                            metadata={b"MINKNOW:pod5_version": b"0.3.2", b"MINKNOW:software": b"dynamont_amd",
                                      b"MINKNOW:file_identifier": str(uuid.uuid4()).encode()})
     sig_ids, sig_vals, sig_n, read_rows = [], [], [], []
-    for rid, adc in zip(read_ids, adcs):
-        adc = np.ascontiguousarray(adc, dtype=np.int16)
+    packed = {}  # the same array object handed in again (a replicated synthetic dataset) is compressed once
+    for rid, adc_in in zip(read_ids, adcs):
+        adc = np.ascontiguousarray(adc_in, dtype=np.int16)
         rows = []
         for s in range(0, max(len(adc), 1), chunk_samples):
             part = adc[s:s + chunk_samples]
             rows.append(len(sig_ids))
             sig_ids.append(uuid.UUID(rid).bytes)
-            sig_vals.append(vbz_compress(part) if compress else part.tolist())
+            if compress:
+                key = (id(adc_in), s)
+                if key not in packed:
+                    packed[key] = vbz_compress(part)
+                sig_vals.append(packed[key])
+            else:
+                sig_vals.append(part.tolist())
             sig_n.append(len(part))
         read_rows.append(rows)
 

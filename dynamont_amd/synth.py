@@ -174,7 +174,7 @@ def pack_reads(reads: list[SynthRead]):
 
 def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, seed: int = 0,
                   drop_polya_every: int = 3, lead: int = 37, sm: float = 90.0, sd: float = 15.0,
-                  container: str = "npz", pod5_chunk_samples: int = 102400):
+                  container: str = "npz", pod5_chunk_samples: int = 102400, replicate: int = 1, basecalls: str = "tsv"):
     """Write reads as the vendor-free containers of ``dynamont_amd.pod5_io``: ``<name>.dynraw.npz``
     (int16 ADC + calibration) and ``<name>.dynbam.tsv`` (the BAM fields segment.py:222-256 reads).
 
@@ -184,14 +184,17 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
     Returns (raw_path, basecalls_path, expected) where expected[i] = (normalised float64 signal the
     harness must reconstruct, aligner-orientation sequence).
     ``container="pod5"`` writes ``<name>.pod5`` (``dynamont_amd.pod5_native.write_pod5``, UUID read ids)
-    instead of the .npz container."""
+    instead of the .npz container; ``basecalls="bam"`` writes ``<name>.bam`` (``dynamont_amd.bam_io.write_bam``: an
+    unaligned BAM with the tags dorado writes, sm/sd/qs single precision) instead of the TSV.
+    ``replicate`` > 1 writes every read that many times under distinct read ids (the whole list, then again): a large
+    dataset for throughput runs from a small number of generated reads. ``expected`` covers the first copy."""
     import os
     import uuid
     _, rna, _k = PORES[pore]
     raw_name = f"{name}.pod5" if container == "pod5" else f"{name}.dynraw.npz"
     rng = np.random.default_rng(seed)
     scale, offset = 0.1755, -240.0
-    adcs, offs, ids, rows, expected = [], [0], [], [], []
+    adcs, offs, ids, rows, expected, records = [], [0], [], [], [], []
     for i, r in enumerate(reads):
         pa = r.signal * sd + sm
         adc = np.rint(pa / scale - offset).astype(np.int16)
@@ -210,22 +213,38 @@ def write_dataset(outdir: str, name: str, reads: list[SynthRead], pore: str, see
             bam_seq = seq
         qs = float(np.round(rng.uniform(8.0, 20.0), 3))
         rows.append(f"{rid}\t{bam_seq}\t{qs}\t*\t{len(full)}\t{lead}\t*\t{raw_name}\t{sm}\t{sd}\n")
+        records.append((rid, bam_seq, {"qs": qs, "ns": len(full), "ts": lead, "fn": raw_name, "sm": float(sm), "sd": float(sd)}))
         # what the harness reconstructs: float64((adc+offset)*scale in float32), -sm, /sd
         pa32 = (adc.astype(np.float32) + np.float32(offset)) * np.float32(scale)
         x = pa32.astype(np.float64)
         x -= sm
         x /= sd
         expected.append((x, seq if not rna else ("A" * 9 + bam_seq[::-1] if not bam_seq[::-1].startswith("A" * 9) else bam_seq[::-1])))
+    n0 = len(reads)
+    for rep in range(1, max(1, replicate)):
+        for i in range(n0):
+            j = rep * n0 + i
+            rid = str(uuid.UUID(int=(seed << 64) | j)) if container == "pod5" else f"read-{seed}-{j:05d}"
+            ids.append(rid)
+            adcs.append(adcs[i])  # the same array object: write_pod5 compresses it once
+            offs.append(offs[-1] + len(adcs[i]))
+            rows.append(rid + rows[i][rows[i].index("\t"):])
+            records.append((rid, records[i][1], records[i][2]))
     os.makedirs(outdir, exist_ok=True)
     raw = os.path.join(outdir, raw_name)
     if container == "pod5":
         from dynamont_amd.pod5_native import write_pod5
-        write_pod5(raw, ids, adcs, np.full(len(reads), offset), np.full(len(reads), scale), chunk_samples=pod5_chunk_samples)
+        write_pod5(raw, ids, adcs, np.full(len(ids), offset), np.full(len(ids), scale), chunk_samples=pod5_chunk_samples)
     else:
         np.savez(raw, read_ids=np.array(ids), offsets=np.array(offs, dtype=np.int64), adc=np.concatenate(adcs),
-                 cal_scale=np.full(len(reads), scale), cal_offset=np.full(len(reads), offset))
-    bam = os.path.join(outdir, f"{name}.dynbam.tsv")
-    with open(bam, "w") as w:
-        w.write("query_name\tsequence\tqs\tpi\tns\tts\tsp\tfn\tsm\tsd\n")
-        w.writelines(rows)
+                 cal_scale=np.full(len(ids), scale), cal_offset=np.full(len(ids), offset))
+    if basecalls == "bam":
+        from dynamont_amd.bam_io import write_bam
+        bam = os.path.join(outdir, f"{name}.bam")
+        write_bam(bam, records)
+    else:
+        bam = os.path.join(outdir, f"{name}.dynbam.tsv")
+        with open(bam, "w") as w:
+            w.write("query_name\tsequence\tqs\tpi\tns\tts\tsp\tfn\tsm\tsd\n")
+            w.writelines(rows)
     return raw, bam, expected

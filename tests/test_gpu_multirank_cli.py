@@ -67,3 +67,26 @@ def test_train_two_ranks_allreduce(models, tmp_path):
     ra, rb = open(tmp_path / "single" / "params.csv").read().splitlines(), open(tmp_path / "multi" / "params.csv").read().splitlines()
     assert ra[0] == rb[0] and rb[1].startswith("0,1,8,")
     assert abs(float(ra[1].split(",")[-1]) - float(rb[1].split(",")[-1])) <= 1e-6
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher (what a driver may type): bench.py starts its two ranks itself as a
+    child torch.distributed.run and prints ONE line that says n_gpus 2. Rehearsal hooks: both ranks on cuda:0, gloo
+    (a 1-GPU box cannot host two RCCL ranks). Without the hooks the same command must refuse a box with one device
+    instead of measuring one GPU and calling it two."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DYN_BENCH_ONE_DEVICE="1", DYN_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg2_small",
+           "--no-plain"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["strict_mode"] == "ties" and len(d["per_rank_ms"]) == 2
+    env.pop("DYN_BENCH_ONE_DEVICE")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "refusing to measure fewer GPUs" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
