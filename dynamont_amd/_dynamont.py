@@ -745,19 +745,23 @@ class RcclComm:
 
     __del__ = close
 
-    def gather_rows(self, batch, root: int = 0, total_rows_hint: int = 0):
+    def gather_rows(self, batch, root: int = 0):
         """(rows, counts): on ``root`` a structured array of every rank's segment rows in rank order; elsewhere rows is
-        None. ``batch``: an aligned Batch or an AsyncBatch ticket. ``total_rows_hint``: capacity to provide on root
-        (default: n_ranks x this rank's own count, retried with the exact total if that was too small)."""
+        None. ``batch``: an aligned Batch or an AsyncBatch ticket. Two collectives: the counts (dyn_comm_gather_counts),
+        then -- root's buffer allocated for exactly their sum -- the rows. A rank whose batch failed still takes part in
+        both (with 0 rows) before its error is raised here, so its peers never block on it."""
         counts = np.zeros(self.n_ranks, dtype=np.uint64)
-        own = int(batch.capacity) if hasattr(batch, "capacity") else int(batch.result.cap)
-        cap = int(total_rows_hint) or max(1, own * self.n_ranks)
-        rows = np.empty(cap, dtype=self.ROW) if self.rank == root else None
+        rc1 = self._L.dyn_comm_gather_counts(self._h, batch._h, _ptr(counts, N.c_u64_p))
+        err1 = (self._L.dyn_comm_last_error(self._h) or b"").decode()
+        total = int(counts.sum())
+        rows = np.empty(max(1, total), dtype=self.ROW) if self.rank == root else None
         rc = self._L.dyn_comm_gather_rows(self._h, batch._h, int(root), rows.ctypes.data if rows is not None else None,
-                                          cap if rows is not None else 0, _ptr(counts, N.c_u64_p))
+                                          total if rows is not None else 0, None)
+        if rc1 != N.DYN_OK:
+            _raise(rc1, err1)
         if rc != N.DYN_OK:
             _raise(rc, (self._L.dyn_comm_last_error(self._h) or b"").decode())
-        return (rows[:int(counts.sum())] if rows is not None else None), counts
+        return (rows[:total] if rows is not None else None), counts
 
     def allreduce_pooled(self, batch, num_kmers: int) -> np.ndarray:
         out = np.empty(3 * int(num_kmers))

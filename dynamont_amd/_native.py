@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
 SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "rccl_comm.cpp", "model_format.cpp",
-           "nt_kernels.hip"]
+           "nt_kernels.hip", "pool_stats.hip"]
 HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
@@ -91,6 +91,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_u64_p]),
     "dyn_csv_sink_error_line": (C.c_int, [C.c_void_p, C.c_char_p]),
     "dyn_csv_sink_completed": (C.c_uint64, [C.c_void_p]),
+    "dyn_csv_sink_failed": (C.c_int, [C.c_void_p]),
     "dyn_csv_sink_close": (C.c_int, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, C.c_char_p, C.c_uint64]),
     "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                    C.POINTER(C.c_void_p)]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     "dyn_comm_create": (C.c_int, [c_u8_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_comm_destroy": (None, [C.c_void_p]),
     "dyn_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "dyn_comm_gather_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_u64_p]),
     "dyn_comm_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, c_u64_p]),
     "dyn_comm_allreduce_pooled": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "dyn_multi_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.c_int,

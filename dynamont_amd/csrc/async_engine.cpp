@@ -204,9 +204,8 @@ int Pipeline::front_stage(dyn_batch* b) {
     if (rs.vbz) {
       // POD5 chunks, still compressed: every helper thread decodes whole reads (zstd + svb16 + zigzag + delta, the
       // decode ONT's pod5 library does inside record.signal) and copies the [start:end) slice into the staging buffer
-      std::atomic<int> failed{0};
-      std::string first_error;
-      std::mutex err_mu;
+      // A chunk that does not decode fails ITS read (status DYN_READ_BAD_SIGNAL, the slice zero-filled, no lattice work
+      // for it) -- the reference's worker reports one line for such a read and goes on (segment.py:178-187).
       const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 4)));
       helpers.parallel_for(parts, [&](int t) {
         std::vector<uint8_t> tmp;
@@ -217,7 +216,6 @@ int Pipeline::front_stage(dyn_batch* b) {
           uint64_t total = 0;
           for (uint64_t c = rs.vbz_read_off[i]; c < rs.vbz_read_off[i + 1]; ++c) total += rs.vbz_samples[c];
           bool ok = rs.vbz_skip[i] + len <= total;
-          if (!ok) err = "VBZ: the read's chunks hold fewer samples than its [start:end) slice needs";
           if (ok && whole.size() < total) whole.resize(total);
           uint64_t pos = 0;
           for (uint64_t c = rs.vbz_read_off[i]; ok && c < rs.vbz_read_off[i + 1]; ++c) {
@@ -226,16 +224,12 @@ int Pipeline::front_stage(dyn_batch* b) {
           }
           if (ok) {
             std::memcpy(h_raw + h_offs[i] * 2, whole.data() + rs.vbz_skip[i], len * 2);
-          } else if (!failed.exchange(1)) {
-            std::lock_guard<std::mutex> lk(err_mu);
-            first_error = err + " (read " + std::to_string(i) + " of the batch)";
+          } else {
+            std::memset(h_raw + h_offs[i] * 2, 0, len * 2);
+            if (b->reads[i].status == DYN_READ_OK) b->reads[i].status = DYN_READ_BAD_SIGNAL;  // (each read has one writer)
           }
         }
       });
-      if (failed.load()) {
-        b->error = first_error;
-        return DYN_ERR_RUNTIME;
-      }
     } else if (rs.scattered) {  // one pointer per read: the gather into the staging buffer IS the only host copy
       const void* const* slices = static_cast<const void* const*>(rs.raw);
       const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 8)));

@@ -229,7 +229,10 @@ struct dyn_csv_sink {
       if (it.res->status[i] == DYN_READ_OK) continue;
       char msg[128];
       dyn_read_strerror(it.res->status[i], it.res->bad_char ? it.res->bad_char[i] : 0, msg, sizeof msg);
-      std::string line = std::string("error: native, ") + msg + "\tT: " + std::to_string(it.signal_lengths[i]) + "\tN: " +
+      // a read whose signal could not be read fails in the reference's WORKER, before the aligner (segment.py:178-187)
+      const bool worker = it.res->status[i] == DYN_READ_BAD_SIGNAL;
+      std::string line = std::string(worker ? "error: worker, " : "error: native, ") + msg +
+                         (worker ? std::string() : "\tT: " + std::to_string(it.signal_lengths[i])) + "\tN: " +
                          std::to_string(it.seq_offsets[i + 1] - it.seq_offsets[i]) + "\tRid: " + it.readids[i] + "\tSid: " + it.signalids[i];
       write_error_line(line);
     }
@@ -307,6 +310,7 @@ int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, cons
   {
     std::lock_guard<std::mutex> lk(s->m);
     if (s->closing) return DYN_ERR_INVALID_ARGUMENT;
+    if (s->failed) return DYN_ERR_RUNTIME;  // a batch, the compressor or the file has failed: dyn_csv_sink_close has the message
     s->items.push_back(Item{a, ticket, res, n_reads, seqs, seq_offsets, readids, signalids, sig_offsets, signal_lengths});
   }
   s->cv_items.notify_one();
@@ -326,6 +330,12 @@ int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line) {
 }
 
 uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s) { return s ? s->completed.load() : 0; }
+
+int dyn_csv_sink_failed(dyn_csv_sink* s) {
+  if (!s) return 1;
+  std::lock_guard<std::mutex> lk(s->m);
+  return s->failed ? 1 : 0;
+}
 
 int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compressed_bytes, uint64_t* error_lines, char* err,
                        uint64_t errcap) {

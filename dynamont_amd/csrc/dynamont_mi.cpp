@@ -302,7 +302,7 @@ namespace dyneng {
 void attach_cache(dyn_batch* b) {
   dyneng::BufCache* c = &b->a->cache;
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
-                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_poolwork, &b->d_pooltemp, &b->d_pp,
                     &b->d_pathn, &b->d_norm, &b->d_meta})
     d->cache = c;
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->cache = c;
@@ -631,6 +631,7 @@ int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
     case DYN_READ_INTERNAL: s = "Traceback left the lattice"; break;
     case DYN_READ_TOO_LARGE: s = "Read too large for the device memory budget"; break;
     case DYN_READ_NTK_MISMATCH: s = "NTK alignment failed: alignment scores do not match"; break;
+    case DYN_READ_BAD_SIGNAL: s = "Signal could not be decoded"; break;
     default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
   }
   copy_msg(buf, cap, s);
@@ -810,7 +811,7 @@ void dyn_batch_destroy(dyn_batch* b) {
   if (b->async && b->a && b->a->pipe) (void)b->a->pipe->wait(b);  // returns at once when the batch is done
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
-                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_pp,
+                    &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_poolwork, &b->d_pooltemp, &b->d_pp,
                     &b->d_pathn, &b->d_norm, &b->d_meta})
     d->release();
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->release();
@@ -1052,6 +1053,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     HIP_TRY(a, b->d_trans.ensure(std::max<uint64_t>(16, b->n * 16)));
     HIP_TRY(a, b->d_pooled.ensure(3 * m.num_kmers * 8));
     HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->stream));
+    HIP_TRY(a, b->d_poolwork.ensure(std::max<size_t>(8, dynk::pool_stats_work_bytes(b->total_cols))));
+    HIP_TRY(a, b->d_pooltemp.ensure(std::max<size_t>(8, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers))));
   }
 
   // HBM budget for the page pool
@@ -1257,7 +1260,9 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
   if (calc) dynk::launch_segments(q.descs, nr, max_T, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
   if (job == DynJob::Train)
-    dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers, a->stream);
+    HIP_TRY(a, dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers,
+                                       b->total_cols, b->d_poolwork.p, b->d_pooltemp.p, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers),
+                                       a->stream));
   HIP_TRY(a, hipEventRecord(ev[2], a->stream));
   HIP_TRY(a, hipEventRecord(b->ev_done, a->stream));
   HIP_TRY(a, hipGetLastError());

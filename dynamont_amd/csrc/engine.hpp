@@ -156,7 +156,7 @@ struct dyn_batch {
   uint64_t total_cols = 0;     // sum of kc over ok reads
   uint32_t max_T = 0, max_N = 0;
   dyneng::DevBuf d_sig, d_kmers, d_par, d_state, d_rows, d_segrow, d_medhi, d_medlo, d_descs;
-  dyneng::DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled;
+  dyneng::DevBuf d_colw, d_cols1, d_cols2, d_trans, d_pooled, d_poolwork, d_pooltemp;
   dyneng::DevBuf d_pp, d_pathn;                // per-row path arrays (traceback -> k_median / k_final)
   dyneng::PinnedBuf h_descs, h_state, h_rows;  // h_state/h_rows: D2H targets of the asynchronous path
   dyneng::PinnedBuf h_stats;                   // wave-cycle statistics of the read-queue launch

@@ -1569,30 +1569,6 @@ void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pooled sufficient statistics for the multi-GPU M-step (BASELINE.json config 5): every lattice
-// column of every successfully trained read adds its (w, s1, s2) to its k-mer's bins. One fp64
-// atomic per statistic per column; ~2 000 columns per read spread over 4^k bins, so contention
-// is negligible. (The per-read results of dyn_batch_fetch_train are summed on the host in column
-// order instead and are bitwise reproducible; this pooled form is for the all-reduce.)
-// ---------------------------------------------------------------------------------------------
-__global__ void k_pool_stats(const ReadDesc* __restrict__ descs, const ReadState* __restrict__ st,
-                             const int32_t* __restrict__ kmers, TrainBuffers tb,
-                             double* __restrict__ pooled, uint64_t num_kmers) {
-  const ReadDesc rd = descs[blockIdx.y];
-  if (st[rd.read].status != 0) return;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // column index - 1
-  if (c >= (int)rd.N - 1) return;
-  const uint64_t i = rd.par_off + c;
-  const int32_t code = kmers[i];
-  const double w = tb.col_w[i];
-  if (w > 0.0) {
-    atomicAdd(&pooled[code], w);
-    atomicAdd(&pooled[num_kmers + code], tb.col_s1[i]);
-    atomicAdd(&pooled[2 * num_kmers + code], tb.col_s2[i]);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
@@ -1633,16 +1609,6 @@ void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_
     hipLaunchKernelGGL(k_median, dim3((max_T + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb);
     hipLaunchKernelGGL(k_median_long, dim3(nr), dim3(256), 0, s, descs + r0, st, tb);
     hipLaunchKernelGGL(k_final, dim3((max_N + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, tb, rows, kmer_size);
-  }
-}
-
-void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
-                       const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,
-                       hipStream_t s) {
-  for (int r0 = 0; r0 < n_reads; r0 += MAX_GRID_Y) {
-    const int nr = std::min(MAX_GRID_Y, n_reads - r0);
-    hipLaunchKernelGGL(k_pool_stats, dim3((max_N + 255) / 256, nr), dim3(256), 0, s, descs + r0, st, kmers, tb,
-                       pooled, num_kmers);
   }
 }
 

@@ -137,9 +137,13 @@ void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n
 // per-segment median posterior + output rows for all reads of descs (after launch_read_queue)
 void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
                      TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s);
-// pooled[3*num_kmers] += per-k-mer (w, s1, s2) of the reads in descs (fp64 atomics)
-void launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st,
-                       const int32_t* kmers, TrainBuffers tb, double* pooled, uint64_t num_kmers,
-                       hipStream_t s);
+// pooled[3*num_kmers] (zeroed by the caller) = per-k-mer (w, s1, s2) of the ok reads in descs, summed in a FIXED order:
+// per read over its columns ascending, then over the reads in input order -- bit for bit the host's sum (pool_stats.hip).
+// work: pool_stats_work_bytes(total_cols) device bytes; temp: pool_stats_temp_bytes(...) (rocprim's radix sort).
+size_t pool_stats_temp_bytes(uint64_t total_cols, uint64_t num_kmers);
+size_t pool_stats_work_bytes(uint64_t total_cols);
+hipError_t launch_pool_stats(const ReadDesc* descs, int n_reads, uint32_t max_N, const ReadState* st, const int32_t* kmers,
+                             TrainBuffers tb, double* pooled, uint64_t num_kmers, uint64_t total_cols, void* work, void* temp,
+                             size_t temp_bytes, hipStream_t s);
 
 }  // namespace dynk

@@ -27,6 +27,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -62,6 +63,7 @@ struct Rccl {
     DYN_R(GetUniqueId, "ncclGetUniqueId");
     DYN_R(CommInitRank, "ncclCommInitRank");
     DYN_R(CommDestroy, "ncclCommDestroy");
+    DYN_R(CommAbort, "ncclCommAbort");
     DYN_R(GetErrorString, "ncclGetErrorString");
     DYN_R(GroupStart, "ncclGroupStart");
     DYN_R(GroupEnd, "ncclGroupEnd");
@@ -90,7 +92,20 @@ struct dyn_comm {
   void* d_recv = nullptr;        // root: gathered rows
   size_t recv_bytes = 0;
   std::string last_error;
+  // rows every rank announced in the last dyn_comm_gather_counts (the exchange dyn_comm_gather_rows then performs)
+  std::vector<uint64_t> counts;
+  bool counts_valid = false;
+  bool aborted = false;
 };
+
+// A failure BETWEEN the collectives of one exchange (an allocation on the root, an RCCL call inside the group) would leave
+// the peers blocked in their half of it: the communicator is aborted instead, so that their pending operations return
+// with an error. The handle is unusable afterwards (every later call fails).
+static void abort_comm(dyn_comm* c) {
+  if (c->comm && !c->aborted) (void)g_rccl.CommAbort(c->comm);
+  c->comm = nullptr;
+  c->aborted = true;
+}
 
 #define C_TRY(c, expr)                                                                     \
   do {                                                                                     \
@@ -166,7 +181,7 @@ void dyn_comm_destroy(dyn_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  if (c->comm && !c->aborted) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_recv) (void)hipFree(c->d_recv);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -175,88 +190,145 @@ void dyn_comm_destroy(dyn_comm* c) {
 
 const char* dyn_comm_last_error(const dyn_comm* c) { return c ? c->last_error.c_str() : ""; }
 
+// hipError / ncclResult inside an exchange that has begun: abort the communicator, then fail
+#define C_TRY_X(c, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      (c)->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr; \
+      abort_comm(c);                                                                       \
+      return DYN_ERR_DEVICE;                                                               \
+    }                                                                                      \
+  } while (0)
+#define N_TRY_X(c, expr)                                                                        \
+  do {                                                                                          \
+    ncclResult_t _r = (expr);                                                                   \
+    if (_r != ncclSuccess) {                                                                    \
+      (c)->last_error = std::string("RCCL error: ") + g_rccl.GetErrorString(_r) + " at " #expr; \
+      abort_comm(c);                                                                            \
+      return DYN_ERR_DEVICE;                                                                    \
+    }                                                                                           \
+  } while (0)
+
+// rows this rank contributes: 0 when its batch failed (the error is kept; the rank still takes part in the collectives)
+static int local_rows(dyn_comm* c, dyn_batch* b, void** d_rows, uint64_t* n_rows) {
+  *d_rows = nullptr;
+  *n_rows = 0;
+  int rc = dyn_batch_wait(b);  // asynchronous tickets: the rows exist once the batch is complete
+  if (rc != DYN_OK) {
+    c->last_error = std::string("this rank's batch failed: ") + dyn_aligner_last_error(b->a);
+    return rc;
+  }
+  rc = dyn_batch_device_results(b, d_rows, n_rows, nullptr);
+  if (rc != DYN_OK) {
+    c->last_error = "dyn_comm_gather: the batch has not been aligned";
+    *d_rows = nullptr;
+    *n_rows = 0;
+  }
+  return rc;
+}
+
+int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out) {
+  if (!c || !b) return DYN_ERR_INVALID_ARGUMENT;
+  if (c->aborted) {
+    c->last_error = "the communicator was aborted by an earlier failure";
+    return DYN_ERR_DEVICE;
+  }
+  void* d_rows = nullptr;
+  uint64_t mine = 0;
+  const int local_rc = local_rows(c, b, &d_rows, &mine);  // a failed batch announces 0 rows: the peers must not hang
+  C_TRY_X(c, hipSetDevice(c->device));
+  C_TRY_X(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+  N_TRY_X(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
+  c->counts.assign((size_t)c->n_ranks, 0);
+  C_TRY_X(c, hipMemcpyAsync(c->counts.data(), c->d_counts, sizeof(uint64_t) * c->counts.size(), hipMemcpyDeviceToHost, c->stream));
+  C_TRY_X(c, hipStreamSynchronize(c->stream));
+  c->counts_valid = true;
+  if (counts_out) std::memcpy(counts_out, c->counts.data(), sizeof(uint64_t) * c->counts.size());
+  return local_rc;
+}
+
 int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* rows_out, uint64_t rows_cap,
                          uint64_t* counts_out) {
   if (!c || !b || root < 0 || root >= c->n_ranks) return DYN_ERR_INVALID_ARGUMENT;
-  int rc = dyn_batch_wait(b);  // asynchronous tickets: the rows exist once the batch is complete
-  if (rc != DYN_OK) {
-    c->last_error = dyn_aligner_last_error(b->a);
-    return rc;
+  if (c->aborted) {
+    c->last_error = "the communicator was aborted by an earlier failure";
+    return DYN_ERR_DEVICE;
   }
-  void* d_rows = nullptr;
-  uint64_t cap = 0;
-  rc = dyn_batch_device_results(b, &d_rows, &cap, nullptr);
-  if (rc != DYN_OK) {
-    c->last_error = "dyn_comm_gather_rows: the batch has not been aligned";
-    return rc;
+  int local_rc = DYN_OK;
+  if (!c->counts_valid) {  // one-call form: the count exchange first (collective on every rank alike)
+    local_rc = dyn_comm_gather_counts(c, b, nullptr);
+    if (c->aborted) return DYN_ERR_DEVICE;
   }
-  C_TRY(c, hipSetDevice(c->device));
-  // every rank learns every rank's row count (8 bytes each)
-  const uint64_t mine = cap;
-  C_TRY(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-  N_TRY(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
-  std::vector<uint64_t> counts((size_t)c->n_ranks);
-  C_TRY(c, hipMemcpyAsync(counts.data(), c->d_counts, sizeof(uint64_t) * counts.size(), hipMemcpyDeviceToHost, c->stream));
-  C_TRY(c, hipStreamSynchronize(c->stream));
+  c->counts_valid = false;  // the counts are consumed by this exchange
+  const std::vector<uint64_t>& counts = c->counts;
   if (counts_out) std::memcpy(counts_out, counts.data(), sizeof(uint64_t) * counts.size());
+  void* d_rows = nullptr;
+  uint64_t mine = 0;
+  if (counts[(size_t)c->rank]) (void)local_rows(c, b, &d_rows, &mine);  // (complete already: no waiting here)
+  C_TRY_X(c, hipSetDevice(c->device));
   uint64_t total = 0;
   for (uint64_t n : counts) total += n;
   constexpr size_t ROW = sizeof(dyn_segment_row);
-  if (c->rank == root) {
-    if (rows_out && rows_cap < total) {
-      c->last_error = "dyn_comm_gather_rows: rows_cap is smaller than the sum of all ranks' rows";
-      // still take part in the exchange below so that the peers do not hang; the rows are dropped
-    }
-    if (c->recv_bytes < total * ROW) {
-      if (c->d_recv) C_TRY(c, hipFree(c->d_recv));
-      c->d_recv = nullptr;
-      c->recv_bytes = 0;
-      C_TRY(c, hipMalloc(&c->d_recv, std::max<size_t>(total * ROW + total * ROW / 8, ROW)));
-      c->recv_bytes = total * ROW + total * ROW / 8;
-    }
+  const bool too_small = c->rank == root && rows_out && rows_cap < total;
+  if (c->rank == root && c->recv_bytes < total * ROW) {
+    if (c->d_recv) C_TRY_X(c, hipFree(c->d_recv));
+    c->d_recv = nullptr;
+    c->recv_bytes = 0;
+    C_TRY_X(c, hipMalloc(&c->d_recv, std::max<size_t>(total * ROW + total * ROW / 8, ROW)));
+    c->recv_bytes = total * ROW + total * ROW / 8;
   }
   // the rows: each peer's link to the root carries its rows once
-  N_TRY(c, g_rccl.GroupStart());
+  N_TRY_X(c, g_rccl.GroupStart());
   if (c->rank == root) {
     uint64_t off = 0;
     for (int r = 0; r < c->n_ranks; ++r) {
       char* dst = static_cast<char*>(c->d_recv) + off * ROW;
       if (r == root) {
-        if (counts[(size_t)r]) C_TRY(c, hipMemcpyAsync(dst, d_rows, counts[(size_t)r] * ROW, hipMemcpyDeviceToDevice, c->stream));
+        if (counts[(size_t)r]) C_TRY_X(c, hipMemcpyAsync(dst, d_rows, counts[(size_t)r] * ROW, hipMemcpyDeviceToDevice, c->stream));
       } else if (counts[(size_t)r]) {
-        N_TRY(c, g_rccl.Recv(dst, counts[(size_t)r] * ROW, ncclUint8, r, c->comm, c->stream));
+        N_TRY_X(c, g_rccl.Recv(dst, counts[(size_t)r] * ROW, ncclUint8, r, c->comm, c->stream));
       }
       off += counts[(size_t)r];
     }
   } else if (mine) {
-    N_TRY(c, g_rccl.Send(d_rows, mine * ROW, ncclUint8, root, c->comm, c->stream));
+    N_TRY_X(c, g_rccl.Send(d_rows, mine * ROW, ncclUint8, root, c->comm, c->stream));
   }
-  N_TRY(c, g_rccl.GroupEnd());
-  if (c->rank == root && rows_out && rows_cap >= total && total)
-    C_TRY(c, hipMemcpyAsync(rows_out, c->d_recv, total * ROW, hipMemcpyDeviceToHost, c->stream));
-  C_TRY(c, hipStreamSynchronize(c->stream));  // the batch's buffers may be released after this call
-  return (c->rank == root && rows_out && rows_cap < total) ? DYN_ERR_INVALID_ARGUMENT : DYN_OK;
+  N_TRY_X(c, g_rccl.GroupEnd());
+  if (c->rank == root && rows_out && !too_small && total)
+    C_TRY_X(c, hipMemcpyAsync(rows_out, c->d_recv, total * ROW, hipMemcpyDeviceToHost, c->stream));
+  C_TRY_X(c, hipStreamSynchronize(c->stream));  // the batch's buffers may be released after this call
+  if (too_small) {  // the exchange itself is complete on every rank: nothing hangs, the root may call again with room
+    c->last_error = "dyn_comm_gather_rows: rows_cap is smaller than the sum of all ranks' rows (dyn_comm_gather_counts tells it)";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  return local_rc;
 }
 
 int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n) {
   if (!c || !b) return DYN_ERR_INVALID_ARGUMENT;
-  int rc = dyn_batch_wait(b);
-  if (rc != DYN_OK) {
-    c->last_error = dyn_aligner_last_error(b->a);
-    return rc;
+  if (c->aborted) {
+    c->last_error = "the communicator was aborted by an earlier failure";
+    return DYN_ERR_DEVICE;
   }
   void* d_pooled = nullptr;
   uint64_t count = 0;
-  rc = dyn_batch_device_pooled(b, &d_pooled, &count);
+  int rc = dyn_batch_wait(b);
+  if (rc != DYN_OK) c->last_error = std::string("this rank's batch failed: ") + dyn_aligner_last_error(b->a);
+  if (rc == DYN_OK) {
+    rc = dyn_batch_device_pooled(b, &d_pooled, &count);
+    if (rc != DYN_OK) c->last_error = "dyn_comm_allreduce_pooled: the batch has not been trained";
+  }
   if (rc != DYN_OK) {
-    c->last_error = "dyn_comm_allreduce_pooled: the batch has not been trained";
+    // the peers are (or will be) inside ncclAllReduce with a buffer this rank cannot match: fail them fast
+    abort_comm(c);
     return rc;
   }
-  C_TRY(c, hipSetDevice(c->device));
+  C_TRY_X(c, hipSetDevice(c->device));
   // linear-domain sums (w, s1, s2)[numKmers]: a plain sum all-reduce is exact up to fp64 association
-  N_TRY(c, g_rccl.AllReduce(d_pooled, d_pooled, count, ncclDouble, ncclSum, c->comm, c->stream));
-  if (pooled3n) C_TRY(c, hipMemcpyAsync(pooled3n, d_pooled, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  C_TRY(c, hipStreamSynchronize(c->stream));
+  N_TRY_X(c, g_rccl.AllReduce(d_pooled, d_pooled, count, ncclDouble, ncclSum, c->comm, c->stream));
+  if (pooled3n) C_TRY_X(c, hipMemcpyAsync(pooled3n, d_pooled, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  C_TRY_X(c, hipStreamSynchronize(c->stream));
   return DYN_OK;
 }
 

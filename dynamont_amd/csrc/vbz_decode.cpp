@@ -57,7 +57,7 @@ bool svb16_decode(const uint8_t* buf, size_t bytes, uint32_t n, int16_t* out) {
 
 bool decode_chunk(const void* blob, size_t blob_bytes, uint32_t samples, int16_t* out, std::vector<uint8_t>& tmp, std::string& err) {
   dynzstd::Zstd& z = zstd();
-  if (!z.lib && !z.load(err)) return false;
+  if (!z.load(err)) return false;  // (one acquire load once the library is in)
   if (samples == 0) return true;
   unsigned long long n = z.getFrameContentSize(blob, blob_bytes);
   const size_t worst = ((size_t)samples + 7) / 8 + 2 * (size_t)samples;

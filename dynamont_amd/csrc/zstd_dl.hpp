@@ -5,7 +5,9 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstddef>
+#include <mutex>
 #include <string>
 
 namespace dynzstd {
@@ -24,21 +26,30 @@ struct Zstd {
   unsigned (*isError)(size_t) = nullptr;
   const char* (*getErrorName)(size_t) = nullptr;
 
+  // Thread-safe and idempotent: the first VBZ batch of a process decodes on every helper thread at once. `ready` is
+  // published (release) only after EVERY entry point has been resolved; a caller that sees it set (acquire) may use
+  // them all, anybody else queues behind the mutex. A failed load leaves the object untouched for the next attempt.
+  std::atomic<bool> ready{false};
+  std::mutex load_m;
+
   bool load(std::string& err) {
-    if (lib) return true;
+    if (ready.load(std::memory_order_acquire)) return true;
+    std::lock_guard<std::mutex> lk(load_m);
+    if (ready.load(std::memory_order_relaxed)) return true;
+    void* h = nullptr;
     for (const char* name : {"libzstd.so.1", "libzstd.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
     }
-    if (!lib) {
+    if (!h) {
       err = "libzstd.so.1 not found";
       return false;
     }
 #define DYN_Z(field, name)                                        \
-  field = reinterpret_cast<decltype(field)>(dlsym(lib, name));    \
+  field = reinterpret_cast<decltype(field)>(dlsym(h, name));      \
   if (!field) {                                                   \
     err = std::string("libzstd lacks ") + name;                   \
-    lib = nullptr;                                                \
+    dlclose(h);                                                   \
     return false;                                                 \
   }
     DYN_Z(createCCtx, "ZSTD_createCCtx");
@@ -53,6 +64,8 @@ struct Zstd {
     DYN_Z(isError, "ZSTD_isError");
     DYN_Z(getErrorName, "ZSTD_getErrorName");
 #undef DYN_Z
+    lib = h;
+    ready.store(true, std::memory_order_release);
     return true;
   }
 };

@@ -283,6 +283,9 @@ class _Pipeline:
             self.sink.put(buf[:total].tobytes())
         for i in np.flatnonzero(res.status[:len(g)] != 0):
             signal, read, job = g[i][:3]
+            if int(res.status[i]) == 10:  # DYN_READ_BAD_SIGNAL: the reference's worker fails before the aligner (segment.py:178-187)
+                self.sink.put(f"error: worker, {res.error(i)}\tN: {len(read)}\tRid: {job[6]}\tSid: {job[7]}")
+                continue
             self.sink.put(f"error: native, {res.error(i)}\tT: {len(signal)}\tN: {len(read)}\tRid: {job[6]}\tSid: {job[7]}")
         t.close()
         self.free.append(res)
@@ -331,7 +334,8 @@ class _NativePipeline:
 
     def put(self, line: str) -> None:
         """an error line from the producer (reads that failed before the aligner, segment.py:178-187)"""
-        self.L.dyn_csv_sink_error_line(self.h, line.encode())
+        if self.L.dyn_csv_sink_error_line(self.h, line.encode()) != self.N.DYN_OK:
+            raise OSError("cannot append to the .errors file")
 
     def _reap(self, block_until: int | None = None) -> None:
         import time
@@ -343,6 +347,7 @@ class _NativePipeline:
                 self.free.append(res)
             if block_until is None or self.submitted - done <= block_until:
                 return
+            self.check()
             time.sleep(0.0005)
 
     def submit(self, pending, end_of_round: bool = False) -> None:
@@ -356,6 +361,7 @@ class _NativePipeline:
         for g in groups:
             if not g:
                 continue
+            self.check()
             self._reap(block_until=self.depth - 1)
             n = len(g)
             sig, sig_off, seqs, seq_off = _pack_jobs(g, scattered=self.raw)
@@ -377,12 +383,16 @@ class _NativePipeline:
                                             starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p))
             if rc != N.DYN_OK:
                 t.close()
+                self.check()  # the sink's own failure, with its message
                 raise RuntimeError("dyn_csv_sink_submit failed")
             self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g)  # g: the slices (and their readers) stay alive
             self.submitted += 1
 
     def check(self) -> None:
-        pass
+        """raise as soon as the sink has failed (a batch error, zstd, the output file) instead of parsing and aligning the
+        rest of the input first; close() delivers the message"""
+        if self.h is not None and self.L.dyn_csv_sink_failed(self.h):
+            self.close()
 
     def close(self) -> None:
         C = self.C

@@ -72,9 +72,14 @@ enum dyn_read_status {
                                     what every read that passes validation gets from a handle created with mode
                                     "resquiggle"/"ntk" -- the reference's NTKAligner fails that check on every read in this
                                     snapshot (observed with the compiled reference, tests/golden/g11_ntk_messages.json) */
-  DYN_READ_TOO_LARGE = 8         /* "Read too large for the device memory budget": this read's lattice alone exceeds
+  DYN_READ_TOO_LARGE = 8,        /* "Read too large for the device memory budget": this read's lattice alone exceeds
                                     the HBM budget (or 2^31 rows); the reference would raise std::bad_alloc for that
                                     read only (segment.py:172-176), so it is a per-read status, not a batch error */
+  DYN_READ_BAD_SIGNAL = 10       /* "Signal could not be decoded" (dyn_batch_align_vbz_async): a POD5 chunk of this read is
+                                    corrupt, truncated or shorter than the read's [start:end) slice. In the reference the
+                                    pod5 reader raises inside the worker and the listener gets ONE line for that read,
+                                    "error: worker, <message>\tN: ..\tRid: ..\tSid: .." (segment.py:178-187); the CSV sink
+                                    writes that form for this status. The rest of the batch is unaffected. */
 };
 
 /* or-ed into raw_dtype of the *_raw_async calls: `raw` is not one concatenated array but a table of n_reads pointers
@@ -309,6 +314,9 @@ int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, cons
                         const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths);
 /* one line for `.errors` from the caller (reads that failed before they reached the aligner, segment.py:178-187) */
 int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line);
+/* 1 once the sink has failed (a batch error, the compressor, the output file): later submits return DYN_ERR_RUNTIME, and
+ * dyn_csv_sink_close reports the first message. Lets a producer stop instead of aligning the rest of its input. */
+int dyn_csv_sink_failed(dyn_csv_sink* s);
 /* batches fully consumed so far */
 uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s);
 /* drains, closes the frame and the file, frees the sink; DYN_ERR_RUNTIME + message if any batch, compression or write
@@ -460,10 +468,20 @@ int dyn_comm_unique_id(uint8_t* id_out128, char* err, uint64_t errcap);
 int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn_comm** out, char* err, uint64_t errcap);
 void dyn_comm_destroy(dyn_comm* c);
 const char* dyn_comm_last_error(const dyn_comm* c);
-/* Collective. `b` = an aligned batch or a ticket of dyn_batch_align[_raw]_async (waited for here). Every rank's
- * dyn_segment_row records (dyn_segment_capacity() of them, read i at seg_offsets[i] as in dyn_align_out) travel device to
- * device to `root`: one ncclSend per peer, each over its own xGMI link, no padding. On root rows_out (host, may be NULL)
- * receives them back to back in rank order and counts_out[r] (may be NULL, any rank) the rows of rank r. */
+/* The gather of config 4 is two collectives: the 8-byte count exchange, then the rows.
+ * dyn_comm_gather_counts: collective. `b` = an aligned batch or a ticket of dyn_batch_align[_raw]_async (waited for
+ * here). counts_out[r] (n_ranks entries, may be NULL) = the dyn_segment_row records rank r will send
+ * (dyn_segment_capacity() of its batch). A rank whose batch FAILED announces 0 rows, takes part in both collectives all
+ * the same -- its peers never block on it -- and gets its batch's error code back from both calls.
+ * dyn_comm_gather_rows: collective. The rows travel device to device to `root`: one ncclSend per peer, each over its own
+ * xGMI link, no padding. On root rows_out (host, may be NULL; rows_cap records) receives them back to back in rank order
+ * (read i of a rank at seg_offsets[i] as in dyn_align_out). Called without a preceding dyn_comm_gather_counts it performs
+ * the count exchange itself; a root that cannot know the total in advance calls dyn_comm_gather_counts first and
+ * allocates sum(counts). rows_cap < total on root: the exchange completes on every rank (nothing hangs), the rows are
+ * dropped and root gets DYN_ERR_INVALID_ARGUMENT.
+ * A HIP / RCCL failure in the middle of an exchange aborts the communicator (ncclCommAbort): the peers' pending
+ * operations fail instead of blocking, every later call on the handle returns DYN_ERR_DEVICE. */
+int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out);
 int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* rows_out, uint64_t rows_cap,
                          uint64_t* counts_out);
 /* Collective. `b` = a trained batch or a ticket of dyn_batch_train[_raw]_async. Sum over ranks of the device-resident

@@ -140,3 +140,47 @@ def test_resquiggle_cli_on_a_pod5_file_equals_the_npz_container(models, tmp_path
         assert len(errs) == 1 and "Signal too short compared to sequence" in errs[0]
         seg.close_raw_cache()
     assert len(rows["pod5"]) > 1000 and rows["pod5"] == rows["npz"]
+
+
+def test_resquiggle_cli_corrupt_pod5_chunk_fails_that_read_only(models, tmp_path):
+    """A POD5 chunk that does not decode (here: its zstd frame header overwritten in the file) fails ITS read with the
+    line the reference's worker writes for a read whose signal cannot be read (segment.py:178-187) -- the other reads of
+    the batch come out as they do from the intact file. Basecalls from a real (unaligned) BAM."""
+    from dynamont_amd.pod5_native import vbz_compress
+    pore = "rna004"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(73, 9, pore, mean, sd, (60, 400))
+    outs = {}
+    for name in ("intact", "corrupt"):
+        d = tmp_path / name
+        raw, bam, _ = synth.write_dataset(str(d / "in"), "ds", reads, pore, seed=9, container="pod5", basecalls="bam")
+        assert bam.endswith(".bam")
+        if name == "corrupt":
+            # read 4's only chunk, as write_dataset compressed it
+            sm, sdv, scale, offset = 90.0, 15.0, 0.1755, -240.0
+            rng = np.random.default_rng(9)
+            blob = None
+            for i, r in enumerate(reads):
+                adc = np.rint((r.signal * sdv + sm) / scale - offset).astype(np.int16)
+                pre = rng.integers(300, 900, size=37).astype(np.int16)
+                rng.uniform(8.0, 20.0)
+                if i == 4:
+                    blob = vbz_compress(np.concatenate([pre, adc]))
+            data = bytearray(open(raw, "rb").read())
+            at = bytes(data).find(blob)
+            assert at > 0 and bytes(data).find(blob, at + 1) < 0
+            data[at:at + 4] = b"\xde\xad\xbe\xef"   # no longer a zstd frame
+            open(raw, "wb").write(bytes(data))
+        out = d / "out" / "res.csv"
+        seg.main(["-r", str(d / "in"), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore, "--model_path", model,
+                  "--batch-reads", "4"])
+        body = zstd_io.decompress(open(str(out) + ".zst", "rb").read()).decode().splitlines()
+        errs = open(str(d / "out" / "res.errors")).read().splitlines() if os.path.exists(str(d / "out" / "res.errors")) else []
+        outs[name] = (body, errs)
+    body_ok, errs_ok = outs["intact"]
+    body_bad, errs_bad = outs["corrupt"]
+    assert errs_ok == []
+    assert len(errs_bad) == 1 and errs_bad[0].startswith("error: worker, Signal could not be decoded\tN: ")
+    rid = errs_bad[0].split("\tRid: ")[1].split("\t")[0]
+    assert [r for r in body_ok if not r.startswith(rid + ",")] == body_bad and len(body_bad) < len(body_ok)

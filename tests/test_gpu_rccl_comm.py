@@ -42,6 +42,19 @@ with al.batch_packed(sig, so, sq, qo) as b:
         ok &= np.array_equal(rows["sequence_pos"][a:a + n], res.sequence_positions[a:a + n].astype(np.uint32))
         ok &= np.array_equal(rows["probability"][a:a + n], res.probabilities[a:a + n])
     out["rows_equal_fetch"] = bool(ok)
+    # the two-call form below Python: counts first, then a root buffer that is too small -- the exchange completes (nobody
+    # would hang), root is told, and the communicator is still good for the next gather
+    from dynamont_amd import _native as N
+    import ctypes as C
+    L = N.lib()
+    cnt = np.zeros(1, dtype=np.uint64)
+    out["counts_rc"] = int(L.dyn_comm_gather_counts(comm._h, b._h, cnt.ctypes.data_as(N.c_u64_p)))
+    out["counts_two_call"] = cnt.tolist()
+    small = np.empty(10, dtype=RcclComm.ROW)
+    out["too_small_rc"] = int(L.dyn_comm_gather_rows(comm._h, b._h, 0, small.ctypes.data, 10, None))
+    out["too_small_msg"] = (L.dyn_comm_last_error(comm._h) or b"").decode()
+    rows3, _ = comm.gather_rows(b, root=0)
+    out["gather_after_too_small"] = bool(np.array_equal(rows3, rows))
 t = al.align_async(sig, so, sq, qo, True)      # a ticket works too (the call waits for it)
 rows2, _ = comm.gather_rows(t, root=0)
 out["ticket_rows_equal"] = bool(np.array_equal(rows2, rows))
@@ -52,6 +65,27 @@ with al.batch_packed(sig, so, sq, qo) as b:
     got = comm.allreduce_pooled(b, al.num_kmers)
     out["pooled_close"] = bool(np.allclose(got, want, rtol=1e-12, atol=1e-12))
     out["pooled_weight"] = float(got[:al.num_kmers].sum())
+    # the device-resident pooled statistics are summed in a fixed order (pool_stats.hip): the host's sum in read order,
+    # bit for bit, and the same bits on every run (a one-rank all-reduce is the identity)
+    out["pooled_bits_equal_host"] = bool(np.array_equal(got.view(np.uint64), want.view(np.uint64)))
+same = True
+for _ in range(10):
+    with al.batch_packed(sig, so, sq, qo) as b:
+        b.train()
+        again = comm.allreduce_pooled(b, al.num_kmers)
+        same &= bool(np.array_equal(again.view(np.uint64), got.view(np.uint64)))
+out["pooled_identical_over_10_runs"] = same
+# a batch in which one read fails on the host (an N) and one on the device (a NaN sample): both stay out of the sums
+seqs2 = [r.sequence for r in reads]
+seqs2[3] = seqs2[3][:20] + "N" + seqs2[3][21:]
+sigs2 = [r.signal.copy() for r in reads]
+sigs2[7][50] = np.nan
+with al.batch(sigs2, seqs2) as b:
+    b.train()
+    r2 = b.fetch_train(pooled=True)
+    got2 = comm.allreduce_pooled(b, al.num_kmers)
+    out["failed_reads"] = [int(x) for x in np.flatnonzero(r2.status != 0)]
+    out["pooled_bits_equal_host_with_failed_reads"] = bool(np.array_equal(got2.view(np.uint64), r2.pooled.view(np.uint64)))
 comm.close()
 al.close()
 print("RESULT " + json.dumps(out))
@@ -66,4 +100,8 @@ def test_one_rank_rccl_gather_and_allreduce(models):
     out = json.loads(line[-1][7:])
     assert out["counts"] == [out["capacity"]] and out["capacity"] > 1000
     assert out["rows_equal_fetch"] and out["ticket_rows_equal"] and out["pooled_close"]
+    assert out["counts_rc"] == 0 and out["counts_two_call"] == out["counts"]
+    assert out["too_small_rc"] == 1 and "rows_cap" in out["too_small_msg"] and out["gather_after_too_small"]
     assert out["pooled_weight"] > 100.0
+    assert out["pooled_bits_equal_host"] and out["pooled_identical_over_10_runs"]
+    assert out["failed_reads"] == [3, 7] and out["pooled_bits_equal_host_with_failed_reads"]
