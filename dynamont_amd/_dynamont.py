@@ -483,6 +483,11 @@ class Aligner:
         if rc != N.DYN_OK:
             raise ValueError(self.last_error() or "strict mode must be 0 (off), 1 (ties) or 2 (all)")
 
+    def set_train_zcheck(self, on: bool) -> None:
+        """dyn_aligner_set_train_zcheck: also refuse the reads the reference's |Zf - Zb| rule refuses (one more Z-only
+        forward sweep per read)."""
+        self._L.dyn_aligner_set_train_zcheck(self._h, 1 if on else 0)
+
     def tie_rows(self, kmers, signal_len: int) -> int:
         """dyn_tie_rows: 0 = the read carries no structural tie; else the forward rows mode "ties" runs bit for bit
         (0xffffffff = all)."""

@@ -70,6 +70,7 @@ SIGNATURES = {
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
+    "dyn_aligner_set_train_zcheck": (C.c_int, [C.c_void_p, C.c_int]),
     "dyn_tie_rows": (C.c_uint32, [C.c_void_p, c_i32_p, C.c_uint64, C.c_uint64]),
     "dyn_aligner_last_error": (C.c_char_p, [C.c_void_p]),
     "dyn_read_strerror": (C.c_int, [C.c_int, C.c_char, C.c_char_p, C.c_uint64]),

@@ -275,6 +275,16 @@ struct SoftplusLookup {
 template <int M>
 DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusLookup<M>& L,
                            const SoftplusNode* __restrict__ tab) {
+#if defined(DYN_EXP_MAXPLUS)
+  // FLOOR MEASUREMENT ONLY (tools/floor_bench.sh; never a product build): logPlus -> max, i.e. the sweeps in the max-plus
+  // semiring: one operation instead of 19 and no table lookup, with the same loads, stores, ballots, band hand-overs and
+  // traceback (forward and backward maxima agree, so every read passes its Z check). What is left is what the sweeps
+  // cost WITHOUT the softplus: the bound DESIGN.md section 7 quotes.
+#pragma unroll
+  for (int j = 0; j < M; ++j) L.hi[j] = __builtin_fmax(x[j], y[j]);
+  (void)tab;
+  return;
+#endif
   double d[M], m[M], kf[M];
   const double magic = vreg_const(SP_MAGIC), neg_steps = sreg_const(-(double)SP_STEPS);
 #pragma unroll
@@ -306,6 +316,11 @@ DYN_HD void log_plus_issue(const double (&x)[M], const double (&y)[M], SoftplusL
 
 template <int M>
 DYN_HD void log_plus_finish(const SoftplusLookup<M>& L, double (&out)[M]) {
+#if defined(DYN_EXP_MAXPLUS)
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = L.hi[j];
+  return;
+#endif
   double u[M], w[M], p[M], q[M];
   const double c120 = vreg_const(1.0 / 120.0), c24 = vreg_const(1.0 / 24.0);
   const double m10 = sreg_const(-12.0 / 120.0), m4 = sreg_const(-0.25);

@@ -576,6 +576,12 @@ int dyn_aligner_set_strict(dyn_aligner* a, int mode) {
   return DYN_OK;
 }
 
+int dyn_aligner_set_train_zcheck(dyn_aligner* a, int on) {
+  if (!a) return DYN_ERR_INVALID_ARGUMENT;
+  a->train_zcheck = on != 0;
+  return DYN_OK;
+}
+
 }  // extern "C"
 
 namespace dyneng {
@@ -1245,7 +1251,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   q.e2 = m.log_e2;
   q.sp_tab = a->d_sptab.as<dynmath::SoftplusNode>();
   q.z_fail_status = z_fail;
-  const dynk::QueueJob qjob = job == DynJob::Train ? dynk::JOB_TRAIN
+  const dynk::QueueJob qjob = job == DynJob::Train ? (a->train_zcheck ? dynk::JOB_TRAIN_ZCHECK : dynk::JOB_TRAIN)
                               : !calc              ? dynk::JOB_Z
                               : lpe_separate       ? dynk::JOB_ALIGN
                                                    : dynk::JOB_ALIGN_INPLACE;

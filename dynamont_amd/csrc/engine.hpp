@@ -101,6 +101,7 @@ struct dyn_aligner {
   dyneng::DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
   uint64_t mem_budget = 0;
   int strict_mode = 1;  // dyn_aligner_set_strict: reads with a structural tie run bit for bit by default
+  bool train_zcheck = false;  // dyn_aligner_set_train_zcheck
   bool ntk = false;     // created with mode "resquiggle" / "ntk"
   std::string last_error;
   // grow-only lattice workspace pool, reused across batches (only ever touched by work on `stream`,

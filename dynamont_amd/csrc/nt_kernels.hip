@@ -1246,11 +1246,18 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
       else
         Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows, &n_fallback);
     } else {
-      if constexpr (JOB == JOB_TRAIN) {
+      if constexpr (JOB == JOB_TRAIN || JOB == JOB_TRAIN_ZCHECK) {
         // backward sweep in the log domain (the emission's constant folded), then the posterior chain
         Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
         Zf = forward_train_chain(rd, w, sig, q.pool.ws, q.tr, Zb, s_tab, ring_base);
+        if constexpr (JOB == JOB_TRAIN_ZCHECK) {
+          // dyn_aligner_set_train_zcheck: the reference's own refusal rule (NT_aligner_api.cpp:619-625) on top of the
+          // chain's -- a forward value of Z (the cheap Z-only sweep: no lattice traffic) must agree with the backward one
+          // to 1e-8 per lattice cell, so that `.errors` lists the reads the reference lists (|Z| ~ 1e12 and beyond)
+          const double Zf_log = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
+          if (!z_ok(rd, Zf_log, Zb)) Zf = NEG_INF;
+        }
       } else {
         Zb = backward_sweep<LATTICE, JOB == JOB_Z ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
         t2 = __builtin_amdgcn_s_memtime();
@@ -1599,6 +1606,7 @@ void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n
     case JOB_ALIGN: hipLaunchKernelGGL((k_read_queue<JOB_ALIGN, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
     case JOB_ALIGN_INPLACE: hipLaunchKernelGGL((k_read_queue<JOB_ALIGN_INPLACE, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
     case JOB_TRAIN: hipLaunchKernelGGL((k_read_queue<JOB_TRAIN, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
+    case JOB_TRAIN_ZCHECK: hipLaunchKernelGGL((k_read_queue<JOB_TRAIN_ZCHECK, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
   }
 }
 

@@ -100,7 +100,7 @@ constexpr int QUEUE_CTL_WORDS = 32;   // 32-bit words reserved for ctl (stats st
 constexpr int QUEUE_STATS = 8;        // first stats word (as uint32 index)
 constexpr int QUEUE_N_STATS = 10;
 
-enum QueueJob { JOB_Z = 0, JOB_ALIGN = 1, JOB_ALIGN_INPLACE = 2, JOB_TRAIN = 3 };
+enum QueueJob { JOB_Z = 0, JOB_ALIGN = 1, JOB_ALIGN_INPLACE = 2, JOB_TRAIN = 3, JOB_TRAIN_ZCHECK = 4 };
 
 struct QueueArgs {
   const ReadDesc* descs;   // in processing order

@@ -100,6 +100,9 @@ def parse(argv=None) -> Namespace:
                    help="parameter update: the reference's sliding-window mean of per-read estimates, or a pooled M-step")
     p.add_argument("--no-timestamp", action="store_true", help="write into OUTDIR itself (the reference appends a timestamp)")
     p.add_argument("--host-preprocess", action="store_true", help="normalise + Hampel-filter with NumPy on the host instead of on the GPU (same values)")
+    p.add_argument("--reference-zcheck", action="store_true",
+                   help="also refuse the reads the reference's |Zf - Zb| / size > 1e-8 rule refuses (NT_aligner_api.cpp:619-625): "
+                        "one more Z-only forward sweep per read; default: the posterior chain's own mass check")
     return p.parse_args(argv)
 
 
@@ -173,7 +176,7 @@ def _z_items(al: Aligner, items, raw: bool):
 
 def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_file: str, mode: str, model_path: str,
           max_batches, pore: str, minq=None, device: int = 0, aggregate: str = "window-mean", comm=None,
-          host_preprocess: bool = False) -> None:
+          host_preprocess: bool = False, reference_zcheck: bool = False) -> None:
     """Counterpart of train.py:68-253. ``comm`` (optional, dynamont_amd.parallel.Comm): multi-GPU
     run -- accepted reads are dealt round-robin to the ranks (each rank fills ``batch_size`` reads of
     its own per batch, so all ranks reach a batch boundary on the same read), the pooled sufficient
@@ -229,6 +232,7 @@ def train(data_path: str, basecalls: str, batch_size: int, epochs: int, param_fi
                 # those values (set_model below; a float64 survives the file's shortest decimal representation unchanged)
                 if al is None:
                     al = Aligner(trained_model, pore, mode="basic", threads=4, band=400, device=device)
+                    al.set_train_zcheck(reference_zcheck)
                 cur_mean, cur_sd = al.model_table()
                 res = _train_items(al, items, aggregate == "pooled", raw=not host_preprocess)
                 preZ = {}
@@ -328,7 +332,7 @@ def main(argv=None) -> None:
     with parallel.abort_on_error(comm):
         train(args.raw, args.basecalls, args.batch_size, args.epochs, param_file, "basic", model_path, args.max_batches,
               args.pore, args.qscore, device=local_rank if comm else args.device, aggregate=args.aggregate, comm=comm,
-              host_preprocess=args.host_preprocess)
+              host_preprocess=args.host_preprocess, reference_zcheck=args.reference_zcheck)
 
 
 if __name__ == "__main__":

@@ -234,6 +234,12 @@ int dyn_aligner_set_mem_budget(dyn_aligner* a, uint64_t bytes);
  * Returns DYN_ERR_INVALID_ARGUMENT for an unknown mode, and for modes 1/2 on a model holding a stdev whose significand
  * is all ones (no division-free exact quotient exists for that one divisor; no decimal parses to it). */
 int dyn_aligner_set_strict(dyn_aligner* a, int mode);
+/* train(): which reads are refused. Off (default): the posterior chain's own rule -- Z finite, all mass delivered to the
+ * end cell, weight 1 per sample (see DYN_READ_TRAIN_Z_MISMATCH). On: additionally the reference's rule,
+ * |Zf - Zb| / (T x B) > 1e-8 -> "Training failed: alignment scores do not match" (NT_aligner_api.cpp:619-625), with Zf
+ * from one more (Z-only, no lattice traffic) forward sweep per read: `.errors` then lists the pathological reads the
+ * reference lists (a sample ~1e6 model standard deviations out), at ~25 % more time per train() launch. */
+int dyn_aligner_set_train_zcheck(dyn_aligner* a, int on);
 /* The rule of mode 1 for one read, given its k-mer codes (dyn_validate_batch) and signal length: 0 = no structural tie;
  * otherwise the number of forward rows that run in the strict arithmetic (UINT32_MAX: all of them). Host only. */
 uint32_t dyn_tie_rows(const dyn_aligner* a, const int32_t* kmers, uint64_t n_kmers, uint64_t signal_len);

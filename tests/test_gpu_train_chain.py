@@ -130,6 +130,33 @@ def test_train_sample_at_the_edge_of_double_precision(models):
     al.close()
 
 
+def test_train_reference_zcheck_refuses_what_the_reference_refuses(models):
+    """dyn_aligner_set_train_zcheck: with the reference's own rule on top (|Zf - Zb| / size > 1e-8, NT_aligner_api.cpp:
+    619-625), the read with a sample 1e6 standard deviations out is refused with the reference's message -- as the oracle
+    refuses it -- and ordinary reads train exactly as without the switch."""
+    path = models["syn9"]
+    _, mean, sd = synth.read_model_file(path)
+    base = synth.make_reads(78, 3, "rna004", mean, sd, (200, 300))
+    far = base[2].signal.copy()
+    far[len(far) // 4] = 2e5
+    reads = base + [synth.SynthRead(far, base[2].sequence)]
+    orc = Oracle(path, 1)
+    with pytest.raises(RuntimeError, match="Training failed: alignment scores do not match"):
+        orc.train(far, base[2].sequence)
+    al = Aligner(path, "rna004", device=0)
+    plain = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
+    assert plain.status.tolist() == [0, 0, 0, 0]            # the chain trains all four (stated deviation)
+    al.set_train_zcheck(True)
+    strict = al.train_batch([r.signal for r in reads], [r.sequence for r in reads])
+    assert strict.status.tolist()[:3] == [0, 0, 0] and strict.status[3] != 0
+    assert strict.error(3) == "Training failed: alignment scores do not match"
+    for i in range(3):
+        assert strict.Z[i] == plain.Z[i]
+        a, c = int(plain.em_offsets[i]), int(plain.em_count[i])
+        assert np.array_equal(strict.em_weight[a:a + c], plain.em_weight[a:a + c])
+    al.close()
+
+
 def test_train_long_dna_reads(models):
     """cfg3-shaped reads through train(): 8 DNA r10.4.1 reads of 40 k - 100 k samples (the lattice of one read spans
     hundreds of pages, the band moves every ~12 rows); every read conserves its mass, two are compared with the oracle."""
