@@ -80,6 +80,7 @@ def parse():
                          "bit) and what the bench line is quoted in; 'off' / 'all' are experiments, not bench lines")
     ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e_cli` record (N = 1: the whole CLI on a synthetic .pod5 + basecall file)")
     ap.add_argument("--e2e-reads", type=int, default=32768, help="reads of the e2e_cli dataset (a multiple of 4 096: that many distinct reads, repeated)")
+    ap.add_argument("--e2e-batch-reads", type=int, default=0, help="--batch-reads of the e2e_cli run (0 = the CLI's default)")
     ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
                     help="align = the headline metric; train = Baum-Welch statistics pass (config 5 shape, secondary)")
@@ -107,7 +108,7 @@ def load_traffic():
     return None
 
 
-def run_e2e_cli(n_reads: int, workdir: str, strict: str) -> dict:
+def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -> dict:
     """north_star's "throughput on synthetic pod5+bam": the dynamont-resquiggle counterpart end to end, in this process.
     A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
     dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
@@ -131,7 +132,7 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str) -> dict:
     out = os.path.join(d, "out.csv")
     t0 = time.perf_counter()
     seg.main(["-r", os.path.join(d, "in"), "-b", bam, "-o", out, "--mode", "basic", "-p", "rna004", "--model_path", model,
-              "--batch-reads", "1024", "--strict-ties", strict])
+              "--strict-ties", strict] + (["--batch-reads", str(batch_reads)] if batch_reads else []))
     dt = time.perf_counter() - t0
     err = out + ".errors" if os.path.exists(out + ".errors") else None
     rec = {"value": round(samples / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "reads": distinct * rep,
@@ -140,6 +141,7 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str) -> dict:
                     f"{distinct} distinct synthetic rna004 reads x {rep}, written by synth.write_dataset in {t_gen:.1f} s (not timed)",
            "output": f"out.csv.zst, {os.path.getsize(out + '.zst') / 1e6:.1f} MB" if os.path.exists(out + ".zst") else None,
            "error_lines": sum(1 for _ in open(err)) if err else 0, "strict_mode": strict,
+           "batch_reads": batch_reads or "CLI default",
            "timed": "segment.main: model load, BAM parse, pod5 VBZ decode, device preprocessing, DP, CSV format, zstd, write",
            "not_timed": "interpreter start-up, lattice pool allocation (the bench handle's parked pool is taken over)"}
     return rec
@@ -502,7 +504,7 @@ def main():
     al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
     if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
         try:
-            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, {"start": "ties"}.get(args.strict, args.strict))
+            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, {"start": "ties"}.get(args.strict, args.strict), args.e2e_batch_reads)
         except Exception as e:  # the headline stands on its own
             line["e2e_cli"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
