@@ -1264,7 +1264,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
   // (Running the per-segment kernels on a stream of their own, beside the next batch's read queue, was measured:
   //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
-  if (calc) dynk::launch_segments(q.descs, nr, max_T, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
+  if (calc) dynk::launch_segments(q.descs, nr, rows_total, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
   if (job == DynJob::Train)
     HIP_TRY(a, dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers,
                                        b->total_cols, b->d_poolwork.p, b->d_pooltemp.p, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers),

@@ -135,7 +135,7 @@ void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, h
 // that carries both arithmetic flavours and branches per read
 void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n_cus, hipStream_t s);
 // per-segment median posterior + output rows for all reads of descs (after launch_read_queue)
-void launch_segments(const ReadDesc* descs, int n_reads, uint32_t max_T, uint32_t max_N, const ReadState* st,
+void launch_segments(const ReadDesc* descs, int n_reads, uint64_t rows_total, uint32_t max_N, const ReadState* st,
                      TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s);
 // pooled[3*num_kmers] (zeroed by the caller) = per-k-mer (w, s1, s2) of the ok reads in descs, summed in a FIXED order:
 // per read over its columns ascending, then over the reads in input order -- bit for bit the host's sum (pool_stats.hip).
