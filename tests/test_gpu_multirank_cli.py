@@ -67,6 +67,12 @@ def test_train_two_ranks_allreduce(models, tmp_path):
     ra, rb = open(tmp_path / "single" / "params.csv").read().splitlines(), open(tmp_path / "multi" / "params.csv").read().splitlines()
     assert ra[0] == rb[0] and rb[1].startswith("0,1,8,")
     assert abs(float(ra[1].split(",")[-1]) - float(rb[1].split(",")[-1])) <= 1e-6
+    # pooled statistics are summed in a fixed order on every rank (pool_stats.hip): the same job again writes the SAME
+    # model file, byte for byte (rounds 1-3: fp64 atomics, last digits differed run to run)
+    _torchrun("dynamont_amd.segmentation.train", common + ["-o", str(tmp_path / "multi2"), "--batch_size", "4", "--max_batches", "1"], 29623)
+    assert open(tmp_path / "multi" / "trained_0_1.model", "rb").read() == open(tmp_path / "multi2" / "trained_0_1.model", "rb").read()
+    trn.main(common + ["-o", str(tmp_path / "single2"), "--batch_size", "8", "--max_batches", "1"])
+    assert open(tmp_path / "single" / "trained_0_1.model", "rb").read() == open(tmp_path / "single2" / "trained_0_1.model", "rb").read()
 
 
 def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
