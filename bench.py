@@ -159,7 +159,12 @@ def launch_ranks(args) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries the ONE JSON line and nothing else (the launcher and gloo print banners there): the rest goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
