@@ -165,7 +165,7 @@ typedef struct dyn_timing {
   uint64_t cells;        /* in-band lattice cells processed: sum over ok reads of T*min(2bw+1,N) */
   uint64_t samples;      /* sum of signal lengths over ok reads */
   uint64_t reads_ok;
-  uint32_t launches;     /* read-queue launches (1; 0 for a batch without an ok read; 2 when strict and default reads mix) */
+  uint32_t launches;     /* read-queue launches (1; 0 for a batch without an ok read): strict and plain reads share one launch */
   uint32_t lp_inplace;   /* 1: the page pool could not hold a separate-layout lattice (12 B per band slot) for every
                             wave, the posteriors overwrote the backward rows in place (8 B per slot, slower sweep) */
   uint32_t pool_pages;   /* pages in the lattice pool */
