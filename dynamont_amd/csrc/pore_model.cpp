@@ -4,9 +4,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cstdint>
 #include <fstream>
-#include <sstream>
+#include <iterator>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 #include "../../include/dynamont_mi.h"
 
@@ -38,14 +42,6 @@ const PoreDefaults& defaults_for(int pore) {
   return kTable[pore];
 }
 
-double parse_field(const std::string& s) {
-  const char* b = s.c_str();
-  char* end = nullptr;
-  const double v = std::strtod(b, &end);
-  if (end == b) throw std::invalid_argument("stod");
-  return v;
-}
-
 }  // namespace
 
 void PoreModel::load(const std::string& path, int pore_id, uint64_t band) {
@@ -63,56 +59,126 @@ void PoreModel::load(const std::string& path, int pore_id, uint64_t band) {
   const int digit_of[] = {0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 4, 4};
   for (int i = 0; letters[i]; ++i) base_digit[(unsigned char)letters[i]] = (int8_t)digit_of[i];
 
-  std::ifstream in(path);
+  std::ifstream in(path, std::ios::binary);
   if (!in) throw std::runtime_error("Could not open model file, please prove a valid model path " + path);
-
-  // Read every data line once; the reference makes two passes over the file, the observable
-  // behaviour (error precedence: k-mer length check over the whole file first) is kept.
-  struct Row { std::string kmer, mean, stdev; };
-  std::vector<Row> rows;
-  std::string line;
-  std::getline(in, line);  // header
-  bool seen[256] = {false};
-  while (std::getline(in, line)) {
-    Row r;
-    size_t a = line.find('\t');
-    r.kmer = line.substr(0, a);
-    if (r.kmer.size() != (size_t)k) throw std::runtime_error("Inconsistent kmer size in model");
-    for (char c : r.kmer) seen[(unsigned char)c] = true;
-    if (a != std::string::npos) {
-      size_t b = line.find('\t', a + 1);
-      r.mean = line.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1);
-      if (b != std::string::npos) {
-        size_t c = line.find('\t', b + 1);
-        r.stdev = line.substr(b + 1, c == std::string::npos ? std::string::npos : c - b - 1);
-      }
+  // The whole file in one read (a 9-mer table is 262 145 lines, 12 MB): line by line through an ifstream, with a
+  // std::string per field, the load took 0.3 s -- a sixth of a 32 768-read dynamont-resquiggle run.
+  std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  in.close();
+  // line table; the header line is skipped (aligner.cpp:97-99), a last line without '\n' counts, "\r\n" is tolerated
+  // the way std::getline + substr tolerate it (the '\r' stays with the last field, where strtod ignores it)
+  struct Line { const char* b; const char* e; };
+  std::vector<Line> lines;
+  {
+    const char* p = text.data();
+    const char* const end = p + text.size();
+    bool header = true;
+    while (p < end) {
+      const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(end - p)));
+      const char* le = nl ? nl : end;
+      if (!header) lines.push_back(Line{p, le});
+      header = false;
+      p = nl ? nl + 1 : end;
     }
-    rows.push_back(std::move(r));
+  }
+  // Pass 1, in file order, as the reference's first pass (aligner.cpp:100-119): every k-mer has length k -- this check
+  // takes precedence over every other complaint about the file -- and the alphabet is what the k-mers are made of.
+  bool seen[256] = {false};
+  for (const Line& ln : lines) {
+    const char* tab = static_cast<const char*>(std::memchr(ln.b, '\t', (size_t)(ln.e - ln.b)));
+    const size_t klen = (size_t)((tab ? tab : ln.e) - ln.b);
+    if (klen != (size_t)k) throw std::runtime_error("Inconsistent kmer size in model");
+    for (size_t i = 0; i < klen; ++i) seen[(unsigned char)ln.b[i]] = true;
   }
   alphabet = 0;
-  for (bool s : seen) alphabet += s ? 1 : 0;
+  for (bool sn : seen) alphabet += sn ? 1 : 0;
   num_kmers = (uint64_t)std::pow((double)alphabet, (double)k);
   mean.assign(num_kmers, 0.0);
   stdev.assign(num_kmers, 0.0);
-  for (Row& r : rows) {
-    std::string key = r.kmer;
-    if (rna) key.assign(r.kmer.rbegin(), r.kmer.rend());  // 5'->3' file, 3'->5' sequencing
-    uint64_t code = 0;
-    for (char c : key) {
-      const int dgt = base_digit[(unsigned char)c];
-      if (dgt < 0 || dgt >= alphabet) throw std::runtime_error("Invalid nucleotide in k-mer: " + key);
-      code = code * (uint64_t)alphabet + (uint64_t)dgt;
+  // Pass 2 on several threads: k-mer code (reversed for RNA, aligner.cpp:136-139) and the two numbers of every line. The
+  // first offending line IN FILE ORDER decides which error is raised, as in the reference's serial loop; values are
+  // scattered into the table serially afterwards, so that a k-mer listed twice keeps its LAST line, as there.
+  const size_t n_lines = lines.size();
+  std::vector<uint64_t> codes(n_lines);
+  std::vector<double> means(n_lines), sds(n_lines);
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 1), n_lines / 4096 + 1}));
+  std::vector<size_t> bad_line(n_threads, SIZE_MAX);
+  std::vector<int> bad_kind(n_threads, 0);  // 1: invalid nucleotide, 2: a field that is not a number
+  std::vector<std::string> bad_text(n_threads);
+  auto parse_range = [&](size_t t) {
+    const size_t lo = n_lines * t / n_threads, hi = n_lines * (t + 1) / n_threads;
+    char buf[64];
+    auto number = [&](const char* fb, const char* fe, double* out) {  // strtod on a bounded copy (fields are not terminated)
+      const size_t len = std::min<size_t>((size_t)(fe - fb), sizeof buf - 1);
+      std::memcpy(buf, fb, len);
+      buf[len] = 0;
+      char* endp = nullptr;
+      *out = std::strtod(buf, &endp);
+      return endp != buf;
+    };
+    for (size_t i = lo; i < hi; ++i) {
+      const Line& ln = lines[i];
+      const char* t1 = static_cast<const char*>(std::memchr(ln.b, '\t', (size_t)(ln.e - ln.b)));
+      uint64_t code = 0;
+      bool ok = true;
+      for (int j = 0; j < k && ok; ++j) {
+        const char c = rna ? ln.b[k - 1 - j] : ln.b[j];  // 5'->3' file, 3'->5' sequencing
+        const int dgt = base_digit[(unsigned char)c];
+        if (dgt < 0 || dgt >= alphabet) ok = false;
+        else code = code * (uint64_t)alphabet + (uint64_t)dgt;
+      }
+      if (!ok) {
+        bad_line[t] = i;
+        bad_kind[t] = 1;
+        bad_text[t].assign(ln.b, (size_t)k);
+        if (rna) bad_text[t].assign(bad_text[t].rbegin(), bad_text[t].rend());
+        return;
+      }
+      // fields 2 and 3; a missing field is an empty string, which strtod rejects like the reference's std::stod
+      const char* f2b = t1 ? t1 + 1 : ln.e;
+      const char* t2 = t1 ? static_cast<const char*>(std::memchr(f2b, '\t', (size_t)(ln.e - f2b))) : nullptr;
+      const char* f2e = t2 ? t2 : ln.e;
+      const char* f3b = t2 ? t2 + 1 : ln.e;
+      const char* t3 = t2 ? static_cast<const char*>(std::memchr(f3b, '\t', (size_t)(ln.e - f3b))) : nullptr;
+      const char* f3e = t3 ? t3 : ln.e;
+      if (!number(f2b, f2e, &means[i]) || !number(f3b, f3e, &sds[i])) {
+        bad_line[t] = i;
+        bad_kind[t] = 2;
+        return;
+      }
+      codes[i] = code;
     }
-    mean[code] = parse_field(r.mean);
-    stdev[code] = parse_field(r.stdev);
+  };
+  {
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < n_threads; ++t) workers.emplace_back(parse_range, t);
+    parse_range(0);
+    for (std::thread& w : workers) w.join();
+  }
+  for (size_t t = 0; t < n_threads; ++t) {  // ranges are in file order: the first one with a complaint holds the first bad line
+    if (bad_line[t] == SIZE_MAX) continue;
+    if (bad_kind[t] == 1) throw std::runtime_error("Invalid nucleotide in k-mer: " + bad_text[t]);
+    throw std::invalid_argument("stod");
+  }
+  for (size_t i = 0; i < n_lines; ++i) {
+    mean[codes[i]] = means[i];
+    stdev[codes[i]] = sds[i];
   }
   highest_power = 1;
   for (int i = 1; i < k; ++i) highest_power *= (uint64_t)alphabet;
 
   table.resize(num_kmers);
-  for (uint64_t i = 0; i < num_kmers; ++i) {
+  {
     // std::log: the same libm call the reference makes per cell (aligner.cpp:291)
-    table[i] = dynmath::make_emis(mean[i], stdev[i], std::log(stdev[i]));
+    auto fill = [&](size_t t) {
+      for (uint64_t i = num_kmers * t / n_threads; i < num_kmers * (t + 1) / n_threads; ++i)
+        table[i] = dynmath::make_emis(mean[i], stdev[i], std::log(stdev[i]));
+    };
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < n_threads; ++t) workers.emplace_back(fill, t);
+    fill(0);
+    for (std::thread& w : workers) w.join();
   }
 }
 
