@@ -35,7 +35,7 @@ __device__ __forceinline__ void store_row(double* row, int lane, double v) {
   __builtin_nontemporal_store(h, reinterpret_cast<f2*>(row + 384 + lane));
 }
 
-// mode: 0 = B on every wave, 1 = F on every wave, 2 = mix
+// mode: 0 = B on every wave, 1 = F on every wave, 2 = mix, 3 = F with the LPE / bits stores of two rows issued together
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k(double* ws, float* lpe, unsigned long long* bits, int rows, int mode, double* sink) {
   __shared__ __attribute__((aligned(16))) double ring[4][D][P];
@@ -45,7 +45,7 @@ void k(double* ws, float* lpe, unsigned long long* bits, int rows, int mode, dou
   double* my_ws = ws + slot * (size_t)rows * P;
   float* my_lp = lpe + slot * (size_t)rows * P;
   unsigned long long* my_bits = bits + slot * (size_t)rows * 7;
-  const bool backward = mode == 0 || (mode == 2 && slot % 5 < 2);
+  const bool backward = mode == 0 || (mode == 2 && slot % 5 < 2);  // (mode 3: forward on every wave)
   double acc = 0.0;
   if (backward) {
     for (int t = rows - 1; t >= 0; --t) store_row(my_ws + (size_t)t * P, lane, (double)t);
@@ -59,12 +59,17 @@ void k(double* ws, float* lpe, unsigned long long* bits, int rows, int mode, dou
       const int nx = t + D < rows ? t + D : rows - 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       dma_row(src + (size_t)nx * P, base + (t % D) * ROWB);
-      float* o = my_lp + (size_t)t * P;
-      f2 h; h.x = h.y = (float)t;
+      if (mode != 3 || (t & 1)) {
+        for (int tt = (mode == 3 ? t - 1 : t); tt <= t; ++tt) {
+          float* o = my_lp + (size_t)tt * P;
+          f2 h; h.x = h.y = (float)tt;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) __builtin_nontemporal_store(h, reinterpret_cast<f2*>(o + q * 128 + lane * 2));
-      __builtin_nontemporal_store((float)t, o + 384 + lane);
-      if (lane < 7) my_bits[(size_t)t * 7 + lane] = (unsigned long long)t;
+          for (int q = 0; q < 3; ++q) __builtin_nontemporal_store(h, reinterpret_cast<f2*>(o + q * 128 + lane * 2));
+          __builtin_nontemporal_store((float)tt, o + 384 + lane);
+        }
+        if (mode == 3) { if (lane < 14) my_bits[(size_t)(t - 1) * 7 + lane] = (unsigned long long)t; }
+        else if (lane < 7) my_bits[(size_t)t * 7 + lane] = (unsigned long long)t;
+      }
     }
     wait_vm<0>();
   }
@@ -78,14 +83,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ws, cells * 8)); CK(hipMalloc(&lpe, cells * 4)); CK(hipMalloc(&bits, slots * (size_t)rows * 56)); CK(hipMalloc(&sink, 8));
   CK(hipMemset(ws, 0, cells * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const char* names[3] = {"B (backward: 3584 B/row written)", "F (forward: 3584 B/row read by LDS-DMA + 1848 B/row written)", "M (2 of 5 waves B, 3 of 5 F)"};
-  for (int mode = 0; mode < 3; ++mode) {
+  const char* names[4] = {"B (backward: 3584 B/row written)", "F (forward: 3584 B/row read by LDS-DMA + 1848 B/row written)", "M (2 of 5 waves B, 3 of 5 F)",
+                          "F2 (forward, the float / bit stores of two rows issued together)"};
+  for (int mode = 0; mode < 4; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
       hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, ws, lpe, bits, rows, mode, sink);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      const double nb = mode == 0 ? 1.0 : mode == 1 ? 0.0 : 410.0 / 1024.0;  // 1024 slots: slot % 5 < 2 -> 410 of them
+      const double nb = mode == 0 ? 1.0 : (mode == 1 || mode == 3) ? 0.0 : 410.0 / 1024.0;  // 1024 slots: slot % 5 < 2 -> 410 of them
       const double bytes = (double)slots * rows * (nb * ROWB + (1.0 - nb) * (ROWB + P * 4 + 56));
       if (rep) printf("%-64s rep %d  %.3f ms  %.2f TB/s\n", names[mode], rep, ms, bytes / ms * 1e-9);
     }
