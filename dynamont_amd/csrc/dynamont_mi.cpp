@@ -1168,15 +1168,29 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));
   pool.ctl = a->ctl.as<uint32_t>();
 
-  // Page-starved launches: the queue order is planned (plan_queue above); `rows` is each read's duration.
+  // Page-starved launches: the queue order is planned (plan_queue above); `rows` is each read's duration. The planner
+  // works on a queue in LENGTH order (pages descending). A launch with strict reads is in cost order: when its first
+  // round does not fit the pool it goes back to length order first -- a strict read costs 1.2x a plain one of its length,
+  // which matters far less than idle slots in a starved launch (config 3 holds ~50 tie reads in 4 096; round 4's first
+  // builds skipped the planner for such launches).
   if (lattice && order.size() > n_slots && !std::getenv("DYN_NO_BRIDGE")) {
-    std::vector<uint32_t> need(order.size());
-    std::vector<uint64_t> rows(order.size());
-    for (size_t k = 0; k < order.size(); ++k) {
-      need[k] = pages_of(b->reads[order[k]].S);
-      rows[k] = cost_rows(order[k]);
+    bool plan = true;
+    if (n_strict) {
+      uint64_t first_round = 0;
+      for (size_t k = 0; k < n_slots; ++k) first_round += pages_of(b->reads[order[k]].S);
+      plan = first_round > pool.n_pages;
+      if (plan)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->reads[x].S > b->reads[y].S; });
     }
-    if (!n_strict) plan_queue(order, need, rows, n_slots, pool.n_pages);  // the planner assumes pages ~ duration
+    if (plan) {
+      std::vector<uint32_t> need(order.size());
+      std::vector<uint64_t> rows(order.size());
+      for (size_t k = 0; k < order.size(); ++k) {
+        need[k] = pages_of(b->reads[order[k]].S);
+        rows[k] = cost_rows(order[k]);
+      }
+      plan_queue(order, need, rows, n_slots, pool.n_pages);
+    }
   }
 
   // (Dealing the first round's strict reads out across the CUs instead of four to a CU was measured: 50.6 vs 50.9 ms on
