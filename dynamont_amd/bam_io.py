@@ -9,6 +9,7 @@ tests and for producing synthetic datasets; they emit only what the readers cons
 """
 from __future__ import annotations
 
+import binascii
 import gzip
 import struct
 import zlib
@@ -18,9 +19,7 @@ import numpy as np
 from dynamont_amd.pod5_io import BasecallRecord
 
 _SEQ_DECODE = "=ACMGRSVTWYHKDBN"
-# packed byte -> its two bases (one table lookup per byte instead of a Python expression per base: a 2 000-base
-# record costs 6 us instead of 120)
-_SEQ_LUT = np.array([[ord(_SEQ_DECODE[b >> 4]), ord(_SEQ_DECODE[b & 15])] for b in range(256)], dtype=np.uint8)
+_HEX_TO_BASE = bytes.maketrans(b"0123456789abcdef", _SEQ_DECODE.encode())
 _TAG_SIZE = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
 _TAG_NP = {"c": "<i1", "C": "<u1", "s": "<i2", "S": "<u2", "i": "<i4", "I": "<u4", "f": "<f4"}
 _TAG_FMT = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
@@ -54,18 +53,31 @@ def iter_sam(path: str):
 class _Stream:
     """Bounded-memory reader over the inflated BGZF stream (a series of gzip members, which Python's gzip module
     reads as one stream): a multi-GB dorado BAM is never held in memory, and the first record is available after
-    the first block."""
+    the first chunk. The stream is pulled in 1 MB pieces and records are cut out of that buffer: two gzip reads per
+    record (its length, its body) cost more than parsing the record."""
+
+    CHUNK = 1 << 20
 
     def __init__(self, path: str):
         self.f = gzip.open(path, "rb")
+        self.buf = b""
+        self.pos = 0
 
     def take(self, n: int) -> bytes:
-        out = self.f.read(n)
-        while len(out) < n:
-            more = self.f.read(n - len(out))
-            if not more:
-                break
-            out += more
+        if self.pos + n > len(self.buf):
+            rest = self.buf[self.pos:]
+            parts = [rest]
+            have = len(rest)
+            while have < n:
+                more = self.f.read(max(self.CHUNK, n - have))
+                if not more:
+                    break
+                parts.append(more)
+                have += len(more)
+            self.buf = b"".join(parts)
+            self.pos = 0
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += len(out)
         return out
 
     def close(self):
@@ -105,7 +117,9 @@ def _parse_bam_record(path: str, data: bytes):
     name = data[q:q + l_read_name - 1].decode()
     q += l_read_name + 4 * n_cigar
     nb = (l_seq + 1) // 2
-    seq = _SEQ_LUT[np.frombuffer(data, dtype=np.uint8, count=nb, offset=q)].tobytes()[:l_seq].decode("ascii")
+    # two bases per byte, high nibble first: hexlify spells the nibbles out as hex digits, translate maps those to bases
+    # (two C calls per record; the NumPy table lookup this replaces cost 3 us of call overhead for a 2 000-base read)
+    seq = binascii.hexlify(data[q:q + nb]).translate(_HEX_TO_BASE)[:l_seq].decode("ascii")
     q += nb + l_seq
     tags = {}
     while q < end:
