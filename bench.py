@@ -504,6 +504,11 @@ def main():
         elif n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         if plain is not None:
+            # the same algorithmic bytes over the plain kernel's launch time: what `roofline.frac` was before bit-exact
+            # borders became the default (in cfg2 every wave holds ONE read, so the default launch lasts as long as its
+            # slowest, certified read)
+            if plain.get("avg_launch_ms"):
+                plain["roofline_frac"] = round(cells_per_launch * bpc / (plain["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             line["plain_arithmetic"] = plain
         assert line["n_gpus"] == args.gpus
     al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
