@@ -13,7 +13,11 @@ kernels exactly as a stream of batches does in production; the timed region star
 pipeline and ends when the last batch's results are in host memory (and, for N > 1, the RCCL
 collective of the last step is complete). `value` = signal samples of all ranks / max-over-ranks
 wall time. The kernel-only rate with inputs resident in HBM is reported as the secondary
-`kernel_resident_Msamp_s`.
+`kernel_resident_Msamp_s` -- of ONE batch in one launch: the engine merges tickets that wait while the GPU is busy into one
+launch (include/dynamont_mi.h), and a launch of two or three 1 024-read batches balances better than one of a single batch,
+so `pipeline_efficiency` can exceed 1. `roofline` prices the launches as they ran: `cells_per_launch`, `avg_launch_ms` and
+`batches_per_launch` describe the merged launches (HIP events per launch, each counted once through the tickets'
+`launch_share`), which is what a rocprofv3 kernel trace of the same command shows.
 
 N = 1 workload: BASELINE.json configs[1] -- 1 024 synthetic RNA004 reads x ~20 k samples per batch,
 synthetic 9-mer model, --mode basic, band 400. N > 1: configs[3]'s per-GPU share, 4 096 reads per
@@ -69,7 +73,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=0, help="distinct batches the steps cycle through (0 = workload default)")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight")
+    ap.add_argument("--depth", type=int, default=6,
+                    help="batches in flight. The engine merges tickets that wait while the GPU is busy into one launch (a launch "
+                         "of 1 024 reads on 1 024 waves cannot balance): 3 overlap copies with kernels, 6 let two or three "
+                         "batches share a launch")
     ap.add_argument("--pinned-inputs", action="store_true",
                     help="experiment: caller arrays in page-locked memory (dyn_host_alloc); default is ordinary NumPy memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -326,11 +333,16 @@ def main():
                 else:  # gloo rehearsal: host hop
                     gather_pending[slot] = dist.gather(sb.cpu(), gather_sets[slot] if rank == 0 else None, dst=0, async_op=True)
         if timed:
+            # tickets that waited together are merged into ONE launch by the engine: each reports that launch's timing and
+            # its share of it (dyn_timing.launch_share), so sums over tickets count every launch once
             tm = t.timing()
+            share = tm["launch_share"]
             for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy",
                         "ms_backward_strict", "ms_forward_strict"):
-                kern[key] += tm[key]
-            for key in ("launches", "cells", "lp_inplace", "reads_strict", "cert_fallbacks", "cert_rows"):
+                kern[key] += tm[key] * share
+            for key in ("launches", "lp_inplace", "cert_fallbacks", "cert_rows"):
+                launches[key] += tm[key] * share
+            for key in ("cells", "reads_strict"):
                 launches[key] += tm[key]
             launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
             launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
@@ -411,10 +423,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
             p_el = float(t[0].item())
             p_samples *= n_gpus
-        p_launch = max(1, launches["launches"] - keep[1]["launches"])
+        p_launch = max(1e-9, launches["launches"] - keep[1]["launches"])
+        p_cells, p_ms = launches["cells"] - keep[1]["cells"], kern["ms_dp"] - keep[0]["ms_dp"]
         plain = {"strict_mode": "off", "steps": p_steps, "value": round(p_samples / p_el / 1e6, 3), "unit": "Msamp/s",
                  "ms_per_step": round(p_el * 1e3 / p_steps, 3),
-                 "avg_launch_ms": round((kern["ms_dp"] - keep[0]["ms_dp"]) / p_launch, 3),
+                 "avg_launch_ms": round(p_ms / p_launch, 3), "batches_per_launch": round(p_steps / p_launch, 3),
+                 "cells": p_cells, "kernel_ms": round(p_ms, 3),
                  "note": "the table softplus alone: equal to the reference on every read without a structural tie, and on "
                          "3 397 of the 3 400 tie-bearing reads of tests/golden/g10_ties.npz"}
         al.set_strict(args.strict)
@@ -428,7 +442,7 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = total_samples / elapsed / 1e6
         cells_total = launches["cells"]
-        n_launch = max(1, launches["launches"])
+        n_launch = max(1e-9, launches["launches"])
         ms_dp = kern["ms_dp"] / n_launch             # average duration of the dominant kernel (HIP events on its stream)
         cells_per_launch = cells_total / n_launch
         inplace = bool(launches["lp_inplace"])
@@ -454,18 +468,21 @@ def main():
             # certified rows move the same bytes), quoted only for the workload and layout they were measured on
             "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, round %s)" % traffic.get("round")) if tbytes else None,
             "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
-            "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": n_launch,
+            "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": round(n_launch, 3),
             "avg_launch_ms": round(ms_dp, 3),
             # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
             "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
-                                "waiting_for_pages": round(kern["wave_wait_share"] / steps, 4)},
+                                "waiting_for_pages": round(kern["wave_wait_share"] / n_launch, 4)},
             # the two sweeps apart: their algorithmic bytes over their share of the launch (they overlap in time only
             # when waves are out of phase, i.e. in batches of more reads than waves)
             "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(ms_dp * share("ms_backward"), 3),
                                           "frac": round(cells_per_launch * KBWD_BYTES_PER_CELL / (ms_dp * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
                        "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(ms_dp * share("ms_forward"), 3),
                                          "frac": round(cells_per_launch * bpc_f / (ms_dp * share("ms_forward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_forward") else None}},
-            "wave_occupancy": round(kern["wave_occupancy"] / steps, 4),
+            "wave_occupancy": round(kern["wave_occupancy"] / n_launch, 4),
+            # tickets per launch: batches that were waiting while the GPU was busy share one launch (one queue balances
+            # what one read per wave cannot)
+            "batches_per_launch": round(steps / n_launch, 3),
             "page_pool": {"pages": launches["pool_pages"], "rows_per_page": launches["page_rows"],
                           "reads_with_reserved_pages": launches["n_static"], "waves": launches["n_waves"]},
         }
@@ -507,8 +524,8 @@ def main():
             # the same algorithmic bytes over the plain kernel's launch time: what `roofline.frac` was before bit-exact
             # borders became the default (in cfg2 every wave holds ONE read, so the default launch lasts as long as its
             # slowest, certified read)
-            if plain.get("avg_launch_ms"):
-                plain["roofline_frac"] = round(cells_per_launch * bpc / (plain["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            if plain.get("kernel_ms"):
+                plain["roofline_frac"] = round(plain.pop("cells") * bpc / (plain.pop("kernel_ms") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             line["plain_arithmetic"] = plain
         assert line["n_gpus"] == args.gpus
     al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)

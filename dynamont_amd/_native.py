@@ -54,7 +54,7 @@ class DynTiming(C.Structure):
                 ("page_rows", C.c_uint32), ("n_static", C.c_uint32), ("n_waves", C.c_uint32),
                 ("reads_strict", C.c_uint32), ("reserved", C.c_uint32),
                 ("ms_backward_strict", C.c_double), ("ms_forward_strict", C.c_double), ("cert_fallbacks", C.c_uint64),
-                ("cert_rows", C.c_uint64)]
+                ("cert_rows", C.c_uint64), ("launch_share", C.c_double)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)

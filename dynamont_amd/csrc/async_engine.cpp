@@ -104,19 +104,146 @@ void Pipeline::drain() {
   cv_done.wait(lk, [&] { return in_flight == 0; });
 }
 
+// ---- merged launches ---------------------------------------------------------------------------------
+// A read-queue launch of FEWER reads than waves cannot balance: every wave holds one read and the launch lasts as long
+// as its slowest one (BASELINE config 2 with its 26 % certified reads: a fifth of the wave time idles). Tickets that are
+// waiting while the GPU still has work queued are therefore merged into ONE batch -- one launch, one queue, the waves
+// that finish early take the next reads -- instead of one launch each. Rules (front_loop):
+//   * at most one launch is queued behind the one that runs: a third waits as tickets, where it can still be merged;
+//   * with the GPU busy the front thread lingers up to 2 ms for tickets that are about to arrive (a consumer that has
+//     just got two results back submits two new batches a fraction of a millisecond apart);
+//   * only align tickets of the same kind (same calc flag, same raw format and preprocessing) are merged, up to
+//     MERGE_MAX_TICKETS tickets and three reads per wave slot -- at three the queue balances to within a few per cent
+//     (config 2: 41.3 ms per batch against 40.4 for an endless queue), and launches stay short enough for the copies of
+//     the next one to hide behind them; training tickets never are (their pooled statistics are per batch).
+// With nothing queued behind it a ticket starts at once, alone: latency is only ever added while the GPU is busy anyway.
+constexpr size_t MERGE_MAX_TICKETS = 16;
+constexpr uint64_t MERGE_READS_PER_SLOT = 3;
+
+static uint64_t merge_max_reads(const dyn_aligner* a) { return MERGE_READS_PER_SLOT * (uint64_t)a->n_cus * dynk::WAVES_PER_CU; }
+static bool mergeable(const dyn_batch* x) {
+  return x->job != DynJob::Train && x->n > 0 && 2 * x->n <= merge_max_reads(x->a);
+}
+static bool same_kind(const dyn_batch* x, const dyn_batch* y) {
+  if (x->job != y->job || x->has_raw != y->has_raw) return false;
+  if (!x->has_raw) return true;
+  const RawSource &p = x->raw_src, &q = y->raw_src;
+  return p.vbz == q.vbz && p.dtype == q.dtype && p.window == q.window && p.n_sigmas == q.n_sigmas && p.compute_f32 == q.compute_f32;
+}
+
+BatchGroup::~BatchGroup() {
+  if (g) dyn_batch_destroy(g);
+}
+
+// one batch out of several tickets: per-read metadata concatenated, bulk data left where it is (a pointer per read)
+std::shared_ptr<BatchGroup> Pipeline::merge(const std::vector<dyn_batch*>& tickets) {
+  auto grp = std::make_shared<BatchGroup>();
+  dyn_batch* first = tickets[0];
+  uint64_t n = 0;
+  for (dyn_batch* t : tickets) n += t->n;
+  grp->sig_offsets.assign(1, 0);
+  grp->seq_offsets.assign(1, 0);
+  const bool raw = first->has_raw, vbz = raw && first->raw_src.vbz;
+  const size_t esz = raw ? first->raw_src.elem_size() : 8;
+  if (vbz) grp->vbz_read_off.assign(1, 0);
+  for (dyn_batch* t : tickets) {
+    t->g_read0 = grp->sig_offsets.size() - 1;
+    const RawSource& rs = t->raw_src;
+    for (uint64_t i = 0; i < t->n; ++i) {
+      const uint64_t len = t->in_sig_offsets[i + 1] - t->in_sig_offsets[i];
+      grp->sig_offsets.push_back(grp->sig_offsets.back() + len);
+      grp->seq_offsets.push_back(grp->seq_offsets.back() + (t->in_seq_offsets[i + 1] - t->in_seq_offsets[i]));
+      if (!raw) {
+        grp->ptrs.push_back(t->in_signals + t->in_sig_offsets[i]);
+      } else if (vbz) {
+        for (uint64_t c = rs.vbz_read_off[i]; c < rs.vbz_read_off[i + 1]; ++c) {
+          grp->ptrs.push_back(rs.vbz_chunks[c]);
+          grp->vbz_bytes.push_back(rs.vbz_bytes[c]);
+          grp->vbz_samples.push_back(rs.vbz_samples[c]);
+        }
+        grp->vbz_read_off.push_back(grp->ptrs.size());
+        grp->vbz_skip.push_back(rs.vbz_skip[i]);
+      } else if (rs.scattered) {
+        grp->ptrs.push_back(static_cast<const void* const*>(rs.raw)[i]);
+      } else {
+        grp->ptrs.push_back(static_cast<const char*>(rs.raw) + t->in_sig_offsets[i] * esz);
+      }
+      if (raw) {
+        grp->shift.push_back(rs.shift[i]);
+        grp->scale.push_back(rs.scale[i]);
+        if (rs.dtype == 3) {
+          grp->cal_offset.push_back(rs.cal_offset[i]);
+          grp->cal_scale.push_back(rs.cal_scale[i]);
+        }
+      }
+    }
+    grp->seqs.append(t->in_seqs + t->in_seq_offsets[0], t->in_seq_offsets[t->n] - t->in_seq_offsets[0]);
+  }
+  dyn_batch* g = new dyn_batch();
+  g->a = a;
+  attach_cache(g);
+  g->n = n;
+  g->job = first->job;
+  g->in_sig_offsets = grp->sig_offsets.data();
+  g->in_seqs = grp->seqs.data();
+  g->in_seq_offsets = grp->seq_offsets.data();
+  if (!raw) {
+    g->in_sig_ptrs = reinterpret_cast<const double* const*>(grp->ptrs.data());
+  } else {
+    g->has_raw = true;
+    RawSource rs = first->raw_src;
+    rs.raw = grp->ptrs.data();
+    rs.scattered = !vbz;
+    rs.shift = grp->shift.data();
+    rs.scale = grp->scale.data();
+    rs.cal_offset = rs.dtype == 3 ? grp->cal_offset.data() : nullptr;
+    rs.cal_scale = rs.dtype == 3 ? grp->cal_scale.data() : nullptr;
+    if (vbz) {
+      rs.vbz_chunks = grp->ptrs.data();
+      rs.vbz_bytes = grp->vbz_bytes.data();
+      rs.vbz_samples = grp->vbz_samples.data();
+      rs.vbz_read_off = grp->vbz_read_off.data();
+      rs.vbz_skip = grp->vbz_skip.data();
+    }
+    g->raw_src = rs;
+  }
+  grp->g = g;
+  grp->members = tickets;
+  return grp;
+}
+
 void Pipeline::front_loop() {
   if (!a->host_only) (void)hipSetDevice(a->device);
+  const bool merging = !a->host_only && std::getenv("DYN_NO_MERGE") == nullptr;
   for (;;) {
-    dyn_batch* b = nullptr;
+    std::vector<dyn_batch*> take;
     {
       std::unique_lock<std::mutex> lk(m);
-      cv_front.wait(lk, [&] { return stop || !q_front.empty(); });
+      cv_front.wait(lk, [&] { return (stop || !q_front.empty()) && (launches_pending < 2 || (stop && q_front.empty())); });
       if (q_front.empty()) return;  // stop requested and nothing left
-      b = q_front.front();
+      if (merging && launches_pending >= 1 && mergeable(q_front.front()) && q_front.size() < MERGE_MAX_TICKETS)
+        cv_front.wait_for(lk, std::chrono::milliseconds(2), [&] { return stop || q_front.size() >= MERGE_MAX_TICKETS; });
+      take.push_back(q_front.front());
       q_front.pop_front();
+      uint64_t reads = take[0]->n;
+      while (merging && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < MERGE_MAX_TICKETS &&
+             mergeable(q_front.front()) && same_kind(take[0], q_front.front()) && reads + q_front.front()->n <= merge_max_reads(a)) {
+        reads += q_front.front()->n;
+        take.push_back(q_front.front());
+        q_front.pop_front();
+      }
+      ++launches_pending;
     }
-    const int rc = front_stage(b);
-    if (rc != DYN_OK && !a->host_only) {
+    Work w;
+    if (take.size() > 1) {
+      w.grp = merge(take);
+      w.b = w.grp->g;
+      for (dyn_batch* t : take) t->group = w.grp;
+    } else {
+      w.b = take[0];
+    }
+    w.rc = front_stage(w.b);
+    if (w.rc != DYN_OK && !a->host_only) {
       // whatever part of the batch was already enqueued must have left the GPU before the caller may tear it down
       for (hipStream_t st : {a->s_in, a->stream, a->s_out})
         if (st) (void)hipStreamSynchronize(st);
@@ -124,8 +251,7 @@ void Pipeline::front_loop() {
     }
     {
       std::lock_guard<std::mutex> lk(m);
-      b->rc = rc;
-      q_back.push_back(b);  // failed batches pass through the back thread too: completion stays in order
+      q_back.push_back(w);  // failed batches pass through the back thread too: completion stays in order
     }
     cv_back.notify_one();
   }
@@ -134,23 +260,35 @@ void Pipeline::front_loop() {
 void Pipeline::back_loop() {
   if (!a->host_only) (void)hipSetDevice(a->device);
   for (;;) {
-    dyn_batch* b = nullptr;
+    Work w;
     {
       std::unique_lock<std::mutex> lk(m);
       cv_back.wait(lk, [&] { return stop || !q_back.empty(); });
       if (q_back.empty()) return;
-      b = q_back.front();
+      w = q_back.front();
       q_back.pop_front();
     }
-    int rc = b->rc;
-    if (rc == DYN_OK) rc = back_stage(b);
+    int rc = w.rc;
+    if (rc == DYN_OK) rc = back_stage(w.b, w.grp);
     {
       std::lock_guard<std::mutex> lk(m);
-      b->rc = rc;
-      b->done = true;
-      --in_flight;
+      if (w.grp) {
+        for (dyn_batch* t : w.grp->members) {
+          t->rc = rc;
+          if (rc != DYN_OK) t->error = w.b->error;
+          t->done = true;
+          --in_flight;
+        }
+        w.grp->members.clear();
+      } else {
+        w.b->rc = rc;
+        w.b->done = true;
+        --in_flight;
+      }
+      --launches_pending;
     }
     cv_done.notify_all();
+    cv_front.notify_all();  // the gate on launches_pending
   }
 }
 
@@ -248,6 +386,16 @@ int Pipeline::front_stage(dyn_batch* b) {
     P_TRY(b, b->d_meta.ensure(meta + total_sig * esz));
     P_TRY(b, b->d_norm.ensure(total_sig * (rs.compute_f32 ? 4 : 8)));
     P_TRY(b, hipMemcpyAsync(b->d_meta.p, b->h_sig.p, meta + bytes, hipMemcpyHostToDevice, a->s_in));
+  } else if (total_sig && b->in_sig_ptrs) {
+    // a merged batch of float64 signals: one pointer per read, gathered into the pinned staging buffer by the helpers
+    P_TRY(b, b->h_sig.ensure(total_sig * 8));
+    double* dst = b->h_sig.as<double>();
+    const int parts = std::max(1, std::min<int>(helpers.size() * 4, (int)(n / 8)));
+    helpers.parallel_for(parts, [&](int t) {
+      for (uint64_t i = n * t / parts; i < n * (t + 1) / parts; ++i)
+        std::memcpy(dst + (b->in_sig_offsets[i] - b->in_sig_offsets[0]), b->in_sig_ptrs[i], (b->in_sig_offsets[i + 1] - b->in_sig_offsets[i]) * 8);
+    });
+    P_TRY(b, hipMemcpyAsync(b->d_sig.p, dst, total_sig * 8, hipMemcpyHostToDevice, a->s_in));
   } else if (total_sig) {
     const double* src = b->in_signals + b->in_sig_offsets[0];
     if (!is_pinned(src)) {
@@ -317,7 +465,7 @@ int Pipeline::front_stage(dyn_batch* b) {
 }
 
 // Wait for the batch's last D2H, then turn the device records into the caller's arrays.
-int Pipeline::back_stage(dyn_batch* b) {
+int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
   const double t0 = now_ms();
   P_TRY(b, hipEventSynchronize(b->ev_out));
   const double t1 = now_ms();
@@ -333,6 +481,34 @@ int Pipeline::back_stage(dyn_batch* b) {
     const uint64_t c = need_cols ? b->total_cols : 0;
     const double* h = b->h_rows.as<double>();
     finalise_train(b, st, h, h + c, h + 2 * c, h + 3 * c, b->out_train, b->out_pooled);
+  } else if (grp) {
+    // a merged launch: every member gets its reads' results in its own arrays, the launch's timing, and its own counts
+    // (dyn_timing.launch_share = its part of the launch, by lattice cells)
+    for (dyn_batch* t : grp->members) {
+      dyn_align_out* out = t->out_align;
+      t->capacity = 0;
+      for (uint64_t i = 0; i < t->n; ++i) t->capacity += b->reads[t->g_read0 + i].kc;
+      t->g_seg0 = t->n ? b->reads[t->g_read0].seg_off : 0;
+      const bool want_rows = b->job == DynJob::AlignFull && t->capacity &&
+                             (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
+      unpack_align(b, st, want_rows ? b->h_rows.as<SegRow>() : nullptr, out, &helpers, t->g_read0, t->n, t->g_seg0);
+      dyn_timing tm = b->timing;
+      tm.cells = tm.samples = tm.reads_ok = 0;
+      tm.reads_strict = 0;
+      for (uint64_t i = 0; i < t->n; ++i) {
+        const HostRead& r = b->reads[t->g_read0 + i];
+        if (r.status != DYN_READ_OK || st[t->g_read0 + i].status == DYN_READ_TOO_LARGE) continue;  // never reached the device
+        const uint64_t N = r.kc + 1, bw = std::min<uint64_t>(a->model.half_band, N / 2);
+        tm.cells += (r.S + 1) * std::min<uint64_t>(2 * bw + 1, N);
+        tm.samples += r.S;
+        ++tm.reads_ok;
+        if (t->g_read0 + i < b->strict_flag.size()) tm.reads_strict += b->strict_flag[t->g_read0 + i];
+      }
+      tm.launch_share = b->timing.cells ? (double)tm.cells / (double)b->timing.cells : 0.0;
+      t->timing = tm;
+      t->aligned = true;
+      t->last_calc = b->last_calc;
+    }
   } else {
     dyn_align_out* out = b->out_align;
     const bool want_rows = b->job == DynJob::AlignFull && b->capacity &&

@@ -1288,6 +1288,9 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, hipGetLastError());
   tm.reads_ok = n_ok;
   tm.reads_strict = (uint32_t)n_strict;
+  tm.launch_share = 1.0;
+  b->strict_flag.assign(b->n, 0);
+  for (uint64_t i = 0; i < b->n; ++i) b->strict_flag[i] = strict_rows[i] != 0;
   tm.launches = nr ? 1 : 0;
   tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
   tm.pool_pages = pool.n_pages;
@@ -1345,33 +1348,37 @@ int collect_timing(dyn_batch* b) {
 // array-of-rows -> the caller's columns; reads are independent, so contiguous ranges of reads go to
 // the helper threads (2 M segments per 1 024-read batch take ~10 ms on one core)
 void unpack_align(const dyn_batch* b, const ReadState* st, const SegRow* rows, dyn_align_out* out,
-                  HelperPool* pool) {
+                  HelperPool* pool, uint64_t read0, uint64_t n, uint64_t seg0) {
+  if (n == ~0ull) n = b->n - read0;
   const bool want_rows = rows != nullptr;
+  uint64_t cap = 0;
+  for (uint64_t i = read0; i < read0 + n; ++i) cap += b->reads[i].kc;
   auto unpack = [&](uint64_t lo, uint64_t hi) {
     for (uint64_t i = lo; i < hi; ++i) {
       const HostRead& r = b->reads[i];
+      const uint64_t j = i - read0, so = r.seg_off - seg0;  // the caller's indices
       const bool ok = st[i].status == DYN_READ_OK;
-      out->status[i] = st[i].status;
-      out->Z[i] = ok ? st[i].Zb : 0.0;  // Result::Z = Zb (NT_aligner_api.cpp:293)
-      if (out->bad_char) out->bad_char[i] = r.bad;
-      if (out->seg_offsets) out->seg_offsets[i] = r.seg_off;
+      out->status[j] = st[i].status;
+      out->Z[j] = ok ? st[i].Zb : 0.0;  // Result::Z = Zb (NT_aligner_api.cpp:293)
+      if (out->bad_char) out->bad_char[j] = r.bad;
+      if (out->seg_offsets) out->seg_offsets[j] = so;
       const uint64_t ns = (ok && b->last_calc) ? st[i].n_segments : 0;
-      if (out->n_segments) out->n_segments[i] = ns;
+      if (out->n_segments) out->n_segments[j] = ns;
       if (want_rows) {
         for (uint64_t s = 0; s < ns; ++s) {
           const SegRow& row = rows[r.seg_off + s];
-          if (out->sequence_positions) out->sequence_positions[r.seg_off + s] = row.sequence_pos;
-          if (out->signal_positions) out->signal_positions[r.seg_off + s] = row.signal_pos;
-          if (out->probabilities) out->probabilities[r.seg_off + s] = row.probability;
-          if (out->states) out->states[r.seg_off + s] = 'M';
+          if (out->sequence_positions) out->sequence_positions[so + s] = row.sequence_pos;
+          if (out->signal_positions) out->signal_positions[so + s] = row.signal_pos;
+          if (out->probabilities) out->probabilities[so + s] = row.probability;
+          if (out->states) out->states[so + s] = 'M';
         }
       }
     }
   };
-  const int parts = (pool && want_rows && b->capacity > (1u << 16)) ? (int)std::min<uint64_t>(pool->size(), std::max<uint64_t>(1, b->n / 64)) : 1;
-  if (parts <= 1) unpack(0, b->n);
-  else pool->parallel_for(parts, [&](int t) { unpack(b->n * t / parts, b->n * (t + 1) / parts); });
-  if (out->seg_offsets) out->seg_offsets[b->n] = b->capacity;
+  const int parts = (pool && want_rows && cap > (1u << 16)) ? (int)std::min<uint64_t>(pool->size(), std::max<uint64_t>(1, n / 64)) : 1;
+  if (parts <= 1) unpack(read0, read0 + n);
+  else pool->parallel_for(parts, [&](int t) { unpack(read0 + n * t / parts, read0 + n * (t + 1) / parts); });
+  if (out->seg_offsets) out->seg_offsets[n] = cap;
 }
 
 // Host finalisation of runTraining (NT_aligner_api.cpp:516-535) from per-column sums, and of
@@ -1489,6 +1496,13 @@ int dyn_batch_timing(const dyn_batch* b, dyn_timing* t) {
 
 int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, void** d_z_status) {
   if (!b || !b->aligned) return DYN_ERR_INVALID_ARGUMENT;
+  if (b->group && b->group->g) {  // a member of a merged launch: its slice of the group's device arrays
+    const dyn_batch* g = b->group->g;
+    if (d_rows) *d_rows = static_cast<char*>(g->d_rows.p) + b->g_seg0 * sizeof(SegRow);
+    if (capacity) *capacity = b->capacity;
+    if (d_z_status) *d_z_status = static_cast<char*>(g->d_state.p) + b->g_read0 * sizeof(ReadState);
+    return DYN_OK;
+  }
   if (d_rows) *d_rows = b->d_rows.p;
   if (capacity) *capacity = b->capacity;
   if (d_z_status) *d_z_status = b->d_state.p;

@@ -148,6 +148,10 @@ struct RawSource {
   size_t elem_size() const { return dtype == 0 ? 4 : (dtype == 1 || dtype == 3) ? 2 : 8; }
 };
 
+namespace dyneng {
+struct BatchGroup;
+}
+
 struct dyn_batch {
   dyn_aligner* a = nullptr;
   uint64_t n = 0;
@@ -169,6 +173,7 @@ struct dyn_batch {
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;  // ev_done: every kernel of the last job has finished
   uint32_t n_chunks = 0;                       // launches enqueued by the last job (0 or 1)
+  std::vector<uint8_t> strict_flag;            // per read: took the certified sweeps in the last job
   dyn_timing timing{};
   bool aligned = false, trained = false;
   int last_calc = 0;
@@ -185,8 +190,32 @@ struct dyn_batch {
   int rc = DYN_OK;             // result of the pipeline stages
   std::string error;           // message for rc != DYN_OK (copied to the handle by dyn_batch_wait)
   bool done = false;
+  // ---- merged launches (async_engine.cpp): tickets that waited together share ONE read-queue launch ----
+  // A member ticket owns no device buffers of its own: its reads are reads [g_read0, g_read0 + n) and its segment rows
+  // [g_seg0, g_seg0 + capacity) of the group's batch, which lives as long as any member does.
+  std::shared_ptr<dyneng::BatchGroup> group;
+  uint64_t g_read0 = 0, g_seg0 = 0;
+  // merged batches (the group's own batch): no contiguous signal array -- one pointer per read (float64 samples)
+  const double* const* in_sig_ptrs = nullptr;
   const int32_t* kmers() const { return h_kmers.as<int32_t>(); }
 };
+
+namespace dyneng {
+
+// The batch a merged launch runs, and everything it borrows pointers into: the members' concatenated per-read metadata.
+struct BatchGroup {
+  dyn_batch* g = nullptr;               // the launch's batch (internal: never handed to a caller)
+  std::vector<dyn_batch*> members;      // in submission order; cleared once they are complete
+  std::vector<uint64_t> sig_offsets, seq_offsets, vbz_bytes, vbz_read_off, vbz_skip;
+  std::vector<uint32_t> vbz_samples;
+  std::vector<const void*> ptrs;        // one source pointer per read (raw slices, float64 signals) or per VBZ chunk
+  std::vector<double> shift, scale;
+  std::vector<float> cal_offset, cal_scale;
+  std::string seqs;
+  ~BatchGroup();
+};
+
+}  // namespace dyneng
 
 namespace dyneng {
 
@@ -204,9 +233,10 @@ int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig);
 int enqueue_job(dyn_batch* b, DynJob job);
 // after the compute stream has passed the batch: read the event timings into b->timing
 int collect_timing(dyn_batch* b);
-// rows/state (host copies) -> the caller's columns
+// rows/state (host copies) -> the caller's columns; reads [read0, read0 + n) of b, whose segment rows start at seg0, land at
+// index 0 of `out` (a member of a merged launch; the whole batch: read0 = seg0 = 0, n = b->n)
 void unpack_align(const dyn_batch* b, const dynk::ReadState* st, const dynk::SegRow* rows, dyn_align_out* out,
-                  HelperPool* pool);
+                  HelperPool* pool, uint64_t read0 = 0, uint64_t n = ~0ull, uint64_t seg0 = 0);
 // host finalisation of runTraining / trainTransition from host copies of the per-column sums
 void finalise_train(const dyn_batch* b, const dynk::ReadState* st, const double* cw, const double* c1,
                     const double* c2, const double* tr, dyn_train_out* out, double* pooled3n);
@@ -218,20 +248,30 @@ struct Pipeline {
   int wait(dyn_batch* b);
   void drain();
 
+  // one read-queue launch on its way through the stages: a ticket on its own, or a group of tickets merged into one batch
+  struct Work {
+    dyn_batch* b = nullptr;                  // the batch that runs (the ticket itself, or the group's batch)
+    std::shared_ptr<BatchGroup> grp;         // set for merged launches
+    int rc = DYN_OK;
+  };
+
   dyn_aligner* a;
   HelperPool helpers;
   std::thread t_front, t_back;
   std::mutex m;
   std::condition_variable cv_front, cv_back, cv_done;
-  std::deque<dyn_batch*> q_front, q_back;
-  uint64_t in_flight = 0;
+  std::deque<dyn_batch*> q_front;
+  std::deque<Work> q_back;
+  uint64_t in_flight = 0;        // tickets submitted and not yet done
+  uint64_t launches_pending = 0; // launches handed to the GPU whose results have not been unpacked yet
   bool stop = false;
 
  private:
   void front_loop();
   void back_loop();
   int front_stage(dyn_batch* b);
-  int back_stage(dyn_batch* b);
+  int back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp);
+  std::shared_ptr<BatchGroup> merge(const std::vector<dyn_batch*>& tickets);
 };
 
 }  // namespace dyneng

@@ -51,7 +51,9 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
-    p.add_argument("--depth", type=int, default=3, help="batches inside the asynchronous engine at once")
+    p.add_argument("--depth", type=int, default=6, help="batches inside the asynchronous engine at once (batches that wait "
+                   "while the GPU is busy are merged into one launch: a few more than the 2 that overlap copies with kernels "
+                   "let the launches balance)")
     p.add_argument("--strict-ties", type=str, default="ties", choices=["off", "ties", "start", "all"],
                    help="reproduce the reference's sums bit for bit (dyn_aligner_set_strict): 'ties' (default; 'start' is its "
                         "old name) for reads with a structural tie -- two neighbouring columns with the same emission "
@@ -412,7 +414,7 @@ class _NativePipeline:
 
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
-            host_preprocess: bool = False, depth: int = 3, strict_ties: str = "ties") -> None:
+            host_preprocess: bool = False, depth: int = 6, strict_ties: str = "ties") -> None:
     """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
     on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
     the writer (reads are independent; the gather is the only exchange)."""

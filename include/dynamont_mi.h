@@ -180,6 +180,12 @@ typedef struct dyn_timing {
   double ms_forward_strict;
   uint64_t cert_fallbacks;
   uint64_t cert_rows;    /* lattice rows computed in the certified arithmetic (both sweeps) */
+  /* (ABI 4) Asynchronous tickets that were waiting together while the GPU was busy are MERGED into one read-queue launch
+   * (a launch of fewer reads than waves cannot balance). Such a ticket reports the timing of the launch that carried it
+   * (ms_*, wave_*, cert_*) and its OWN reads, cells, samples and strict reads; launch_share is its part of that launch
+   * (its cells / the launch's cells; 1 for a ticket that ran alone): sum ms_dp x launch_share over tickets = GPU time,
+   * sum launch_share = number of launches. */
+  double launch_share;
 } dyn_timing;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
@@ -387,7 +393,13 @@ int dyn_plan_queue(uint64_t n_reads, const uint32_t* pages, const uint64_t* rows
  * valid and untouched until dyn_batch_wait(ticket) has returned. After the wait the ticket behaves
  * like an aligned batch: dyn_batch_timing and dyn_batch_device_results work on it. Release it with
  * dyn_batch_destroy (which waits first if need be). Inputs allocated with dyn_host_alloc are copied
- * by DMA without staging. */
+ * by DMA without staging.
+ * Merged launches: a read-queue launch of fewer reads than the device has waves (1 024) cannot balance -- every wave
+ * holds one read and the launch lasts as long as its slowest. Align tickets of one kind that are WAITING while the GPU
+ * still has a launch queued are therefore run as one launch (up to three reads per wave): same results, same
+ * completion order, and each ticket still reports the launch that carried it (dyn_timing, launch_share) and serves its
+ * own slice of the device rows (dyn_batch_device_results). A ticket that finds the GPU idle starts at once, alone;
+ * training tickets are never merged. Environment variable DYN_NO_MERGE=1 switches the merging off. */
 int dyn_batch_align_async(dyn_aligner* a, uint64_t n_reads, const double* signals,
                           const uint64_t* sig_offsets, const char* seqs, const uint64_t* seq_offsets,
                           int calc_probabilities, dyn_align_out* out, dyn_batch** ticket);

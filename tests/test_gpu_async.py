@@ -55,6 +55,62 @@ def test_async_equals_sync_with_batches_in_flight(models):
     al.close()
 
 
+def test_waiting_tickets_share_one_launch(models, monkeypatch):
+    """Merged launches (async_engine.cpp): tickets that wait while the GPU is busy run as ONE read-queue launch. Eight
+    tickets of 300 reads x ~4 k samples submitted at once: the first starts alone, later ones share launches (their
+    dyn_timing.launch_share is < 1 and the shares add up to the number of launches), every ticket's results and its slice
+    of the device rows equal the synchronous call's, a failed read stays with its own ticket, tickets of another kind
+    (calc_probabilities = false) are not merged with them -- and DYN_NO_MERGE=1 gives every ticket its own launch."""
+    import ctypes as C
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    data = []
+    for j in range(8):
+        reads = synth.make_reads(1300 + j, 300, "rna004", mean, sd, (300, 500))
+        if j == 5:
+            reads[7] = synth.SynthRead(reads[7].signal, reads[7].sequence[:40] + "N" + reads[7].sequence[41:])
+        data.append((reads, synth.pack_reads(reads)))
+    al = Aligner(models["syn9"], "rna004", device=0)
+    want = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data]
+    for attempt in range(3):   # (whether tickets meet in the queue is a matter of timing: 2 ms of lingering make it all but certain)
+        tickets = [al.align_async(*packed, True) for _, packed in data]
+        z_only = al.align_async(*data[0][1], False)
+        shares = []
+        for t, w in zip(tickets, want):
+            _same(t.wait(), w)
+            tm = t.timing()
+            shares.append(tm["launch_share"])
+            assert tm["reads_ok"] == int((w.status == 0).sum()) and tm["ms_dp"] > 0 and tm["launches"] == 1
+            ptr, cap, st = t.device_results()
+            assert cap == w.seg_offsets[-1]
+            rows = np.empty(int(cap), dtype=[("signal_pos", "<u4"), ("sequence_pos", "<u4"), ("probability", "<f8")])
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(rows.ctypes.data), C.c_void_p(ptr), C.c_size_t(rows.nbytes), 2) == 0   # device -> host
+            for i in range(w.n):
+                lo, ns = int(w.seg_offsets[i]), int(w.n_segments[i])
+                assert np.array_equal(rows["signal_pos"][lo:lo + ns], w.signal_positions[lo:lo + ns].astype(np.uint32))
+        zr = z_only.wait()
+        assert np.array_equal(zr.status, want[0].status) and z_only.timing()["launch_share"] == 1.0
+        assert np.allclose(zr.Z, want[0].Z, rtol=1e-9)
+        for t in tickets + [z_only]:
+            t.close()
+        merged = sum(1 for x in shares if x < 1.0)
+        if merged >= 4:
+            break
+    assert merged >= 4, shares
+    n_launches = sum(shares)
+    assert abs(n_launches - round(n_launches)) < 1e-9 and round(n_launches) < len(shares)
+    assert want[5].status[7] != 0 and sum(int((w.status != 0).sum()) for w in want) == 1
+    al.close()
+    monkeypatch.setenv("DYN_NO_MERGE", "1")
+    al = Aligner(models["syn9"], "rna004", device=0)
+    tickets = [al.align_async(*packed, True) for _, packed in data[:4]]
+    for t, w in zip(tickets, want):
+        _same(t.wait(), w)
+        assert t.timing()["launch_share"] == 1.0
+        t.close()
+    al.close()
+
+
 def test_async_isolates_failed_reads_and_matches_oracle(models):
     al = Aligner(models["syn9"], "rna004", device=0)
     orc = Oracle(models["syn9"], 1)
