@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e_cli` record (N = 1: the whole CLI on a synthetic .pod5 + basecall file)")
     ap.add_argument("--e2e-reads", type=int, default=32768, help="reads of the e2e_cli dataset (a multiple of 4 096: that many distinct reads, repeated)")
     ap.add_argument("--e2e-batch-reads", type=int, default=0, help="--batch-reads of the e2e_cli run (0 = the CLI's default)")
+    ap.add_argument("--no-resident", action="store_true", help="skip the kernel_resident leg (profiling runs: every launch of the process then belongs to the timed region)")
     ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
                     help="align = the headline metric; train = Baum-Welch statistics pass (config 5 shape, secondary)")
@@ -395,7 +396,7 @@ def main():
 
     # ---- secondary: kernels only, inputs resident in HBM (the round-1 headline) -----------------
     resident = None
-    if rank == 0 or use_dist:
+    if (rank == 0 or use_dist) and not args.no_resident:
         sig, sig_off, seqs, seq_off, _n = batches[0]
         with al.batch_packed(sig, sig_off, seqs, seq_off) as b0:
             best = None
@@ -457,6 +458,9 @@ def main():
         # PMC traffic is only quoted for the workload (and layout) it was measured on
         tinfo = traffic.get(tkey) or {}
         tbytes = tinfo.get("bytes_per_launch") if (workload == tinfo.get("workload") and not args.reads and not inplace) else None
+        if tbytes and tinfo.get("cells_per_launch"):
+            # the PMC passes measured launches of ONE batch; a merged launch moves the same bytes per cell
+            tbytes = int(round(tbytes * cells_per_launch / tinfo["cells_per_launch"]))
         achieved = cells_per_launch * bpc / (ms_dp * 1e-3) / 1e9 if ms_dp else 0.0
         share = lambda key: kern[key] / kern["ms_dp"] if kern["ms_dp"] else 0.0
         roofline = {
@@ -466,9 +470,11 @@ def main():
             "traffic": tbytes,
             # NOT a counter of this run: the committed rocprofv3 --pmc passes over the same command (plain arithmetic: the
             # certified rows move the same bytes), quoted only for the workload and layout they were measured on
-            "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, round %s)" % traffic.get("round")) if tbytes else None,
+            "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per lattice cell, round %s) x cells_per_launch" % traffic.get("round")) if tbytes else None,
             "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
             "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": round(n_launch, 3),
+            # totals of the timed region (what a rocprofv3 kernel trace of the same tickets adds up to: launches vary in size)
+            "cells_total": int(cells_total), "kernel_ms_total": round(kern["ms_dp"], 3),
             "avg_launch_ms": round(ms_dp, 3),
             # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
             "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),

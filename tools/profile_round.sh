@@ -14,19 +14,23 @@ run() { name=$1; shift; [[ $name =~ $ONLY ]] || return 0; echo "== $name"; timeo
 # (plain_arithmetic, e2e_cli) are switched off so that every launch in a profile belongs to the headline region; the plain
 # kernel k_read_queue<JOB_ALIGN, false> is profiled by its own runs (--strict off).
 X="--no-cpu-baseline --no-plain --no-e2e"
-run stats_align   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_align   -- python3 $B $X --steps 8
-run stats_align_plain rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_align_plain -- python3 $B $X --steps 8 --strict off
-run stats_train   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train   -- python3 $B $X --steps 8 --mode train
-run stats_cfg3    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3    -- python3 $B $X --workload cfg3 --steps 3 --warmup 1 --batches 1
-run pmc_fetch_align rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_align -- python3 $B $X --steps 2 --warmup 0 --batches 1
-run pmc_write_align rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_align -- python3 $B $X --steps 2 --warmup 0 --batches 1
-run pmc_sq_align  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_align -- python3 $B $X --steps 2 --warmup 0 --batches 1
-run pmc_fetch_align_plain rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --strict off
-run pmc_write_align_plain rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --strict off
-run pmc_sq_align_plain  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --strict off
-run pmc_fetch_train rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --mode train
-run pmc_write_train rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --mode train
-run pmc_sq_train  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --mode train
+# stats runs: no warm-up, no resident leg -- every k_read_queue launch of the process belongs to the timed region, so that
+# rocprofv3's Calls / TotalDurationNs are the bench line's roofline.launches / kernel_ms_total (the engine merges tickets
+# that wait into one launch: launches differ in size, the totals are what has to agree)
+S="$X --no-resident --warmup 0"
+run stats_align   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_align   -- python3 $B $S --steps 24
+run stats_align_plain rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_align_plain -- python3 $B $S --steps 24 --strict off
+run stats_train   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train   -- python3 $B $S --steps 12 --mode train
+run stats_cfg3    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3    -- python3 $B $S --workload cfg3 --steps 4 --batches 1
+run pmc_fetch_align rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_align -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1
+run pmc_write_align rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_align -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1
+run pmc_sq_align  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_align -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1
+run pmc_fetch_align_plain rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --strict off
+run pmc_write_align_plain rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --strict off
+run pmc_sq_align_plain  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_align_plain -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --strict off
+run pmc_fetch_train rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --mode train
+run pmc_write_train rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --mode train
+run pmc_sq_train  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq_train -- python3 $B $X --steps 2 --warmup 0 --batches 1 --depth 1 --mode train
 # keep only what is small enough to travel back: stats + counter csv files
 find $OUT -name "*.csv" -size +8M -delete
 find $OUT -name "*kernel_trace.csv" -delete
