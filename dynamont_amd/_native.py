@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "rccl_comm.cpp", "model_format.cpp",
+SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "bam_reader.cpp", "rccl_comm.cpp", "model_format.cpp",
            "nt_kernels.hip", "pool_stats.hip"]
 HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
@@ -44,6 +44,19 @@ class DynTrainOut(C.Structure):
                 ("em_offsets", c_u64_p), ("em_count", c_u64_p), ("em_code", c_i32_p), ("em_mean", c_double_p),
                 ("em_stdev", c_double_p), ("em_weight", c_double_p), ("em_sum", c_double_p),
                 ("em_sumsq", c_double_p), ("trans_counts", c_double_p), ("capacity", C.c_uint64)]
+
+
+class DynJobBatch(C.Structure):
+    """dyn_job_batch: the columns dyn_bam_next returns (owned by the reader, valid until its next call)"""
+    _fields_ = [("n", C.c_uint64),
+                ("names", C.c_void_p), ("name_off", C.POINTER(C.c_uint64)), ("names_bytes", C.c_uint64),
+                ("signal_ids", C.c_void_p), ("signal_id_off", C.POINTER(C.c_uint64)), ("signal_ids_bytes", C.c_uint64),
+                ("signal_uuid", C.c_void_p), ("signal_uuid_ok", C.c_void_p),
+                ("seqs", C.c_void_p), ("seq_off", C.POINTER(C.c_uint64)), ("seqs_bytes", C.c_uint64),
+                ("shift", C.POINTER(C.c_double)), ("scale", C.POINTER(C.c_double)),
+                ("start", C.POINTER(C.c_int64)), ("end", C.POINTER(C.c_int64)),
+                ("n_files", C.c_uint64), ("files", C.c_void_p), ("file_off", C.POINTER(C.c_uint64)), ("files_bytes", C.c_uint64),
+                ("file_id", C.POINTER(C.c_uint32)), ("bases", C.POINTER(C.c_uint32))]
 
 
 class DynTiming(C.Structure):
@@ -94,6 +107,11 @@ SIGNATURES = {
     "dyn_csv_sink_completed": (C.c_uint64, [C.c_void_p]),
     "dyn_csv_sink_failed": (C.c_int, [C.c_void_p]),
     "dyn_csv_sink_close": (C.c_int, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, C.c_char_p, C.c_uint64]),
+    "dyn_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
+    "dyn_bam_next": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(DynJobBatch),
+                               C.c_char_p, C.c_uint64]),
+    "dyn_bam_skipped": (C.c_uint64, [C.c_void_p]),
+    "dyn_bam_close": (None, [C.c_void_p]),
     "dyn_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,
                                    C.POINTER(C.c_void_p)]),
     "dyn_batch_create_raw": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, c_u64_p, c_double_p, c_double_p,
@@ -166,7 +184,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-ldl", "-o", LIB_PATH + ".tmp"]
+           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-ldl", "-lz", "-o", LIB_PATH + ".tmp"]
     cmd += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -205,3 +205,123 @@ def write_bam(path: str, records) -> None:
         for i in range(0, len(data), 0xFF00):
             w.write(_bgzf_block(data[i:i + 0xFF00]))
         w.write(_bgzf_block(b""))  # EOF marker block
+
+
+# ---------------------------------------------------------------------------------------------
+# the native reader (csrc/bam_reader.cpp): jobs in columns, a batch per call
+# ---------------------------------------------------------------------------------------------
+class JobBatch:
+    """The jobs of one batch as columns (dyn_job_batch, copied out of the reader): what generate_jobs yields read by read
+    (segment.py:189-258), for `n` reads at once. ``names`` / ``sids`` are NUL-terminated strings back to back (uint8
+    arrays) with ``*_off[i]`` = start of entry i; ``seqs`` the sequences in aligner orientation back to back (bytes) with
+    ``seq_off``; ``uuid`` the signal ids as (n, 16) uint8 with ``uuid_ok``; ``shift``, ``scale`` (sm, sd), ``start``,
+    ``end`` (sp + ts, sp + ns); ``files`` the distinct raw-file names of the batch and ``file_id`` each read's index; ``bases`` the stored
+    sequence lengths."""
+
+    __slots__ = ("n", "names", "name_off", "sids", "sid_off", "uuid", "uuid_ok", "seqs", "seq_off", "shift", "scale",
+                 "start", "end", "files", "file_id", "bases")
+
+    def name(self, i: int) -> str:
+        return self.names[int(self.name_off[i]):int(self.name_off[i + 1]) - 1].tobytes().decode()
+
+    def sid(self, i: int) -> str:
+        return self.sids[int(self.sid_off[i]):int(self.sid_off[i + 1]) - 1].tobytes().decode()
+
+    def read(self, i: int) -> str:
+        return self.seqs[int(self.seq_off[i]):int(self.seq_off[i + 1])].decode("ascii")
+
+    def take(self, keep: np.ndarray) -> "JobBatch":
+        """the sub-batch of the reads ``keep`` (ascending indices); strings are re-packed"""
+        keep = np.asarray(keep, dtype=np.int64)
+        out = JobBatch()
+        out.n = len(keep)
+
+        def repack(buf, off):
+            lens = (off[1:] - off[:-1])[keep]
+            new_off = np.zeros(len(keep) + 1, dtype=np.uint64)
+            np.cumsum(lens, out=new_off[1:])
+            total = int(new_off[-1])
+            idx = np.arange(total, dtype=np.int64) - np.repeat(new_off[:-1].astype(np.int64), lens.astype(np.int64)) \
+                + np.repeat(off[:-1][keep].astype(np.int64), lens.astype(np.int64))
+            return buf[idx], new_off
+
+        out.names, out.name_off = repack(self.names, self.name_off)
+        out.sids, out.sid_off = repack(self.sids, self.sid_off)
+        seqs, out.seq_off = repack(np.frombuffer(self.seqs, dtype=np.uint8), self.seq_off)
+        out.seqs = seqs.tobytes()
+        out.uuid, out.uuid_ok = self.uuid[keep], self.uuid_ok[keep]
+        out.shift, out.scale, out.start, out.end = self.shift[keep], self.scale[keep], self.start[keep], self.end[keep]
+        out.files, out.file_id, out.bases = self.files, self.file_id[keep], self.bases[keep]
+        return out
+
+
+class NativeBamJobs:
+    """dyn_bam_open / dyn_bam_next: the basecalls of a BAM file as JobBatch columns. ``rna``: sequences come reversed and
+    with ``pad`` in front unless they start with it (segment.py:149-153). ``min_qual``, ``rank``, ``world`` as in
+    generate_jobs / segment(): reads below the quality are skipped (``skipped``), of the others index % world == rank is
+    kept. A tag the reference reads unconditionally and that is missing raises KeyError, like pysam's get_tag."""
+
+    def __init__(self, path: str, rna: bool = False, pad: str = "", min_qual: float = 0.0, rank: int = 0, world: int = 1,
+                 threads: int = 4):
+        import ctypes as C
+        from dynamont_amd import _native as N
+        self._C, self._N, self._L = C, N, N.lib()
+        self._flags = 1 if rna else 0
+        self._q, self._rank, self._world = float(min_qual or 0.0), int(rank), int(world)
+        h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = self._L.dyn_bam_open(path.encode(), int(threads), pad.encode(), C.byref(h), err, 1024)
+        if rc != N.DYN_OK:
+            raise ValueError(err.value.decode())
+        self._h = h
+
+    @property
+    def skipped(self) -> int:
+        return int(self._L.dyn_bam_skipped(self._h)) if self._h else 0
+
+    def next(self, max_reads: int) -> JobBatch | None:
+        C, N = self._C, self._N
+        b = N.DynJobBatch()
+        err = C.create_string_buffer(1024)
+        rc = self._L.dyn_bam_next(self._h, int(max_reads), self._flags, self._q, self._rank, self._world, C.byref(b), err, 1024)
+        if rc != N.DYN_OK:
+            msg = err.value.decode()
+            if msg.startswith("tag '"):
+                raise KeyError(msg)
+            raise ValueError(msg)
+        n = int(b.n)
+        if n == 0:
+            return None
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            addr = ptr if isinstance(ptr, int) else C.addressof(ptr.contents)
+            return np.ctypeslib.as_array((C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(addr)).view(dtype).copy()
+
+        out = JobBatch()
+        out.n = n
+        out.names, out.name_off = arr(b.names, int(b.names_bytes), np.uint8), arr(b.name_off, n + 1, np.uint64)
+        out.sids, out.sid_off = arr(b.signal_ids, int(b.signal_ids_bytes), np.uint8), arr(b.signal_id_off, n + 1, np.uint64)
+        out.uuid = arr(b.signal_uuid, 16 * n, np.uint8).reshape(n, 16)
+        out.uuid_ok = arr(b.signal_uuid_ok, n, np.uint8)
+        out.seqs = C.string_at(b.seqs, int(b.seqs_bytes)) if b.seqs_bytes else b""
+        out.seq_off = arr(b.seq_off, n + 1, np.uint64)
+        out.shift, out.scale = arr(b.shift, n, np.float64), arr(b.scale, n, np.float64)
+        out.start, out.end = arr(b.start, n, np.int64), arr(b.end, n, np.int64)
+        files = C.string_at(b.files, int(b.files_bytes)) if b.files_bytes else b""
+        out.files = [f.decode() for f in files.split(b"\0")[:int(b.n_files)]]
+        out.file_id = arr(b.file_id, n, np.uint32)
+        out.bases = arr(b.bases, n, np.uint32)
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            self._L.dyn_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -213,6 +213,19 @@ def build_footer(file_identifier: str, software: str, pod5_version: str, content
 # ---------------------------------------------------------------------------------------------
 # reader
 # ---------------------------------------------------------------------------------------------
+_ARROW_NP = {"uint8": "<u1", "int8": "<i1", "uint16": "<u2", "int16": "<i2", "uint32": "<u4", "int32": "<i4", "uint64": "<u8",
+             "int64": "<i8", "float": "<f4", "double": "<f8"}
+
+
+def _primitive(arr) -> np.ndarray:
+    """A fixed-width Arrow array as a NumPy view of its data buffer. (``to_numpy(zero_copy_only=False)`` imports pandas
+    on its way -- 0.4 s of a run's start-up -- and these columns never hold nulls.)"""
+    if arr.null_count:
+        raise ValueError("POD5 column with nulls")
+    dt = np.dtype(_ARROW_NP[str(arr.type)])  # (type.to_pandas_dtype() imports pandas too)
+    return np.frombuffer(arr.buffers()[1], dtype=dt)[arr.offset:arr.offset + len(arr)]
+
+
 class Pod5File:
     """``signal(read_id, calibrated)`` / ``close()`` over one .pod5 file (same surface as the
     synthetic container reader of ``pod5_io``)."""
@@ -248,23 +261,49 @@ class Pod5File:
 
     # -- reads table -------------------------------------------------------------------------
     def _build_index(self):
+        """The reads table as arrays: ``_index`` maps the 16 id bytes to a row r; the read's signal rows are
+        ``_sig_flat[_sig_first[r] : _sig_first[r] + _sig_count[r]]``, its calibration ``_cal_offset[r]``, ``_cal_scale[r]``
+        (float32). Built once per file, without a Python object per signal row."""
         rd = self._tables[CT_READS]
         names = rd.schema.names
         if "calibration_offset" not in names or "calibration_scale" not in names:
             raise ValueError(f"{self.path}: reads table older than version 3 (no calibration_offset/scale columns)")
-        index = {}
+        keys, first, count, flat, cal_o, cal_s = [], [], [], [], [], []
+        base = 0
         for bi in range(rd.num_record_batches):
             b = rd.get_batch(bi)
             ids = b.column(names.index("read_id"))
             ids = ids.storage if hasattr(ids, "storage") else ids
-            raw = np.frombuffer(ids.buffers()[1], dtype=np.uint8)[ids.offset * 16:(ids.offset + len(ids)) * 16].reshape(-1, 16)
-            sig = b.column(names.index("signal"))
-            off = b.column(names.index("calibration_offset")).to_numpy(zero_copy_only=False)
-            sc = b.column(names.index("calibration_scale")).to_numpy(zero_copy_only=False)
-            rows = sig.to_pylist()
-            for i in range(b.num_rows):
-                index[raw[i].tobytes()] = (rows[i], float(off[i]), float(sc[i]))
-        self._index = index
+            raw = np.frombuffer(ids.buffers()[1], dtype=np.uint8)[ids.offset * 16:(ids.offset + len(ids)) * 16].tobytes()
+            keys.extend(raw[i:i + 16] for i in range(0, len(raw), 16))
+            sig = b.column(names.index("signal"))  # list<uint64>: offsets + flat values
+            offs = np.frombuffer(sig.buffers()[1], dtype=np.int64 if str(sig.type).startswith("large_list") else np.int32)
+            offs = offs[sig.offset:sig.offset + len(sig) + 1].astype(np.int64)
+            vals = _primitive(sig.values).astype(np.int64)  # .values ignores the list's own offset: index with offs
+            first.append(offs[:-1] + base)
+            count.append(np.diff(offs))
+            flat.append(vals)
+            base += len(vals)
+            cal_o.append(_primitive(b.column(names.index("calibration_offset"))).astype(np.float32))
+            cal_s.append(_primitive(b.column(names.index("calibration_scale"))).astype(np.float32))
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)  # noqa: E731
+        self._sig_first, self._sig_count, self._sig_flat = cat(first, np.int64), cat(count, np.int64), cat(flat, np.int64)
+        self._cal_offset, self._cal_scale = cat(cal_o, np.float32), cat(cal_s, np.float32)
+        self._index = dict(zip(keys, range(len(keys))))
+
+    def _lookup(self, read_id: str):
+        """(signal rows, calibration offset, calibration scale) of a read; KeyError when the file does not hold it"""
+        if self._index is None:
+            self._build_index()
+        try:
+            key = uuid.UUID(read_id).bytes
+        except ValueError:
+            raise KeyError(read_id) from None
+        r = self._index.get(key)
+        if r is None:
+            raise KeyError(read_id)
+        f = int(self._sig_first[r])
+        return self._sig_flat[f:f + int(self._sig_count[r])], float(self._cal_offset[r]), float(self._cal_scale[r])
 
     @property
     def read_ids(self) -> list[str]:
@@ -303,7 +342,7 @@ class Pod5File:
                 bufs = col.buffers()
                 dt = np.int64 if pa.types.is_large_binary(col.type) else np.int32
                 offs = np.frombuffer(bufs[1], dtype=dt)[col.offset:col.offset + len(col) + 1].astype(np.int64)
-                samples = b.column(names.index("samples")).to_numpy(zero_copy_only=False).astype(np.uint32)
+                samples = _primitive(b.column(names.index("samples"))).astype(np.uint32)
                 meta = (int(bufs[2].address), offs, samples, b)  # b keeps the buffers alive
             else:
                 meta = False
@@ -314,13 +353,7 @@ class Pod5File:
         """The read's signal still compressed: (chunk addresses uint64[c], chunk bytes uint64[c], chunk samples
         uint32[c], calibration offset, calibration scale) for dyn_batch_align_vbz_async / dyn_vbz_decode, or None when
         the file stores uncompressed samples. Nothing is decoded or copied here."""
-        if self._index is None:
-            self._build_index()
-        try:
-            key = uuid.UUID(read_id).bytes
-        except ValueError:
-            raise KeyError(read_id) from None
-        rows, offset, scale = self._index[key]
+        rows, offset, scale = self._lookup(read_id)
         ptrs = np.empty(len(rows), dtype=np.uint64)
         nbytes = np.empty(len(rows), dtype=np.uint64)
         samples = np.empty(len(rows), dtype=np.uint32)
@@ -336,15 +369,53 @@ class Pod5File:
             samples[k] = smp[i]
         return ptrs, nbytes, samples, np.float32(offset), np.float32(scale)
 
-    def signal_adc(self, read_id: str):
-        """(int16 ADC samples, calibration offset, calibration scale)"""
+    def _chunk_tables(self):
+        """(address, bytes, samples) of EVERY row of the signal table, or None when a batch stores uncompressed samples"""
+        t = getattr(self, "_chunk_tab", None)
+        if t is None:
+            ptrs, nbytes, samples = [], [], []
+            for bi in range(len(self._sig_rows) - 1):
+                meta = self._batch_chunk_meta(bi)
+                if meta is None:
+                    self._chunk_tab = t = False
+                    return None
+                base, offs, smp, _ = meta
+                ptrs.append((offs[:-1] + base).astype(np.uint64))
+                nbytes.append(np.diff(offs).astype(np.uint64))
+                samples.append(smp)
+            cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)  # noqa: E731
+            self._chunk_tab = t = (cat(ptrs, np.uint64), cat(nbytes, np.uint64), cat(samples, np.uint32))
+        return t or None
+
+    def signal_chunks_batch(self, ids16: np.ndarray):
+        """signal_chunks for a batch: ``ids16`` = (n, 16) uint8 read ids. Returns (found bool[n], ptrs uint64[c], nbytes
+        uint64[c], samples uint32[c], read_off uint64[n + 1], cal_offset float32[n], cal_scale float32[n]) -- the flattened
+        chunk tables dyn_batch_align_vbz_async takes; reads the file does not hold have ``found`` False and no chunks --
+        or None when the file stores uncompressed samples."""
         if self._index is None:
             self._build_index()
-        try:
-            key = uuid.UUID(read_id).bytes
-        except ValueError:
-            raise KeyError(read_id) from None
-        rows, offset, scale = self._index[key]  # KeyError = read missing (pod5: missing_ok=False raises too)
+        tab = self._chunk_tables()
+        if tab is None:
+            return None
+        n = len(ids16)
+        raw = np.ascontiguousarray(ids16, dtype=np.uint8).tobytes()
+        get = self._index.get
+        rows = np.fromiter((get(raw[i:i + 16], -1) for i in range(0, 16 * n, 16)), dtype=np.int64, count=n)
+        found = rows >= 0
+        r = np.where(found, rows, 0)
+        cnt = np.where(found, self._sig_count[r], 0) if len(self._sig_count) else np.zeros(n, dtype=np.int64)
+        read_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=read_off[1:])
+        total = int(read_off[-1])
+        flat = np.arange(total, dtype=np.int64) - np.repeat(read_off[:-1].astype(np.int64), cnt) + np.repeat(self._sig_first[r] if total else r, cnt)
+        srow = self._sig_flat[flat]
+        cal_o = np.where(found, self._cal_offset[r], np.float32(0)) if len(self._cal_offset) else np.zeros(n, dtype=np.float32)
+        cal_s = np.where(found, self._cal_scale[r], np.float32(0)) if len(self._cal_scale) else np.zeros(n, dtype=np.float32)
+        return found, tab[0][srow], tab[1][srow], tab[2][srow], read_off, cal_o.astype(np.float32), cal_s.astype(np.float32)
+
+    def signal_adc(self, read_id: str):
+        """(int16 ADC samples, calibration offset, calibration scale)"""
+        rows, offset, scale = self._lookup(read_id)  # KeyError = read missing (pod5: missing_ok=False raises too)
         parts = [self._signal_row(int(r)) for r in rows]
         adc = np.concatenate(parts) if len(parts) != 1 else parts[0]
         return adc, np.float32(offset), np.float32(scale)

@@ -118,15 +118,26 @@ def get_raw(path):
     return RAW_CACHE[path]
 
 
-def generate_jobs(dataPath: str, basecalls: str, minQual: float = 0):
+def generate_jobs(dataPath: str, basecalls: str, minQual: float = 0, rank: int = 0, world: int = 1):
     """(rawFile, shift, scale, start, end, sequence, readid, signalid) per basecalled read
     (segment.py:189-258): ``qs`` filter, ``pi`` parent id, ``start = sp+ts``, ``end = sp+ns``,
-    file ``fn`` or ``f5``, normalisation tags ``sm``/``sd``."""
+    file ``fn`` or ``f5``, normalisation tags ``sm``/``sd``. ``rank`` / ``world``: of the jobs that pass the filter only
+    those with index % world == rank (every rank of a multi-GPU run walks the basecalls and keeps its share)."""
     skipped = 0
+    if _native_bam(basecalls):  # the same walk in native code (csrc/bam_reader.cpp), re-yielded read by read
+        for jb in job_batches(basecalls, minQual, 4096, False, rank, world):
+            for i in range(jb.n):
+                yield (join(dataPath, jb.files[jb.file_id[i]]), float(jb.shift[i]), float(jb.scale[i]), int(jb.start[i]), int(jb.end[i]),
+                       jb.read(i), jb.name(i), jb.sid(i))
+        return
+    index = -1
     for rec in iter_basecalls(basecalls):
         qs = rec.get_tag("qs")
         if minQual and qs < minQual:
             skipped += 1
+            continue
+        index += 1
+        if index % world != rank:
             continue
         readid = rec.query_name
         signalid = rec.get_tag("pi") if rec.has_tag("pi") else readid
@@ -136,6 +147,120 @@ def generate_jobs(dataPath: str, basecalls: str, minQual: float = 0):
         raw_file = join(dataPath, rec.get_tag("fn")) if rec.has_tag("fn") else join(dataPath, rec.get_tag("f5"))
         yield (raw_file, rec.get_tag("sm"), rec.get_tag("sd"), sp + ts, sp + ns, rec.query_sequence, readid, signalid)
     print(f"Skipped reads due to low quality: {skipped}", file=sys.stderr)
+
+
+def _native_bam(basecalls: str) -> bool:
+    """BAM basecalls go through the native reader unless DYN_PY_BAM=1 asks for the Python parsers (pysam when present,
+    bam_io.iter_bam otherwise; tests compare the two)"""
+    import os
+    return basecalls.endswith(".bam") and os.environ.get("DYN_PY_BAM", "0") != "1"
+
+
+def job_batches(basecalls: str, minQual: float, batch_reads: int, is_rna: bool, rank: int = 0, world: int = 1):
+    """generate_jobs a batch at a time, as columns (bam_io.JobBatch): the quality filter, the rank's share
+    (index % world == rank) and -- ``is_rna`` -- the workers' sequence orientation (segment.py:149-153) are applied by the
+    native reader."""
+    from dynamont_amd.bam_io import NativeBamJobs
+    reader = NativeBamJobs(basecalls, rna=is_rna, pad=POLYA, min_qual=minQual or 0.0, rank=rank, world=world)
+    try:
+        while True:
+            jb = reader.next(batch_reads)
+            if jb is None:
+                break
+            yield jb
+        print(f"Skipped reads due to low quality: {reader.skipped}", file=sys.stderr)
+    finally:
+        reader.close()
+
+
+def _ragged(starts: np.ndarray, counts: np.ndarray) -> np.ndarray:
+    """[starts[0], starts[0]+1, .. starts[0]+counts[0]-1, starts[1], ..] as one int64 array"""
+    counts = counts.astype(np.int64)
+    total = int(counts.sum())
+    first = np.cumsum(counts) - counts
+    return np.arange(total, dtype=np.int64) - np.repeat(first, counts) + np.repeat(starts.astype(np.int64), counts)
+
+
+def prepare_job_columns(jb, data_path: str, put_error):
+    """prepare_job_raw for a whole JobBatch whose raw files can point at their compressed chunks
+    (pod5_native.Pod5File.signal_chunks_batch). Returns (jb, chunks, raw_off, cal, owners): ``jb`` without the reads that
+    failed (each reported through ``put_error`` with the worker's line, segment.py:178-187), ``chunks`` = (ptrs, nbytes,
+    samples, read_off, slice_start) for dyn_batch_align_vbz_async, ``raw_off`` the prefix sums of the slice lengths,
+    ``cal`` = (offset, scale, calibrated mask); or None when a reader of the batch cannot do that (the caller then takes
+    the per-read path)."""
+    import uuid as uuid_mod
+    n = jb.n
+    for i in np.flatnonzero(jb.uuid_ok == 0):  # ids the native parser did not take: uuid.UUID() accepts a few more spellings
+        try:
+            jb.uuid[i] = np.frombuffer(uuid_mod.UUID(jb.sid(i)).bytes, dtype=np.uint8)
+            jb.uuid_ok[i] = 1
+        except ValueError:
+            pass
+    found = np.zeros(n, dtype=bool)
+    cnt = np.zeros(n, dtype=np.int64)
+    cal_o = np.zeros(n, dtype=np.float32)
+    cal_s = np.zeros(n, dtype=np.float32)
+    parts, owners, failed = [], [], {}
+    for fid, fname in enumerate(jb.files):
+        sel = np.flatnonzero(jb.file_id == fid)
+        if not len(sel):
+            continue
+        try:
+            reader = get_raw(join(data_path, fname))
+            fn = getattr(reader, "signal_chunks_batch", None)
+            res = fn(jb.uuid[sel]) if fn is not None else None
+        except Exception as error:  # noqa: BLE001  the file cannot be opened or read: every read of it fails like in the worker
+            for i in sel:
+                failed[int(i)] = error
+            continue
+        if res is None:
+            return None
+        ok, ptrs, nbytes, samples, roff, co, cs = res
+        ok = ok & (jb.uuid_ok[sel] != 0)
+        if not ok.all():  # (chunks of reads that were found under a damaged id cannot exist: ok False implies no chunks, or drop them)
+            keep_chunks = np.repeat(ok, np.diff(roff.astype(np.int64)))
+            ptrs, nbytes, samples = ptrs[keep_chunks], nbytes[keep_chunks], samples[keep_chunks]
+        c = np.where(ok, np.diff(roff.astype(np.int64)), 0)
+        found[sel], cnt[sel], cal_o[sel], cal_s[sel] = ok, c, co, cs
+        parts.append((sel, c, ptrs, nbytes, samples))
+        owners.append(reader)
+    for i in np.flatnonzero(~found):
+        i = int(i)
+        error = failed.get(i, KeyError(jb.sid(i)))
+        put_error(f"error: worker, {error}\tN: {int(jb.bases[i])}\tRid: {jb.name(i)}\tSid: {jb.sid(i)}")
+    read_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(cnt, out=read_off[1:])
+    total = int(read_off[-1])
+    if len(parts) == 1 and found.all():
+        _, _, ptrs, nbytes, samples = parts[0]
+    else:  # several raw files in one batch: each file's chunks go to its reads' places
+        ptrs, nbytes, samples = np.zeros(total, dtype=np.uint64), np.zeros(total, dtype=np.uint64), np.zeros(total, dtype=np.uint32)
+        for sel, c, p_, b_, s_ in parts:
+            pos = _ragged(read_off[:-1][sel], c)
+            ptrs[pos], nbytes[pos], samples[pos] = p_, b_, s_
+    if not found.all():
+        keep = np.flatnonzero(found)
+        jb = jb.take(keep)
+        cnt, cal_o, cal_s = cnt[keep], cal_o[keep], cal_s[keep]
+        read_off = np.zeros(jb.n + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=read_off[1:])
+    # the [start:end) slice, clipped to the read like VbzSlice clips
+    csum = np.zeros(total + 1, dtype=np.int64)
+    np.cumsum(samples, out=csum[1:])
+    ro = read_off.astype(np.int64)
+    have = csum[ro[1:]] - csum[ro[:-1]]
+    s0 = np.minimum(np.maximum(jb.start, 0), have)
+    e0 = np.minimum(np.maximum(jb.end, s0), have)
+    raw_off = np.zeros(jb.n + 1, dtype=np.uint64)
+    np.cumsum(e0 - s0, out=raw_off[1:])
+    calibrated = jb.shift <= 400  # segment.py:147: the picoampere signal for these reads, the ADC counts otherwise
+    return jb, (ptrs, nbytes, samples, read_off, s0.astype(np.uint64)), raw_off, (cal_o, cal_s, calibrated), owners
+
+
+def jobs_from_columns(jb, data_path: str):
+    """the per-read job tuples of a JobBatch (sequences as the batch holds them: already oriented when it was read so)"""
+    return [(join(data_path, jb.files[jb.file_id[i]]), float(jb.shift[i]), float(jb.scale[i]), int(jb.start[i]), int(jb.end[i]),
+             jb.read(i), jb.name(i), jb.sid(i)) for i in range(jb.n)]
 
 
 def prepare_job(job, is_rna: bool):
@@ -154,7 +279,7 @@ def prepare_job(job, is_rna: bool):
     return signal, read
 
 
-def prepare_job_raw(job, is_rna: bool):
+def prepare_job_raw(job, is_rna: bool, oriented: bool = False):
     """P1 without the arithmetic: the raw [start:end) slice and the aligner-orientation read. The slice is int16 ADC
     counts; ``cal`` = (offset, scale) when the reference would take the calibrated picoampere signal (``shift <= 400``,
     segment.py:147), None when it takes the ADC counts themselves. Calibration, normalisation and the Hampel filter
@@ -170,7 +295,7 @@ def prepare_job_raw(job, is_rna: bool):
         raw = adc[start:end]
         if raw.dtype != np.int16:  # a reader that hands out something else: through the generic float64 path
             raw = raw.astype(np.float64)
-    if is_rna:
+    if is_rna and not oriented:  # (``oriented``: the job comes from a JobBatch that was read in aligner orientation)
         read = read[::-1]
         if not read.startswith(POLYA):
             read = POLYA + read
@@ -390,6 +515,50 @@ class _NativePipeline:
             self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g)  # g: the slices (and their readers) stay alive
             self.submitted += 1
 
+    def submit_columns(self, jb, chunks, raw_off, cal, owners) -> None:
+        """One batch prepared by prepare_job_columns: compressed POD5 chunks and column arrays straight into
+        dyn_batch_align_vbz_async and the sink -- no Python object per read. Reads with and without calibration
+        (segment.py:147) go up as separate submissions, like in submit()."""
+        C, N = self.C, self.N
+        cal_o, cal_s, calibrated = cal
+        if jb.n == 0:
+            return
+        if calibrated.any() and not calibrated.all():
+            ptrs, nbytes, samples, read_off, skip = chunks
+            cnt = np.diff(read_off.astype(np.int64))
+            lens = np.diff(raw_off.astype(np.int64))
+            for mask in (calibrated, ~calibrated):
+                keep = np.flatnonzero(mask)
+                pos = _ragged(read_off[:-1][keep], cnt[keep])
+                ro = np.zeros(len(keep) + 1, dtype=np.uint64)
+                np.cumsum(cnt[keep], out=ro[1:])
+                so = np.zeros(len(keep) + 1, dtype=np.uint64)
+                np.cumsum(lens[keep], out=so[1:])
+                self.submit_columns(jb.take(keep), (ptrs[pos], nbytes[pos], samples[pos], ro, skip[keep]), so,
+                                    (cal_o[keep], cal_s[keep], calibrated[keep]), owners)
+            return
+        self.check()
+        self._reap(block_until=self.depth - 1)
+        n = jb.n
+        out = self.free.pop() if self.free else None
+        t = self.aligner.align_vbz_async(chunks, raw_off, jb.shift, jb.scale, jb.seqs, jb.seq_off, window=3, n_sigmas=3.0, f32=False,
+                                         calc_probabilities=True, out=out, calibration=(cal_o, cal_s) if calibrated.all() else None)
+        res = t.result
+        rid = (jb.names.ctypes.data + jb.name_off[:-1]).astype(np.uint64)  # char* of every NUL-terminated name
+        sid = (jb.sids.ctypes.data + jb.sid_off[:-1]).astype(np.uint64)
+        starts = np.ascontiguousarray(jb.start, dtype=np.int64)
+        lengths = np.diff(raw_off).astype(np.uint64)
+        seq_off = np.ascontiguousarray(jb.seq_off, dtype=np.uint64)
+        rc = self.L.dyn_csv_sink_submit(self.h, self.aligner._h, t._h, C.byref(res._c), n, jb.seqs, seq_off.ctypes.data_as(N.c_u64_p),
+                                        C.cast(rid.ctypes.data, C.POINTER(C.c_char_p)), C.cast(sid.ctypes.data, C.POINTER(C.c_char_p)),
+                                        starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p))
+        if rc != N.DYN_OK:
+            t.close()
+            self.check()
+            raise RuntimeError("dyn_csv_sink_submit failed")
+        self.keep[self.submitted] = (t, res, jb, seq_off, rid, sid, starts, lengths, chunks, raw_off, cal, owners)
+        self.submitted += 1
+
     def check(self) -> None:
         """raise as soon as the sink has failed (a batch error, zstd, the output file) instead of parsing and aligning the
         rest of the input first; close() delivers the message"""
@@ -459,19 +628,37 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 pipe = sink = _NativePipeline(aligner, outfile, raw=not host_preprocess, depth=depth)
             else:
                 pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)
-            job_iter = enumerate(generate_jobs(data_path, basecalls, minq))
+            if native and not host_preprocess and _native_bam(basecalls):
+                # single process, BAM basecalls: the jobs arrive as columns; raw files that can point at their compressed
+                # chunks (.pod5, VBZ) are served without a Python object per read, any other reader read by read
+                for jb in job_batches(basecalls, minq, batch_reads, is_rna):
+                    prepared = prepare_job_columns(jb, data_path, sink.put)
+                    if prepared is not None:
+                        pipe.submit_columns(*prepared)
+                        continue
+                    pending = []
+                    for i, job in enumerate(jobs_from_columns(jb, data_path)):
+                        try:
+                            signal, read, cal = prepare_job_raw(job, is_rna, oriented=True)
+                        except Exception as error:  # noqa: BLE001  (segment.py:178-187)
+                            sink.put(f"error: worker, {error}\tN: {int(jb.bases[i])}\tRid: {job[6]}\tSid: {job[7]}")
+                            continue
+                        pending.append((signal, read, job, cal))
+                    pipe.submit(pending)
+                pipe.close()
+                pipe = None
+                print("Done with segmentation.", file=sys.stderr, flush=True)
+                return
+            job_iter = generate_jobs(data_path, basecalls, minq, rank, world)
             exhausted = False
             rounds = 0
             while True:
                 pending = []
                 while len(pending) < batch_reads:
-                    nxt = next(job_iter, None)
-                    if nxt is None:
+                    job = next(job_iter, None)
+                    if job is None:
                         exhausted = True
                         break
-                    idx, job = nxt
-                    if idx % world != rank:  # every rank walks the basecalls and keeps its share
-                        continue
                     try:
                         if host_preprocess:
                             signal, read = prepare_job(job, is_rna)

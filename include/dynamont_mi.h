@@ -336,6 +336,59 @@ uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s);
 int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compressed_bytes, uint64_t* error_lines, char* err,
                        uint64_t errcap);
 
+/* ---- the input half of dynamont-resquiggle: the basecalls, in batches (src/dynamont/segmentation/segment.py:189-258
+ * generate_jobs over pysam's fetch(until_eof=True); segment.py:141-158 for the RNA orientation) ----
+ *
+ * A reader walks an (unaligned) BAM file -- BGZF blocks inflated a window ahead on `threads` threads, CRC-checked --
+ * and dyn_bam_next returns COLUMNS for the next (up to) max_reads jobs, in file order:
+ *   names / signal_ids     NUL-terminated strings back to back; *_off[i] = start of entry i, *_off[n] = total bytes
+ *                          (signal id = the `pi` tag when present, else the read name)
+ *   signal_uuid[16 i ..]   the signal id as the 16 bytes of its UUID (what a POD5 reads table is keyed by),
+ *                          signal_uuid_ok[i] = 0 when the text is not 32 hex digits (hyphens ignored)
+ *   seqs / seq_off         the basecalled sequences back to back, no separators, ready for dyn_batch_align_*:
+ *                          as stored, or with DYN_JOBS_RNA reversed and with `rna_pad` in front unless the reversed read
+ *                          starts with it
+ *   shift, scale           the `sm`, `sd` tags (a BAM `f` value widened to double, as pysam hands it out)
+ *   start, end             `sp + ts`, `sp + ns` (`sp` = 0 when absent): the slice of the raw signal
+ *   file_id / files        index into the batch's distinct raw-file names (`fn`, else `f5`)
+ *   bases                  bases of the record as stored (the N of the reference's error lines)
+ * The arrays belong to the reader and stay valid until its next call. Reads with `qs` < min_qual (min_qual != 0) are
+ * counted in dyn_bam_skipped and left out; of the reads that remain, those with index % world == rank are returned
+ * (every rank of a multi-GPU run walks the file and keeps its share). n = 0: end of file. A tag generate_jobs reads
+ * without asking (qs, ns, ts, fn|f5, sm, sd) and that is absent fails the call with DYN_ERR_INVALID_ARGUMENT "tag 'xx'
+ * not present" (pysam: KeyError, same text); a damaged file with DYN_ERR_RUNTIME. */
+typedef struct dyn_bam_reader dyn_bam_reader;
+typedef struct dyn_job_batch {
+  uint64_t n;
+  const char* names;
+  const uint64_t* name_off;
+  uint64_t names_bytes;
+  const char* signal_ids;
+  const uint64_t* signal_id_off;
+  uint64_t signal_ids_bytes;
+  const uint8_t* signal_uuid;
+  const uint8_t* signal_uuid_ok;
+  const char* seqs;
+  const uint64_t* seq_off;
+  uint64_t seqs_bytes;
+  const double* shift;
+  const double* scale;
+  const int64_t* start;
+  const int64_t* end;
+  uint64_t n_files;
+  const char* files;
+  const uint64_t* file_off;
+  uint64_t files_bytes;
+  const uint32_t* file_id;
+  const uint32_t* bases;
+} dyn_job_batch;
+#define DYN_JOBS_RNA 1u
+int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_reader** out, char* err, uint64_t errcap);
+int dyn_bam_next(dyn_bam_reader* r, uint64_t max_reads, uint32_t flags, double min_qual, uint32_t rank, uint32_t world,
+                 dyn_job_batch* out, char* err, uint64_t errcap);
+uint64_t dyn_bam_skipped(const dyn_bam_reader* r);
+void dyn_bam_close(dyn_bam_reader* r);
+
 /* ---- staged form: inputs resident in HBM before the timed region (bench.py, pipelining) ---- */
 
 /* Validate (aligner.cpp:145-164), k-mer-code (aligner.cpp:166-205), and upload one batch. */

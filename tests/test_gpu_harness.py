@@ -184,3 +184,43 @@ def test_resquiggle_cli_corrupt_pod5_chunk_fails_that_read_only(models, tmp_path
     assert len(errs_bad) == 1 and errs_bad[0].startswith("error: worker, Signal could not be decoded\tN: ")
     rid = errs_bad[0].split("\tRid: ")[1].split("\t")[0]
     assert [r for r in body_ok if not r.startswith(rid + ",")] == body_bad and len(body_bad) < len(body_ok)
+
+
+def test_resquiggle_cli_column_front_end_equals_the_read_by_read_one(models, tmp_path, monkeypatch):
+    """BAM basecalls + .pod5 files take the native job reader and prepare_job_columns (no Python object per read);
+    DYN_PY_BAM=1 takes the Python BAM parser and prepare_job_raw read by read. Same out.csv.zst rows and the same .errors
+    lines -- over two raw files whose reads interleave, a read no file holds, a read whose id is no UUID, a read normalised
+    with shift > 400 (ADC counts, no calibration: a second submission of the batch) and a slice cut too short."""
+    import uuid
+    from dynamont_amd import bam_io
+    from dynamont_amd.pod5_io import iter_basecalls
+    pore = "rna004"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    d = tmp_path / "in"
+    _, bam_a, _ = synth.write_dataset(str(d), "a", synth.make_reads(81, 14, pore, mean, sd, (60, 500)), pore, seed=3, container="pod5",
+                                      basecalls="bam", pod5_chunk_samples=800)
+    _, bam_b, _ = synth.write_dataset(str(d), "b", synth.make_reads(82, 13, pore, mean, sd, (60, 500)), pore, seed=4, container="pod5",
+                                      basecalls="bam", pod5_chunk_samples=600)
+    monkeypatch.setenv("DYN_PY_BAM", "1")
+    ra, rb = list(iter_basecalls(bam_a)), list(iter_basecalls(bam_b))
+    monkeypatch.delenv("DYN_PY_BAM")
+    tup = lambda r, **kw: (kw.get("name", r.query_name), r.query_sequence, {**r._tags, **kw.get("tags", {})})  # noqa: E731
+    recs = [tup(r) for pair in zip(ra, rb + [ra[0]]) for r in pair][:-1]
+    recs.insert(4, tup(ra[0], name=str(uuid.uuid4())))
+    recs.insert(11, tup(rb[1], name="not-a-uuid"))
+    recs.insert(17, tup(ra[2], tags={"sm": 500.0, "sd": 90.0}))
+    recs.insert(20, tup(rb[3], tags={"ns": rb[3].get_tag("ts") + 30}))
+    bam = str(tmp_path / "mixed.bam")
+    bam_io.write_bam(bam, recs)
+    got = {}
+    for name in ("columns", "per_read"):
+        if name == "per_read":
+            monkeypatch.setenv("DYN_PY_BAM", "1")
+        out = tmp_path / name / "res.csv"
+        seg.main(["-r", str(d), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore, "--model_path", model, "--batch-reads", "8"])
+        got[name] = (zstd_io.decompress(open(str(out) + ".zst", "rb").read()), sorted(open(str(tmp_path / name / "res.errors")).read().splitlines()))
+        seg.close_raw_cache()
+    assert got["columns"][0] == got["per_read"][0] and len(got["columns"][0].splitlines()) > 2000
+    assert got["columns"][1] == got["per_read"][1] and len(got["columns"][1]) == 3
+    assert sum("error: worker" in l for l in got["columns"][1]) == 2 and sum("Signal too short" in l for l in got["columns"][1]) == 1
