@@ -105,6 +105,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_u64_p]),
     "dyn_csv_sink_error_line": (C.c_int, [C.c_void_p, C.c_char_p]),
     "dyn_csv_sink_completed": (C.c_uint64, [C.c_void_p]),
+    "dyn_csv_sink_wait": (C.c_uint64, [C.c_void_p, C.c_uint64, C.c_int]),
     "dyn_csv_sink_failed": (C.c_int, [C.c_void_p]),
     "dyn_csv_sink_close": (C.c_int, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, C.c_char_p, C.c_uint64]),
     "dyn_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),

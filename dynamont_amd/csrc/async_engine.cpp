@@ -311,8 +311,10 @@ int Pipeline::front_stage(dyn_batch* b) {
     return rc;
   }
   const double t3 = now_ms();
-  for (hipEvent_t* e : {&b->ev_in, &b->ev_out})
-    if (!*e) P_TRY(b, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  // ev_out is the one event a host thread waits on (the back thread, for the length of a launch): a blocking wait
+  // leaves its core to the threads that decode, format and compress instead of spinning on it
+  if (!b->ev_in) P_TRY(b, hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+  if (!b->ev_out) P_TRY(b, hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming | hipEventBlockingSync));
   // H2D on the copy-in stream. Pinned caller memory (dyn_host_alloc) is a true asynchronous DMA;
   // for pageable memory the runtime stages the copy and this thread blocks for its duration, which
   // is what the thread is for -- the compute stream keeps running the previous batch meanwhile.

@@ -21,7 +21,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <ctime>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -79,6 +82,7 @@ struct dyn_csv_sink {
   std::map<uint64_t, std::shared_ptr<Job>> inflight;  // by index, until written
   uint64_t next_job = 0, next_write = 0;
   std::atomic<uint64_t> completed{0};
+  std::condition_variable cv_done;  // completed has advanced, or the sink has failed
   uint64_t csv_bytes = 0, zst_bytes = 0;
   std::atomic<uint64_t> error_lines{0};
   bool closing = false, items_done = false, jobs_closed = false, failed = false;
@@ -91,6 +95,7 @@ struct dyn_csv_sink {
   void fail(const std::string& msg) {  // m held or single-threaded context
     if (!failed) error = msg;
     failed = true;
+    cv_done.notify_all();
   }
 
   void add_job(std::shared_ptr<Blob> blob, const char* src, size_t len, bool last) {
@@ -114,6 +119,9 @@ struct dyn_csv_sink {
 
   void compress_loop() {
     void* ctx = z.createCCtx();
+    const char* pe = std::getenv("DYN_SINK_PROBE");
+    const bool probe = pe && *pe == '1';
+    std::vector<char> local;
     for (;;) {
       std::shared_ptr<Job> j;
       {
@@ -123,17 +131,31 @@ struct dyn_csv_sink {
         j = todo.front();
         todo.pop_front();
       }
+      const double k0 = now_ms(), kc0 = thread_cpu_ms();
       const size_t cap = z.compressBound(j->len) + 64;
       j->out.resize(cap);
+      us_resize.fetch_add((uint64_t)((now_ms() - k0) * 1e3));
       size_t rc = z.compressBegin(ctx, level);
       size_t pos = 0;
       if (!z.isError(rc) && j->index != 0) {
         rc = z.compressContinue(ctx, j->out.data(), cap, nullptr, 0);  // this context's frame header: dropped
         if (!z.isError(rc)) z.invalidateRepCodes(ctx);
       }
+      const char* src = j->src;
+      if (probe && j->len) {  // DYN_SINK_PROBE=1: is it reading the rows that is slow, or compressing them?
+        const double p0 = now_ms();
+        local.assign(j->src, j->src + j->len);
+        us_probe.fetch_add((uint64_t)((now_ms() - p0) * 1e3));
+        src = local.data();
+      }
       if (!z.isError(rc))
-        rc = j->last ? z.compressEnd(ctx, j->out.data(), cap, nullptr, 0) : z.compressContinue(ctx, j->out.data(), cap, j->src, j->len);
+        rc = j->last ? z.compressEnd(ctx, j->out.data(), cap, nullptr, 0) : z.compressContinue(ctx, j->out.data(), cap, src, j->len);
       if (!z.isError(rc)) pos = rc;
+      us_compress.fetch_add((uint64_t)((now_ms() - k0) * 1e3));
+      us_compress_cpu.fetch_add((uint64_t)((thread_cpu_ms() - kc0) * 1e3));
+      if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1' && (j->index < 20 || j->index % 40 == 0))
+        std::fprintf(stderr, "[csv sink] job %llu: %zu bytes -> %zu in %.2f ms (cpu %.2f) at %.1f\n", (unsigned long long)j->index, j->len, pos, now_ms() - k0,
+                     thread_cpu_ms() - kc0, now_ms());
       {
         std::lock_guard<std::mutex> lk(m);
         if (z.isError(rc)) fail(std::string("zstd: ") + z.getErrorName(rc));
@@ -159,7 +181,10 @@ struct dyn_csv_sink {
         if (it == inflight.end()) break;
         j = it->second;
       }
-      if (!j->out.empty() && std::fwrite(j->out.data(), 1, j->out.size(), out) != j->out.size()) {
+      const double w0 = now_ms();
+      const bool wrote = j->out.empty() || std::fwrite(j->out.data(), 1, j->out.size(), out) == j->out.size();
+      us_write.fetch_add((uint64_t)((now_ms() - w0) * 1e3));
+      if (!wrote) {
         std::lock_guard<std::mutex> lk(m);
         fail("write to the output file failed");
       }
@@ -187,8 +212,21 @@ struct dyn_csv_sink {
     ++error_lines;
   }
 
+  // DYN_SINK_TRACE=1: where the sink thread's time goes (ms summed over the batches), printed at close
+  double t_wait = 0, t_format = 0, t_compact = 0, t_append = 0, t_errors = 0;
+  std::atomic<uint64_t> us_compress{0}, us_write{0}, us_resize{0}, us_probe{0}, us_compress_cpu{0};
+  static double thread_cpu_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+  }
+  static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
   void consume(const Item& it) {
+    const double c0 = now_ms();
     const int rc = dyn_batch_wait(it.ticket);
+    const double c1 = now_ms();
+    t_wait += c1 - c0;
     if (rc != DYN_OK) {
       std::lock_guard<std::mutex> lk(m);
       fail(std::string("batch failed: ") + dyn_aligner_last_error(it.a));
@@ -216,15 +254,23 @@ struct dyn_csv_sink {
       std::lock_guard<std::mutex> lk(m);
       if (spare.size() < 4) spare.push_back(blob);
     }
+    const double c2 = now_ms();
     const int frc = dyn_format_csv(it.a, it.n, it.res, it.seqs, it.seq_offsets, it.readids, it.signalids, it.sig_offsets,
-                                   last_index.data(), threads, blob->data.get(), blob->cap, begin.data(), end.data());
+                                   last_index.data(), std::min(threads, 8), blob->data.get(), blob->cap, begin.data(), end.data());
     if (frc != DYN_OK) {
       std::lock_guard<std::mutex> lk(m);
       fail("dyn_format_csv failed");
       return;
     }
+    const double c3 = now_ms();
     const uint64_t total = dyn_csv_compact(blob->data.get(), it.n, begin.data(), end.data());
+    const double c4 = now_ms();
     if (total) append(blob, total);
+    const double c5 = now_ms();
+    t_format += c3 - c2;
+    t_compact += c4 - c3;
+    t_append += c5 - c4;
+    t_errors += c2 - c1;
     for (uint64_t i = 0; i < it.n; ++i) {  // segment.py:172-176
       if (it.res->status[i] == DYN_READ_OK) continue;
       char msg[128];
@@ -256,8 +302,15 @@ struct dyn_csv_sink {
         items.pop_front();
       }
       consume(it);
-      completed.fetch_add(1);
+      {
+        std::lock_guard<std::mutex> lk(m);  // (under the lock: dyn_csv_sink_wait must not miss the change between its test and its wait)
+        completed.fetch_add(1);
+      }
+      cv_done.notify_all();
     }
+    if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1')
+      std::fprintf(stderr, "[csv sink] batches %llu: waiting for the GPU %.1f ms, bound + buffer %.1f, format %.1f, compact %.1f, handing jobs to the compressors %.1f; compress threads busy %.1f ms in sum, %.1f ms of CPU time (%d threads; of which sizing the output buffer %.1f, probe copy %.1f), writer in fwrite %.1f ms\n",
+                   (unsigned long long)completed.load(), t_wait, t_errors, t_format, t_compact, t_append, us_compress.load() / 1e3, us_compress_cpu.load() / 1e3, threads, us_resize.load() / 1e3, us_probe.load() / 1e3, us_write.load() / 1e3);
     add_job(nullptr, nullptr, 0, true);  // the empty last block that closes the frame
     {
       std::lock_guard<std::mutex> lk(m);
@@ -330,6 +383,17 @@ int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line) {
 }
 
 uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s) { return s ? s->completed.load() : 0; }
+
+uint64_t dyn_csv_sink_wait(dyn_csv_sink* s, uint64_t count, int timeout_ms) {
+  if (!s) return 0;
+  std::unique_lock<std::mutex> lk(s->m);
+  auto ready = [&] { return s->completed.load() >= count || s->failed; };
+  if (timeout_ms < 0)
+    s->cv_done.wait(lk, ready);
+  else
+    s->cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready);
+  return s->completed.load();
+}
 
 int dyn_csv_sink_failed(dyn_csv_sink* s) {
   if (!s) return 1;

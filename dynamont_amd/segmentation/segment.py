@@ -51,9 +51,11 @@ def parse(argv=None) -> Namespace:
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     p.add_argument("--batch-reads", type=int, default=1024, help="Reads per GPU batch")
     p.add_argument("--mem-budget", type=float, default=0.0, help="HBM budget for lattice workspaces in GiB (0 = 90%% of free)")
-    p.add_argument("--depth", type=int, default=6, help="batches inside the asynchronous engine at once (batches that wait "
-                   "while the GPU is busy are merged into one launch: a few more than the 2 that overlap copies with kernels "
-                   "let the launches balance)")
+    p.add_argument("--depth", type=int, default=12, help="batches in flight at once, from submission to the written rows "
+                   "(batches that wait while the GPU is busy are merged into one launch, whose queue balances reads of unequal "
+                   "length: with 12 in flight launches of 3 batches follow each other)")
+    p.add_argument("--host-threads", type=int, default=0, help="threads that compress the output (0: the CPUs this process "
+                   "may use minus 4, at most 16 -- zstd level 3 of 230 MB of rows per 1 024-read batch is the largest host cost)")
     p.add_argument("--strict-ties", type=str, default="ties", choices=["off", "ties", "start", "all"],
                    help="reproduce the reference's sums bit for bit (dyn_aligner_set_strict): 'ties' (default; 'start' is its "
                         "old name) for reads with a structural tie -- two neighbouring columns with the same emission "
@@ -147,6 +149,19 @@ def generate_jobs(dataPath: str, basecalls: str, minQual: float = 0, rank: int =
         raw_file = join(dataPath, rec.get_tag("fn")) if rec.has_tag("fn") else join(dataPath, rec.get_tag("f5"))
         yield (raw_file, rec.get_tag("sm"), rec.get_tag("sd"), sp + ts, sp + ns, rec.query_sequence, readid, signalid)
     print(f"Skipped reads due to low quality: {skipped}", file=sys.stderr)
+
+
+def available_cpus() -> int:
+    """CPUs this process may use: the affinity mask, cut down to the cgroup's CPU quota when there is one"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _native_bam(basecalls: str) -> bool:
@@ -451,7 +466,9 @@ class _NativePipeline:
         errfile = splitext(splitext(outfile)[0])[0] + ".errors"
         h = C.c_void_p()
         err = C.create_string_buffer(1024)
-        rc = self.L.dyn_csv_sink_open(outfile.encode(), errfile.encode(), 3, int(threads), C.byref(h), err, 1024)
+        import os
+        threads = int(os.environ.get("DYN_SINK_THREADS", threads))
+        rc = self.L.dyn_csv_sink_open(outfile.encode(), errfile.encode(), int(os.environ.get("DYN_SINK_LEVEL", 3)), int(threads), C.byref(h), err, 1024)
         if rc != N.DYN_OK:
             raise OSError(err.value.decode())
         self.h = h
@@ -465,7 +482,8 @@ class _NativePipeline:
             raise OSError("cannot append to the .errors file")
 
     def _reap(self, block_until: int | None = None) -> None:
-        import time
+        """release what the sink has consumed; ``block_until``: wait (in the library, not polling) until at most that many
+        batches are in flight"""
         while True:
             done = int(self.L.dyn_csv_sink_completed(self.h))
             for k in [k for k in self.keep if k < done]:
@@ -475,7 +493,7 @@ class _NativePipeline:
             if block_until is None or self.submitted - done <= block_until:
                 return
             self.check()
-            time.sleep(0.0005)
+            self.L.dyn_csv_sink_wait(self.h, self.submitted - block_until, 200)
 
     def submit(self, pending, end_of_round: bool = False) -> None:
         C, N = self.C, self.N
@@ -527,7 +545,7 @@ class _NativePipeline:
             ptrs, nbytes, samples, read_off, skip = chunks
             cnt = np.diff(read_off.astype(np.int64))
             lens = np.diff(raw_off.astype(np.int64))
-            for mask in (calibrated, ~calibrated):
+            for mask in (~calibrated, calibrated):  # (the order submit() sends its groups in)
                 keep = np.flatnonzero(mask)
                 pos = _ragged(read_off[:-1][keep], cnt[keep])
                 ro = np.zeros(len(keep) + 1, dtype=np.uint64)
@@ -583,7 +601,7 @@ class _NativePipeline:
 
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
-            host_preprocess: bool = False, depth: int = 6, strict_ties: str = "ties") -> None:
+            host_preprocess: bool = False, depth: int = 12, strict_ties: str = "ties", host_threads: int = 0) -> None:
     """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
     on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
     the writer (reads are independent; the gather is the only exchange)."""
@@ -625,7 +643,8 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
             aligner.set_strict(strict_ties)
             if native:
-                pipe = sink = _NativePipeline(aligner, outfile, raw=not host_preprocess, depth=depth)
+                pipe = sink = _NativePipeline(aligner, outfile, raw=not host_preprocess, depth=depth,
+                                              threads=host_threads or max(4, min(16, available_cpus() - 4)))
             else:
                 pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)
             if native and not host_preprocess and _native_bam(basecalls):
@@ -723,7 +742,7 @@ def main(argv=None) -> None:
     ZSTD_PARALLEL_FRAMES = bool(args.parallel_zstd_frames)
     segment(args.raw, args.basecalls, args.processes, outfile, model_path, args.pore, args.mode, args.qscore,
             device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget,
-            host_preprocess=args.host_preprocess, depth=args.depth, strict_ties=args.strict_ties)
+            host_preprocess=args.host_preprocess, depth=args.depth, strict_ties=args.strict_ties, host_threads=args.host_threads)
 
 
 if __name__ == "__main__":

@@ -331,6 +331,9 @@ int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line);
 int dyn_csv_sink_failed(dyn_csv_sink* s);
 /* batches fully consumed so far */
 uint64_t dyn_csv_sink_completed(const dyn_csv_sink* s);
+/* blocks until `count` batches have been consumed, the sink has failed, or timeout_ms have passed (< 0: no timeout);
+ * returns the batches consumed so far. What a producer that keeps a bounded number of batches in flight waits on. */
+uint64_t dyn_csv_sink_wait(dyn_csv_sink* s, uint64_t count, int timeout_ms);
 /* drains, closes the frame and the file, frees the sink; DYN_ERR_RUNTIME + message if any batch, compression or write
  * failed */
 int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compressed_bytes, uint64_t* error_lines, char* err,
