@@ -121,8 +121,8 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -
     A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
     dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
     Timed: model load, BAM parse, pod5 open + VBZ decode, pA calibration + normalisation + Hampel on the device, the
-    DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool is the
-    one the bench's own handle has just parked (a fresh process allocates it: ~1 s on clean VRAM)."""
+    DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool and the
+    batch buffers are the ones the bench's own handle has just parked (a fresh process allocates them: ~1 s on clean VRAM)."""
     from dynamont_amd import synth
     from dynamont_amd.segmentation import segment as seg
     d = os.path.join(workdir, "e2e")
@@ -147,11 +147,13 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -
            "reads_per_s": round(distinct * rep / dt, 1), "samples": samples,
            "input": f"{os.path.basename(raw)} ({os.path.getsize(raw) / 1e6:.0f} MB, VBZ) + {os.path.basename(bam)} ({os.path.getsize(bam) / 1e6:.1f} MB); "
                     f"{distinct} distinct synthetic rna004 reads x {rep}, written by synth.write_dataset in {t_gen:.1f} s (not timed)",
-           "output": f"out.csv.zst, {os.path.getsize(out + '.zst') / 1e6:.1f} MB" if os.path.exists(out + ".zst") else None,
+           "output": (f"out.csv.zst, {os.path.getsize(out + '.zst') / 1e6:.1f} MB (one zstd frame, level 3) holding "
+                      f"{seg.LAST_RUN.get('csv_bytes', 0) / 1e6:.0f} MB of CSV rows") if os.path.exists(out + ".zst") else None,
+           "batches_in_flight": seg.LAST_RUN.get("depth"), "compress_threads": seg.LAST_RUN.get("compress_threads"),
            "error_lines": sum(1 for _ in open(err)) if err else 0, "strict_mode": strict,
            "batch_reads": batch_reads or "CLI default",
            "timed": "segment.main: model load, BAM parse, pod5 VBZ decode, device preprocessing, DP, CSV format, zstd, write",
-           "not_timed": "interpreter start-up, lattice pool allocation (the bench handle's parked pool is taken over)"}
+           "not_timed": "interpreter start-up; allocation of the lattice pool and of the batch buffers (those the bench's own handle has just parked are taken over)"}
     return rec
 
 

@@ -43,13 +43,16 @@ const char kHeader[] = "readid,signalid,start,end,basepos,base,motif,state,poste
 struct Blob {  // the formatted rows of one batch; freed when its last job has been compressed
   std::unique_ptr<char[]> data;
   size_t cap = 0;
+  // Every read is formatted into its own worst-case slot [begin, end) of `data` (dyn_format_csv); the rows as the file
+  // holds them are those slots back to back, prefix[i] = bytes in front of read i. The jobs are cut in THAT coordinate
+  // and each compress thread gathers its 4 MB out of the slots -- no serial compaction pass on the sink thread.
+  std::vector<uint64_t> begin, end, prefix;
 };
 
 struct Job {
   uint64_t index = 0;
   std::shared_ptr<Blob> blob;  // keeps the source alive
-  const char* src = nullptr;
-  size_t len = 0;
+  size_t off = 0, len = 0;  // [off, off + len) of the blob's rows, in the compacted coordinate
   bool last = false;  // the terminating job: no data, closes the frame
   std::vector<char> out;
   bool done = false;
@@ -98,13 +101,13 @@ struct dyn_csv_sink {
     cv_done.notify_all();
   }
 
-  void add_job(std::shared_ptr<Blob> blob, const char* src, size_t len, bool last) {
+  void add_job(std::shared_ptr<Blob> blob, size_t off, size_t len, bool last) {
     std::unique_lock<std::mutex> lk(m);
     cv_space.wait(lk, [&] { return inflight.size() < (size_t)(4 * threads) || failed; });
     auto j = std::make_shared<Job>();
     j->index = next_job++;
     j->blob = std::move(blob);
-    j->src = src;
+    j->off = off;
     j->len = len;
     j->last = last;
     inflight[j->index] = j;
@@ -114,13 +117,11 @@ struct dyn_csv_sink {
 
   void append(std::shared_ptr<Blob> blob, size_t total) {
     csv_bytes += total;
-    for (size_t off = 0; off < total; off += kJobBytes) add_job(blob, blob->data.get() + off, std::min(kJobBytes, total - off), false);
+    for (size_t off = 0; off < total; off += kJobBytes) add_job(blob, off, std::min(kJobBytes, total - off), false);
   }
 
   void compress_loop() {
     void* ctx = z.createCCtx();
-    const char* pe = std::getenv("DYN_SINK_PROBE");
-    const bool probe = pe && *pe == '1';
     std::vector<char> local;
     for (;;) {
       std::shared_ptr<Job> j;
@@ -141,10 +142,21 @@ struct dyn_csv_sink {
         rc = z.compressContinue(ctx, j->out.data(), cap, nullptr, 0);  // this context's frame header: dropped
         if (!z.isError(rc)) z.invalidateRepCodes(ctx);
       }
-      const char* src = j->src;
-      if (probe && j->len) {  // DYN_SINK_PROBE=1: is it reading the rows that is slow, or compressing them?
+      const char* src = nullptr;
+      if (j->len) {  // the job's rows, gathered out of the reads' slots
         const double p0 = now_ms();
-        local.assign(j->src, j->src + j->len);
+        const Blob& b = *j->blob;
+        local.resize(j->len);
+        size_t r = (size_t)(std::upper_bound(b.prefix.begin(), b.prefix.end(), (uint64_t)j->off) - b.prefix.begin()) - 1;
+        size_t at = j->off, filled = 0;
+        while (filled < j->len) {
+          const size_t in_read = at - b.prefix[r];
+          const size_t take = std::min<size_t>(j->len - filled, (size_t)(b.end[r] - b.begin[r]) - in_read);
+          std::memcpy(local.data() + filled, b.data.get() + b.begin[r] + in_read, take);
+          filled += take;
+          at += take;
+          ++r;
+        }
         us_probe.fetch_add((uint64_t)((now_ms() - p0) * 1e3));
         src = local.data();
       }
@@ -263,7 +275,15 @@ struct dyn_csv_sink {
       return;
     }
     const double c3 = now_ms();
-    const uint64_t total = dyn_csv_compact(blob->data.get(), it.n, begin.data(), end.data());
+    blob->begin.assign(begin.begin(), begin.begin() + it.n);
+    blob->end.assign(end.begin(), end.begin() + it.n);
+    blob->prefix.resize(it.n + 1);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < it.n; ++i) {
+      blob->prefix[i] = total;
+      total += end[i] - begin[i];
+    }
+    blob->prefix[it.n] = total;
     const double c4 = now_ms();
     if (total) append(blob, total);
     const double c5 = now_ms();
@@ -290,6 +310,9 @@ struct dyn_csv_sink {
       hdr->cap = sizeof kHeader;
       hdr->data.reset(new char[hdr->cap]);
       std::memcpy(hdr->data.get(), kHeader, sizeof kHeader - 1);
+      hdr->begin = {0};
+      hdr->end = {sizeof kHeader - 1};
+      hdr->prefix = {0, sizeof kHeader - 1};
       append(hdr, sizeof kHeader - 1);
     }
     for (;;) {
@@ -309,9 +332,9 @@ struct dyn_csv_sink {
       cv_done.notify_all();
     }
     if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1')
-      std::fprintf(stderr, "[csv sink] batches %llu: waiting for the GPU %.1f ms, bound + buffer %.1f, format %.1f, compact %.1f, handing jobs to the compressors %.1f; compress threads busy %.1f ms in sum, %.1f ms of CPU time (%d threads; of which sizing the output buffer %.1f, probe copy %.1f), writer in fwrite %.1f ms\n",
+      std::fprintf(stderr, "[csv sink] batches %llu: waiting for the GPU %.1f ms, bound + buffer %.1f, format %.1f, prefix sums %.1f, handing jobs to the compressors %.1f; compress threads busy %.1f ms in sum, %.1f ms of CPU time (%d threads; of which sizing the output buffer %.1f, gathering the rows %.1f), writer in fwrite %.1f ms\n",
                    (unsigned long long)completed.load(), t_wait, t_errors, t_format, t_compact, t_append, us_compress.load() / 1e3, us_compress_cpu.load() / 1e3, threads, us_resize.load() / 1e3, us_probe.load() / 1e3, us_write.load() / 1e3);
-    add_job(nullptr, nullptr, 0, true);  // the empty last block that closes the frame
+    add_job(nullptr, 0, 0, true);  // the empty last block that closes the frame
     {
       std::lock_guard<std::mutex> lk(m);
       jobs_closed = true;

@@ -41,6 +41,15 @@ size_t BufCache::round_up(size_t want) {
   return (want + g - 1) / g * g;
 }
 
+namespace {
+// buffers parked by destroyed handles, per device (BufCache::park); g_bufpark_m guards them
+constexpr int BUFPARK_DEVICES = 32;
+constexpr size_t BUFPARK_MAX_BYTES = (size_t)16 << 30;  // per device and kind
+std::mutex g_bufpark_m;
+std::multimap<size_t, void*> g_bufpark[BUFPARK_DEVICES][2];  // [device][pinned]
+size_t g_bufpark_bytes[BUFPARK_DEVICES][2];
+}  // namespace
+
 hipError_t BufCache::take(bool pinned, size_t want, void** p, size_t* got) {
   {
     std::lock_guard<std::mutex> lk(m);
@@ -49,6 +58,18 @@ hipError_t BufCache::take(bool pinned, size_t want, void** p, size_t* got) {
     if (it != mp.end() && it->first <= 2 * want + ((size_t)1 << 20)) {
       *p = it->second;
       *got = it->first;
+      mp.erase(it);
+      return hipSuccess;
+    }
+  }
+  if (device >= 0 && device < BUFPARK_DEVICES) {
+    std::lock_guard<std::mutex> lk(g_bufpark_m);
+    auto& mp = g_bufpark[device][pinned ? 1 : 0];
+    auto it = mp.lower_bound(want);
+    if (it != mp.end() && it->first <= 2 * want + ((size_t)1 << 20)) {
+      *p = it->second;
+      *got = it->first;
+      g_bufpark_bytes[device][pinned ? 1 : 0] -= it->first;
       mp.erase(it);
       return hipSuccess;
     }
@@ -76,6 +97,41 @@ void BufCache::purge() {
   for (auto& kv : pin) (void)hipHostFree(kv.second);
   dev.clear();
   pin.clear();
+}
+
+void BufCache::park(int dev_id) {
+  if (dev_id < 0 || dev_id >= BUFPARK_DEVICES || std::getenv("DYN_NO_POOL_CACHE") != nullptr) {
+    purge();
+    return;
+  }
+  std::lock_guard<std::mutex> lk(m);
+  std::lock_guard<std::mutex> lk2(g_bufpark_m);
+  for (int k = 0; k < 2; ++k) {
+    auto& from = k ? pin : dev;
+    for (auto& kv : from) {
+      if (g_bufpark_bytes[dev_id][k] + kv.first <= BUFPARK_MAX_BYTES) {
+        g_bufpark[dev_id][k].emplace(kv.first, kv.second);
+        g_bufpark_bytes[dev_id][k] += kv.first;
+      } else if (k) {
+        (void)hipHostFree(kv.second);
+      } else {
+        (void)hipFree(kv.second);
+      }
+    }
+    from.clear();
+  }
+}
+
+static void release_parked_buffers() {
+  std::lock_guard<std::mutex> lk(g_bufpark_m);
+  for (int d = 0; d < BUFPARK_DEVICES; ++d)
+    for (int k = 0; k < 2; ++k) {
+      if (g_bufpark[d][k].empty()) continue;
+      (void)hipSetDevice(d);
+      for (auto& kv : g_bufpark[d][k]) (void)(k ? hipHostFree(kv.second) : hipFree(kv.second));
+      g_bufpark[d][k].clear();
+      g_bufpark_bytes[d][k] = 0;
+    }
 }
 
 // ---- parked lattice pools ---------------------------------------------------------------------------------
@@ -156,6 +212,7 @@ extern "C" void dyn_release_cached_memory(void) {
   std::lock_guard<std::mutex> lk(g_park_m);
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  dyneng::release_parked_buffers();
   for (int d = 0; d < PARK_DEVICES; ++d)
     for (int k = 0; k < PARK_KINDS; ++k)
       if (g_park[d][k].p) {
@@ -471,6 +528,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     if (e != hipSuccess) return fail(e, "hipGetDevice");
   }
   a->device = device;
+  a->cache.device = device;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
   if ((e = hipDeviceGetAttribute(&a->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail(e, "hipDeviceGetAttribute");
   if (const char* f = std::getenv("DYN_QUEUE_CUS")) a->n_cus = std::max(1, std::atoi(f));  // experiments: fewer persistent workgroups
@@ -509,7 +567,7 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->free_list.release();
     a->ctl.release();
     a->h_rows.release();
-    a->cache.purge();
+    a->cache.park(a->device);
     for (hipStream_t s : {a->stream, a->s_in, a->s_out})
       if (s) (void)hipStreamDestroy(s);
   }

@@ -40,7 +40,12 @@ struct BufCache {
   static size_t round_up(size_t want);
   hipError_t take(bool pinned, size_t want, void** p, size_t* got);
   void give(bool pinned, void* p, size_t bytes);
-  void purge();  // frees everything (handle destruction; device idle)
+  void purge();  // frees everything (device idle)
+  // Handle destruction: what the cache holds is PARKED for the next handle on that device instead of freed (hipFree /
+  // hipHostFree of a dozen batches' buffers: 0.2 s at the end of a run; allocating them again: as much at the start of the
+  // next). Bounded; dyn_release_cached_memory() frees what is parked, DYN_NO_POOL_CACHE=1 switches parking off.
+  void park(int device);
+  int device = -1;  // set by the handle: take() looks at the device's parked buffers before it allocates
 };
 
 struct DevBuf {

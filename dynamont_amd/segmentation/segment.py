@@ -29,6 +29,7 @@ from dynamont_amd.zstd_io import open_writer
 CSV_HEADER = b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
 POLYA = "AAAAAAAAA"
 
+LAST_RUN: dict = {}  # what the native sink of the last single-process run reported at close (bench.py's e2e_cli record)
 RAW_CACHE: OrderedDict | None = None
 RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
 ZSTD_WORKERS = 0    # compression threads of the writer (0: up to 8 host cores; level 3 as the reference)
@@ -468,6 +469,7 @@ class _NativePipeline:
         err = C.create_string_buffer(1024)
         import os
         threads = int(os.environ.get("DYN_SINK_THREADS", threads))
+        self.threads = threads
         rc = self.L.dyn_csv_sink_open(outfile.encode(), errfile.encode(), int(os.environ.get("DYN_SINK_LEVEL", 3)), int(threads), C.byref(h), err, 1024)
         if rc != N.DYN_OK:
             raise OSError(err.value.decode())
@@ -591,6 +593,8 @@ class _NativePipeline:
         err = C.create_string_buffer(1024)
         rc = self.L.dyn_csv_sink_close(self.h, C.byref(csv), C.byref(zst), C.byref(nerr), err, 1024)
         self.h = None
+        LAST_RUN.update(csv_bytes=int(csv.value), compressed_bytes=int(zst.value), error_lines=int(nerr.value), batches=self.submitted,
+                        depth=self.depth, compress_threads=self.threads)
         for t, *_ in self.keep.values():
             t.close()
         self.keep = {}
