@@ -430,7 +430,7 @@ int Pipeline::front_stage(dyn_batch* b) {
     P_TRY(b, hipGetLastError());
   }
   if (b->total_cols) {
-    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
+    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, (uint32_t)a->model.num_kmers, a->stream);
     P_TRY(b, hipGetLastError());
   }
   rc = enqueue_job(b, b->job);  // records ev_done behind the batch's last kernel

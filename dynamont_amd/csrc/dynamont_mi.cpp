@@ -423,6 +423,9 @@ int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, cons
       HostRead& r = b->reads[i];
       if (r.status != DYN_READ_OK) continue;
       r.status = m.encode(seqs + seq_offsets[i], r.L, km + r.flat_off, &r.bad);
+      // an invalid nucleotide ends the encoding half-way: the rest of the read's columns would keep whatever the
+      // (recycled) buffer held, and k_prep_params turns every column of the batch into a table index
+      if (r.status != DYN_READ_OK) std::fill(km + r.flat_off, km + r.flat_off + r.kc, 0);
     }
   };
   const int parts = (pool && n >= 64) ? std::min<int>(pool->size() * 2, (int)(n / 16)) : 1;
@@ -817,7 +820,7 @@ int create_impl(dyn_aligner* a, uint64_t n_reads, const double* signals, const R
   }
   if (b->total_cols) {
     B_TRY(hipMemcpyAsync(b->d_kmers.p, b->h_kmers.p, b->total_cols * 4, hipMemcpyHostToDevice, a->stream));
-    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, a->stream);
+    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, (uint32_t)a->model.num_kmers, a->stream);
     B_TRY(hipGetLastError());
   }
   const double t_enqueued = now_ms();
@@ -1658,3 +1661,31 @@ int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
 }
 
 }  // extern "C"
+
+// DYN_BACKTRACE=1: the call stack of the thread that raises SIGABRT / SIGSEGV, written to stderr before the default action
+// (debugging aid on boxes without a debugger; async-signal-safe calls only).
+#include <execinfo.h>
+#include <unistd.h>
+#include <signal.h>
+namespace {
+void dyn_backtrace_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[dynamont_mi] fatal signal, backtrace:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct DynBacktraceInstaller {
+  DynBacktraceInstaller() {
+    const char* e = std::getenv("DYN_BACKTRACE");
+    if (e && *e == '1') {
+      void* warm[2];
+      (void)backtrace(warm, 2);  // loads libgcc now, not inside the handler
+      signal(SIGABRT, dyn_backtrace_handler);
+      signal(SIGSEGV, dyn_backtrace_handler);
+    }
+  }
+} dyn_backtrace_installer;
+}  // namespace

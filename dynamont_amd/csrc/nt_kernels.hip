@@ -1137,10 +1137,13 @@ __device__ __forceinline__ bool pages_take(const QueueArgs& q, const WaveCtx& w,
 // per-column emission table: par[i] = model[kmers[i]]  (aligner.cpp:241-245 scoreKmer lookup)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_prep_params(const int32_t* __restrict__ kmers, const Emis* __restrict__ model,
-                              Emis* __restrict__ par, uint64_t total) {
+                              Emis* __restrict__ par, uint64_t total, uint32_t num_kmers) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) par[i] = model[kmers[i]];
+  // the code is clamped into the table: the columns of a read whose sequence turned out invalid half-way through the
+  // encoding never reach the read queue, but they are part of this range, and whatever a table index is made of must
+  // not be able to take the load out of bounds
+  for (; i < total; i += stride) par[i] = model[min((uint32_t)kmers[i], num_kmers - 1u)];
 }
 
 __global__ void k_pool_init(PagePool pool, uint32_t first_free, uint32_t n_static) {
@@ -1589,13 +1592,13 @@ void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const ui
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
-void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
+void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total, uint32_t num_kmers,
                         hipStream_t s) {
-  if (!total) return;
+  if (!total || !num_kmers) return;
   const int block = 256;
   const uint64_t want = (total + block - 1) / block;
   const int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(k_prep_params, dim3(grid), dim3(block), 0, s, kmers, model, par, total);
+  hipLaunchKernelGGL(k_prep_params, dim3(grid), dim3(block), 0, s, kmers, model, par, total, num_kmers);
 }
 
 void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, hipStream_t s) {

@@ -123,7 +123,7 @@ struct QueueArgs {
 void launch_preprocess(const void* raw, int raw_dtype, int compute_f32, const uint64_t* offs,
                        const double* shift, const double* scale, const float* cal_offset, const float* cal_scale,
                        void* norm_tmp, double* out, int n_reads, uint64_t max_len, int W, double n_sigmas, hipStream_t s);
-void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total,
+void launch_prep_params(const int32_t* kmers, const Emis* model, Emis* par, uint64_t total, uint32_t num_kmers,
                         hipStream_t s);
 // free list = pages [first_free, n_pages); queue head = n_static; statistics cleared
 void launch_pool_init(const PagePool& pool, uint32_t first_free, int n_static, hipStream_t s);
