@@ -29,6 +29,7 @@ from dynamont_amd.zstd_io import open_writer
 CSV_HEADER = b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
 POLYA = "AAAAAAAAA"
 
+MAX_SAMPLES_IN_FLIGHT = 512 << 20  # ~1 GB of pinned int16 staging + ~4 GB of float64 on the device, whatever --depth says
 LAST_RUN: dict = {}  # what the native sink of the last single-process run reported at close (bench.py's e2e_cli record)
 RAW_CACHE: OrderedDict | None = None
 RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
@@ -475,6 +476,7 @@ class _NativePipeline:
             raise OSError(err.value.decode())
         self.h = h
         self.submitted = 0
+        self.samples = {}  # batch number -> signal samples (in flight: bounded by MAX_SAMPLES_IN_FLIGHT as well as by depth)
         self.keep = {}   # batch number -> (ticket, arrays the sink still reads)
         self.free = []   # result objects of consumed batches
 
@@ -490,6 +492,7 @@ class _NativePipeline:
             done = int(self.L.dyn_csv_sink_completed(self.h))
             for k in [k for k in self.keep if k < done]:
                 t, res = self.keep.pop(k)[:2]
+                self.samples.pop(k, None)
                 t.close()
                 self.free.append(res)
             if block_until is None or self.submitted - done <= block_until:
@@ -509,9 +512,9 @@ class _NativePipeline:
             if not g:
                 continue
             self.check()
-            self._reap(block_until=self.depth - 1)
             n = len(g)
             sig, sig_off, seqs, seq_off = _pack_jobs(g, scattered=self.raw)
+            self._room_for(int(sig_off[-1]))
             out = self.free.pop() if self.free else None
             if self.raw:
                 cal = ([p[3][0] for p in g], [p[3][1] for p in g]) if g[0][3] is not None else None
@@ -533,7 +536,15 @@ class _NativePipeline:
                 self.check()  # the sink's own failure, with its message
                 raise RuntimeError("dyn_csv_sink_submit failed")
             self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g)  # g: the slices (and their readers) stay alive
+            self.samples[self.submitted] = int(sig_off[-1])
             self.submitted += 1
+
+    def _room_for(self, samples: int) -> None:
+        """``depth`` batches in flight, fewer when they are large (every batch in flight holds its samples as int16 in
+        pinned host memory and as float64 on the device)"""
+        self._reap(block_until=self.depth - 1)
+        while self.samples and sum(self.samples.values()) + samples > MAX_SAMPLES_IN_FLIGHT:
+            self._reap(block_until=len(self.samples) - 1)
 
     def submit_columns(self, jb, chunks, raw_off, cal, owners) -> None:
         """One batch prepared by prepare_job_columns: compressed POD5 chunks and column arrays straight into
@@ -558,7 +569,7 @@ class _NativePipeline:
                                     (cal_o[keep], cal_s[keep], calibrated[keep]), owners)
             return
         self.check()
-        self._reap(block_until=self.depth - 1)
+        self._room_for(int(raw_off[-1]))
         n = jb.n
         out = self.free.pop() if self.free else None
         t = self.aligner.align_vbz_async(chunks, raw_off, jb.shift, jb.scale, jb.seqs, jb.seq_off, window=3, n_sigmas=3.0, f32=False,
@@ -577,6 +588,7 @@ class _NativePipeline:
             self.check()
             raise RuntimeError("dyn_csv_sink_submit failed")
         self.keep[self.submitted] = (t, res, jb, seq_off, rid, sid, starts, lengths, chunks, raw_off, cal, owners)
+        self.samples[self.submitted] = int(raw_off[-1])
         self.submitted += 1
 
     def check(self) -> None:
