@@ -69,14 +69,14 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=0, help="distinct batches the steps cycle through (0 = workload default)")
-    ap.add_argument("--depth", type=int, default=6,
-                    help="batches in flight. The engine merges tickets that wait while the GPU is busy into one launch (a launch "
-                         "of 1 024 reads on 1 024 waves cannot balance): 3 overlap copies with kernels, 6 let two or three "
-                         "batches share a launch")
+    ap.add_argument("--depth", type=int, default=12,
+                    help="batches in flight (the CLI's default too). The engine merges tickets that wait while the GPU is busy into "
+                         "one launch (a launch of 1 024 reads on 1 024 waves cannot balance): 3 overlap copies with kernels, 12 "
+                         "keep launches of three batches following each other")
     ap.add_argument("--pinned-inputs", action="store_true",
                     help="experiment: caller arrays in page-locked memory (dyn_host_alloc); default is ordinary NumPy memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
