@@ -120,7 +120,15 @@ void Pipeline::drain() {
 constexpr size_t MERGE_MAX_TICKETS = 16;
 constexpr uint64_t MERGE_READS_PER_SLOT = 3;
 
-static uint64_t merge_max_reads(const dyn_aligner* a) { return MERGE_READS_PER_SLOT * (uint64_t)a->n_cus * dynk::WAVES_PER_CU; }
+static uint64_t merge_reads_per_slot() {  // DYN_MERGE_READS_PER_SLOT: experiments
+  static const uint64_t v = [] {
+    const char* e = std::getenv("DYN_MERGE_READS_PER_SLOT");
+    const long x = e ? std::atol(e) : 0;
+    return x > 0 ? (uint64_t)x : MERGE_READS_PER_SLOT;
+  }();
+  return v;
+}
+static uint64_t merge_max_reads(const dyn_aligner* a) { return merge_reads_per_slot() * (uint64_t)a->n_cus * dynk::WAVES_PER_CU; }
 static bool mergeable(const dyn_batch* x) {
   return x->job != DynJob::Train && x->n > 0 && 2 * x->n <= merge_max_reads(x->a);
 }
