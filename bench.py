@@ -42,6 +42,7 @@ import json
 import os
 import subprocess
 import sys
+import shutil
 import tempfile
 import time
 
@@ -87,6 +88,8 @@ def parse():
                          "bit) and what the bench line is quoted in; 'off' / 'all' are experiments, not bench lines")
     ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e_cli` record (N = 1: the whole CLI on a synthetic .pod5 + basecall file)")
     ap.add_argument("--e2e-reads", type=int, default=32768, help="reads of the e2e_cli dataset (a multiple of 4 096: that many distinct reads, repeated)")
+    ap.add_argument("--e2e-large-reads", type=int, default=131072,
+                    help="a second e2e_cli run on that many reads (`e2e_cli.large`: start-up and drain weigh a quarter as much); 0 = skip")
     ap.add_argument("--e2e-batch-reads", type=int, default=0, help="--batch-reads of the e2e_cli run (0 = the CLI's default)")
     ap.add_argument("--no-resident", action="store_true", help="skip the kernel_resident leg (profiling runs: every launch of the process then belongs to the timed region)")
     ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
@@ -539,11 +542,17 @@ def main():
     al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
     if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
         try:
-            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, {"start": "ties"}.get(args.strict, args.strict), args.e2e_batch_reads)
+            strict = {"start": "ties"}.get(args.strict, args.strict)
+            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, strict, args.e2e_batch_reads)
+            if args.e2e_large_reads > args.e2e_reads:
+                shutil.rmtree(os.path.join(workdir, "e2e"), ignore_errors=True)
+                big = run_e2e_cli(args.e2e_large_reads, workdir, strict, args.e2e_batch_reads)
+                line["e2e_cli"]["large"] = {k_: big[k_] for k_ in ("value", "unit", "wall_s", "reads", "reads_per_s", "samples", "input", "output", "error_lines")}
         except Exception as e:  # the headline stands on its own
-            line["e2e_cli"] = {"error": f"{type(e).__name__}: {e}"}
+            line.setdefault("e2e_cli", {})["error"] = f"{type(e).__name__}: {e}"
     if rank == 0:
         print(json.dumps(line))
+    shutil.rmtree(workdir, ignore_errors=True)  # models, the cpu_baseline's files, the e2e datasets and their output
     if use_dist:
         dist.destroy_process_group()
 
