@@ -262,6 +262,10 @@ def main():
     al = Aligner(model_path, pore, mode="basic", band=400, device=local_rank)
     al.set_strict(args.strict)
     depth = max(1, args.depth)
+    if max(b[4] for b in batches) > 1536:
+        # batches of more reads than the engine merges (its cap: three reads per wave slot, two tickets at least) gain nothing
+        # from waiting tickets; each ticket in flight holds its samples twice (pinned staging, device): 4 overlap everything
+        depth = min(depth, 4)
     free_results: list = []  # result objects are reused: fresh 50 MB arrays per batch would be page-faulted in every time
 
     # ---- N > 1: fixed-size buffers for the gather (sizes differ per rank and batch), two sets: the gather of step k
