@@ -89,6 +89,7 @@ struct dyn_csv_sink {
   uint64_t csv_bytes = 0, zst_bytes = 0;
   std::atomic<uint64_t> error_lines{0};
   bool closing = false, items_done = false, jobs_closed = false, failed = false;
+  bool first_part = true, last_part = true;  // dyn_csv_sink_open_part: a part of a frame that several processes write
   std::thread t_sink, t_writer;
   std::vector<std::thread> t_comp;
   std::vector<std::shared_ptr<Blob>> spare;  // recycled row buffers (first-touch page faults cost more than formatting)
@@ -138,7 +139,7 @@ struct dyn_csv_sink {
       us_resize.fetch_add((uint64_t)((now_ms() - k0) * 1e3));
       size_t rc = z.compressBegin(ctx, level);
       size_t pos = 0;
-      if (!z.isError(rc) && j->index != 0) {
+      if (!z.isError(rc) && (j->index != 0 || !first_part)) {
         rc = z.compressContinue(ctx, j->out.data(), cap, nullptr, 0);  // this context's frame header: dropped
         if (!z.isError(rc)) z.invalidateRepCodes(ctx);
       }
@@ -305,7 +306,7 @@ struct dyn_csv_sink {
   }
 
   void sink_loop() {
-    {
+    if (first_part) {
       auto hdr = std::make_shared<Blob>();
       hdr->cap = sizeof kHeader;
       hdr->data.reset(new char[hdr->cap]);
@@ -334,7 +335,7 @@ struct dyn_csv_sink {
     if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1')
       std::fprintf(stderr, "[csv sink] batches %llu: waiting for the GPU %.1f ms, bound + buffer %.1f, format %.1f, prefix sums %.1f, handing jobs to the compressors %.1f; compress threads busy %.1f ms in sum, %.1f ms of CPU time (%d threads; of which sizing the output buffer %.1f, gathering the rows %.1f), writer in fwrite %.1f ms\n",
                    (unsigned long long)completed.load(), t_wait, t_errors, t_format, t_compact, t_append, us_compress.load() / 1e3, us_compress_cpu.load() / 1e3, threads, us_resize.load() / 1e3, us_probe.load() / 1e3, us_write.load() / 1e3);
-    add_job(nullptr, 0, 0, true);  // the empty last block that closes the frame
+    if (last_part) add_job(nullptr, 0, 0, true);  // the empty last block that closes the frame
     {
       std::lock_guard<std::mutex> lk(m);
       jobs_closed = true;
@@ -348,6 +349,11 @@ extern "C" {
 
 int dyn_csv_sink_open(const char* csv_zst_path, const char* errors_path, int level, int threads, dyn_csv_sink** out,
                       char* err, uint64_t errcap) {
+  return dyn_csv_sink_open_part(csv_zst_path, errors_path, level, threads, 1, 1, out, err, errcap);
+}
+
+int dyn_csv_sink_open_part(const char* csv_zst_path, const char* errors_path, int level, int threads, int first, int last,
+                           dyn_csv_sink** out, char* err, uint64_t errcap) {
   auto put = [&](const std::string& s) {
     if (err && errcap) {
       std::snprintf(err, (size_t)errcap, "%s", s.c_str());
@@ -370,6 +376,8 @@ int dyn_csv_sink_open(const char* csv_zst_path, const char* errors_path, int lev
   s->errors_path = errors_path;
   s->level = level;
   s->threads = std::max(1, threads);
+  s->first_part = first != 0;
+  s->last_part = last != 0;
   dyn_csv_sink* p = s.release();
   for (int t = 0; t < p->threads; ++t) p->t_comp.emplace_back([p] { p->compress_loop(); });
   p->t_writer = std::thread([p] { p->writer_loop(); });

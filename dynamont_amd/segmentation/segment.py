@@ -460,18 +460,22 @@ class _NativePipeline:
     dyn_batch_align_raw_async and its ticket straight on to the library's CSV sink, whose threads wait for it, format,
     compress into the one zstd frame and write -- Python only builds the next batch. Same interface as _Pipeline."""
 
-    def __init__(self, aligner: Aligner, outfile: str, raw: bool, depth: int = 3, threads: int = 8):
+    def __init__(self, aligner: Aligner, outfile: str, raw: bool, depth: int = 3, threads: int = 8, first: bool = True,
+                 last: bool = True, errfile: str | None = None):
+        """``first`` / ``last``: this process writes a PART of the frame (dyn_csv_sink_open_part: one process per GPU, every
+        rank compresses its own rows) -- with the header line and the frame header / with the frame's closing block."""
         import ctypes as C
         from dynamont_amd import _native as N
         self.C, self.N, self.L = C, N, N.lib()
         self.aligner, self.raw, self.depth = aligner, raw, max(1, depth)
-        errfile = splitext(splitext(outfile)[0])[0] + ".errors"
+        errfile = errfile or splitext(splitext(outfile)[0])[0] + ".errors"
         h = C.c_void_p()
         err = C.create_string_buffer(1024)
         import os
         threads = int(os.environ.get("DYN_SINK_THREADS", threads))
         self.threads = threads
-        rc = self.L.dyn_csv_sink_open(outfile.encode(), errfile.encode(), int(os.environ.get("DYN_SINK_LEVEL", 3)), int(threads), C.byref(h), err, 1024)
+        rc = self.L.dyn_csv_sink_open_part(outfile.encode(), errfile.encode(), int(os.environ.get("DYN_SINK_LEVEL", 3)), int(threads),
+                                           int(first), int(last), C.byref(h), err, 1024)
         if rc != N.DYN_OK:
             raise OSError(err.value.decode())
         self.h = h
@@ -615,6 +619,43 @@ class _NativePipeline:
             raise RuntimeError(err.value.decode())
 
 
+def _gather_parts(comm, parallel, outfile: str, part: str, part_err: str | None) -> None:
+    """One process per GPU, all ranks done: the parts of the frame (complete zstd blocks, compressed where their rows
+    were computed) travel to rank 0 rank by rank -- a part must stay in one piece -- and are appended to its own part,
+    followed by the frame's closing block; the ranks' error lines likewise. The only exchange of the job."""
+    import os
+    rank, world = comm.rank, comm.world
+    chunk_bytes = 64 << 20
+    out = open(outfile, "ab") if rank == 0 else None
+    for src in range(1, world):
+        f = open(part, "rb") if rank == src else None
+        while True:
+            chunk = f.read(chunk_bytes) if f else b""
+            blobs = parallel.gather_bytes(comm, chunk)
+            if rank == 0 and blobs[src]:
+                out.write(blobs[src])
+            if not parallel.any_rank(comm, rank == src and len(chunk) == chunk_bytes):
+                break
+        if f:
+            f.close()
+    if out:
+        out.write(b"\x01\x00\x00")  # DYN_ZSTD_FRAME_END: an empty last block closes the frame
+        out.close()
+    text = b""
+    if rank != 0 and part_err and os.path.exists(part_err):
+        text = open(part_err, "rb").read()
+    blobs = parallel.gather_bytes(comm, text)
+    if rank == 0:
+        extra = b"".join(b for b in blobs[1:] if b)
+        if extra:
+            with open(splitext(splitext(outfile)[0])[0] + ".errors", "ab") as f:
+                f.write(extra)
+    else:
+        for path in (part, part_err):
+            if path and os.path.exists(path):
+                os.remove(path)
+
+
 def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_path: str, pore: str, mode: str,
             minq: float = 0, device: int = 0, batch_reads: int = 1024, mem_budget_gib: float = 0.0,
             host_preprocess: bool = False, depth: int = 12, strict_ties: str = "ties", host_threads: int = 0) -> None:
@@ -626,9 +667,12 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
     rank, world = (comm.rank, comm.world) if comm else (0, 1)
     if comm:
         device = local_rank
-    # single process: the library's native sink owns the output file; multi-rank: rank 0 runs the Python listener
-    # and receives the other ranks' rows through the gather
-    native = comm is None and not ZSTD_PARALLEL_FRAMES
+    # Every process owns a native sink (csv_sink.cpp). One process: it writes the output file. One process per GPU: every
+    # rank formats AND compresses its own rows into a part of the frame (compression is the largest host cost of the
+    # output: 11 core-seconds per 32 768 reads -- left to rank 0 it would cap the job at one GPU's speed); at the end the
+    # parts' bytes are gathered to rank 0, which appends them to its own and closes the frame. --parallel-zstd-frames keeps
+    # the Python listener (rank 0) and the per-round gather of the formatted rows.
+    native = not ZSTD_PARALLEL_FRAMES
     q = queue_mod.Queue() if (rank == 0 and not native) else None
     writer = None
     if q is not None:
@@ -659,31 +703,59 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
             aligner.set_strict(strict_ties)
             if native:
-                pipe = sink = _NativePipeline(aligner, outfile, raw=not host_preprocess, depth=depth,
-                                              threads=host_threads or max(4, min(16, available_cpus() - 4)))
-            else:
-                pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)
-            if native and not host_preprocess and _native_bam(basecalls):
-                # single process, BAM basecalls: the jobs arrive as columns; raw files that can point at their compressed
-                # chunks (.pod5, VBZ) are served without a Python object per read, any other reader read by read
-                for jb in job_batches(basecalls, minq, batch_reads, is_rna):
-                    prepared = prepare_job_columns(jb, data_path, sink.put)
-                    if prepared is not None:
-                        pipe.submit_columns(*prepared)
-                        continue
+                import os
+                import tempfile
+                part, part_err = outfile, None
+                if rank != 0:  # a part of the frame, in local scratch space; its bytes travel to rank 0 at the end
+                    fd, part = tempfile.mkstemp(prefix=f"dynamont_part{rank}_", suffix=".zst")
+                    os.close(fd)
+                    part_err = part + ".errors"
+                local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+                threads = host_threads or max(2, min(16, available_cpus() // local_world - (4 if local_world == 1 else 2)))
+                pipe = sink = _NativePipeline(aligner, part, raw=not host_preprocess, depth=depth, threads=threads,
+                                              first=rank == 0, last=world == 1, errfile=part_err)
+                if not host_preprocess and _native_bam(basecalls):
+                    # BAM basecalls: the jobs arrive as columns (this rank's share of them); raw files that can point at their
+                    # compressed chunks (.pod5, VBZ) are served without a Python object per read, any other reader read by read
+                    for jb in job_batches(basecalls, minq, batch_reads, is_rna, rank, world):
+                        prepared = prepare_job_columns(jb, data_path, sink.put)
+                        if prepared is not None:
+                            pipe.submit_columns(*prepared)
+                            continue
+                        pending = []
+                        for i, job in enumerate(jobs_from_columns(jb, data_path)):
+                            try:
+                                signal, read, cal = prepare_job_raw(job, is_rna, oriented=True)
+                            except Exception as error:  # noqa: BLE001  (segment.py:178-187)
+                                sink.put(f"error: worker, {error}\tN: {int(jb.bases[i])}\tRid: {job[6]}\tSid: {job[7]}")
+                                continue
+                            pending.append((signal, read, job, cal))
+                        pipe.submit(pending)
+                else:
                     pending = []
-                    for i, job in enumerate(jobs_from_columns(jb, data_path)):
+                    for job in generate_jobs(data_path, basecalls, minq, rank, world):
                         try:
-                            signal, read, cal = prepare_job_raw(job, is_rna, oriented=True)
+                            if host_preprocess:
+                                signal, read = prepare_job(job, is_rna)
+                                cal = None
+                            else:
+                                signal, read, cal = prepare_job_raw(job, is_rna)
                         except Exception as error:  # noqa: BLE001  (segment.py:178-187)
-                            sink.put(f"error: worker, {error}\tN: {int(jb.bases[i])}\tRid: {job[6]}\tSid: {job[7]}")
+                            sink.put(f"error: worker, {error}\tN: {len(job[5])}\tRid: {job[6]}\tSid: {job[7]}")
                             continue
                         pending.append((signal, read, job, cal))
-                    pipe.submit(pending)
+                        if len(pending) >= batch_reads:
+                            pipe.submit(pending)
+                            pending = []
+                    if pending:
+                        pipe.submit(pending)
                 pipe.close()
                 pipe = None
+                if comm is not None:
+                    _gather_parts(comm, parallel, outfile, part, part_err)
                 print("Done with segmentation.", file=sys.stderr, flush=True)
                 return
+            pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)
             job_iter = generate_jobs(data_path, basecalls, minq, rank, world)
             exhausted = False
             rounds = 0

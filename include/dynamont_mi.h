@@ -321,6 +321,14 @@ uint64_t dyn_format_model(const char* kmers, int k, const double* mean, const do
 typedef struct dyn_csv_sink dyn_csv_sink;
 int dyn_csv_sink_open(const char* csv_zst_path, const char* errors_path, int level, int threads, dyn_csv_sink** out,
                       char* err, uint64_t errcap);
+/* The same sink writing a PART of a frame that several processes write (one process per GPU: every rank compresses its
+ * own rows, the root only concatenates bytes -- compressing is the largest host cost of the output by far). A part with
+ * `first` carries the CSV header line and the zstd frame header, a part with `last` the frame's closing block;
+ * first = last = 1 is dyn_csv_sink_open. Parts are sequences of complete zstd blocks: [first part][any other parts, in any
+ * order][DYN_ZSTD_FRAME_END] is ONE valid frame. */
+int dyn_csv_sink_open_part(const char* csv_zst_path, const char* errors_path, int level, int threads, int first, int last,
+                           dyn_csv_sink** out, char* err, uint64_t errcap);
+#define DYN_ZSTD_FRAME_END "\x01\x00\x00" /* an empty last block (raw, size 0): 3 bytes; the frames carry no checksum */
 int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
                         const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
                         const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths);

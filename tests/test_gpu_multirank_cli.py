@@ -41,6 +41,9 @@ def test_resquiggle_two_ranks_gather_rows(models, tmp_path):
     one = zstd_io.decompress(open(tmp_path / "single.csv.zst", "rb").read()).decode().splitlines()
     two = zstd_io.decompress(open(tmp_path / "multi.csv.zst", "rb").read()).decode().splitlines()
     assert one[0] == two[0] and sorted(one[1:]) == sorted(two[1:]) and len(one) > 500
+    # every rank compressed its own rows into a part of the frame; rank 0 appended the parts and closed it: ONE frame
+    assert zstd_io.count_frames(open(tmp_path / "multi.csv.zst", "rb").read()) == 1
+    assert not [f for f in os.listdir(tmp_path) if "part" in f]
     assert sorted(open(tmp_path / "single.errors").read().splitlines()) == sorted(open(tmp_path / "multi.errors").read().splitlines())
 
 
