@@ -158,7 +158,7 @@ struct dyn_csv_sink {
           at += take;
           ++r;
         }
-        us_probe.fetch_add((uint64_t)((now_ms() - p0) * 1e3));
+        us_gather.fetch_add((uint64_t)((now_ms() - p0) * 1e3));
         src = local.data();
       }
       if (!z.isError(rc))
@@ -166,9 +166,6 @@ struct dyn_csv_sink {
       if (!z.isError(rc)) pos = rc;
       us_compress.fetch_add((uint64_t)((now_ms() - k0) * 1e3));
       us_compress_cpu.fetch_add((uint64_t)((thread_cpu_ms() - kc0) * 1e3));
-      if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1' && (j->index < 20 || j->index % 40 == 0))
-        std::fprintf(stderr, "[csv sink] job %llu: %zu bytes -> %zu in %.2f ms (cpu %.2f) at %.1f\n", (unsigned long long)j->index, j->len, pos, now_ms() - k0,
-                     thread_cpu_ms() - kc0, now_ms());
       {
         std::lock_guard<std::mutex> lk(m);
         if (z.isError(rc)) fail(std::string("zstd: ") + z.getErrorName(rc));
@@ -227,7 +224,7 @@ struct dyn_csv_sink {
 
   // DYN_SINK_TRACE=1: where the sink thread's time goes (ms summed over the batches), printed at close
   double t_wait = 0, t_format = 0, t_compact = 0, t_append = 0, t_errors = 0;
-  std::atomic<uint64_t> us_compress{0}, us_write{0}, us_resize{0}, us_probe{0}, us_compress_cpu{0};
+  std::atomic<uint64_t> us_compress{0}, us_write{0}, us_resize{0}, us_gather{0}, us_compress_cpu{0};
   static double thread_cpu_ms() {
     timespec ts;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
@@ -334,7 +331,7 @@ struct dyn_csv_sink {
     }
     if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1')
       std::fprintf(stderr, "[csv sink] batches %llu: waiting for the GPU %.1f ms, bound + buffer %.1f, format %.1f, prefix sums %.1f, handing jobs to the compressors %.1f; compress threads busy %.1f ms in sum, %.1f ms of CPU time (%d threads; of which sizing the output buffer %.1f, gathering the rows %.1f), writer in fwrite %.1f ms\n",
-                   (unsigned long long)completed.load(), t_wait, t_errors, t_format, t_compact, t_append, us_compress.load() / 1e3, us_compress_cpu.load() / 1e3, threads, us_resize.load() / 1e3, us_probe.load() / 1e3, us_write.load() / 1e3);
+                   (unsigned long long)completed.load(), t_wait, t_errors, t_format, t_compact, t_append, us_compress.load() / 1e3, us_compress_cpu.load() / 1e3, threads, us_resize.load() / 1e3, us_gather.load() / 1e3, us_write.load() / 1e3);
     if (last_part) add_job(nullptr, 0, 0, true);  // the empty last block that closes the frame
     {
       std::lock_guard<std::mutex> lk(m);
