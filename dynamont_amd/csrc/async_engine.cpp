@@ -89,6 +89,7 @@ void Pipeline::submit(dyn_batch* b) {
     std::lock_guard<std::mutex> lk(m);
     q_front.push_back(b);
     ++in_flight;
+    peak_in_flight = std::max(peak_in_flight, in_flight);
   }
   cv_front.notify_one();
 }
@@ -112,13 +113,17 @@ void Pipeline::drain() {
 //   * at most one launch is queued behind the one that runs: a third waits as tickets, where it can still be merged;
 //   * with the GPU busy the front thread lingers up to 2 ms for tickets that are about to arrive (a consumer that has
 //     just got two results back submits two new batches a fraction of a millisecond apart);
-//   * only align tickets of the same kind (same calc flag, same raw format and preprocessing) are merged, up to
-//     MERGE_MAX_TICKETS tickets and three reads per wave slot -- at three the queue balances to within a few per cent
-//     (config 2: 41.3 ms per batch against 40.4 for an endless queue), and launches stay short enough for the copies of
-//     the next one to hide behind them; training tickets never are (their pooled statistics are per batch).
+//   * only align tickets of the same kind (same calc flag, same raw format and preprocessing) are merged; training
+//     tickets never are (their pooled statistics are per batch);
+//   * a launch takes at most a QUARTER of the tickets the caller has had in flight at once (two at least), and at most
+//     eight reads per wave slot: a caller that keeps 12 tickets in flight gets launches of three (four launches' worth
+//     of tickets cover the one that runs, the one queued behind it, the one being unpacked and the one being collected
+//     -- larger launches starve that pipeline: the CLI's run of 32 batches got 8 % slower with launches of five), one
+//     that keeps 32 gets launches of eight, whose queue balances better (config 2, kernel time per batch: 42.0 ms at
+//     three, 40.3 at eight, 39.2 without the certified reads).
 // With nothing queued behind it a ticket starts at once, alone: latency is only ever added while the GPU is busy anyway.
 constexpr size_t MERGE_MAX_TICKETS = 16;
-constexpr uint64_t MERGE_READS_PER_SLOT = 3;
+constexpr uint64_t MERGE_READS_PER_SLOT = 8;
 
 static uint64_t merge_reads_per_slot() {  // DYN_MERGE_READS_PER_SLOT: experiments
   static const uint64_t v = [] {
@@ -130,7 +135,9 @@ static uint64_t merge_reads_per_slot() {  // DYN_MERGE_READS_PER_SLOT: experimen
 }
 static uint64_t merge_max_reads(const dyn_aligner* a) { return merge_reads_per_slot() * (uint64_t)a->n_cus * dynk::WAVES_PER_CU; }
 static bool mergeable(const dyn_batch* x) {
-  return x->job != DynJob::Train && x->n > 0 && 2 * x->n <= merge_max_reads(x->a);
+  // batches that leave the waves underfilled (fewer than 1.5 reads per wave slot): a batch of four reads per slot balances
+  // by itself, and merging those only makes the pipeline lumpy
+  return x->job != DynJob::Train && x->n > 0 && 2 * x->n <= 3 * (uint64_t)x->a->n_cus * dynk::WAVES_PER_CU;
 }
 static bool same_kind(const dyn_batch* x, const dyn_batch* y) {
   if (x->job != y->job || x->has_raw != y->has_raw) return false;
@@ -234,7 +241,8 @@ void Pipeline::front_loop() {
       take.push_back(q_front.front());
       q_front.pop_front();
       uint64_t reads = take[0]->n;
-      while (merging && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < MERGE_MAX_TICKETS &&
+      const size_t max_tickets = std::min<size_t>(MERGE_MAX_TICKETS, std::max<size_t>(2, (size_t)(peak_in_flight / 4)));
+      while (merging && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < max_tickets &&
              mergeable(q_front.front()) && same_kind(take[0], q_front.front()) && reads + q_front.front()->n <= merge_max_reads(a)) {
         reads += q_front.front()->n;
         take.push_back(q_front.front());

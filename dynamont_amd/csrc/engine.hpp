@@ -268,6 +268,7 @@ struct Pipeline {
   std::deque<dyn_batch*> q_front;
   std::deque<Work> q_back;
   uint64_t in_flight = 0;        // tickets submitted and not yet done
+  uint64_t peak_in_flight = 0;   // the most the caller has kept in flight: bounds the tickets one launch takes
   uint64_t launches_pending = 0; // launches handed to the GPU whose results have not been unpacked yet
   bool stop = false;
 

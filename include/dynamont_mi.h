@@ -460,7 +460,8 @@ int dyn_plan_queue(uint64_t n_reads, const uint32_t* pages, const uint64_t* rows
  * by DMA without staging.
  * Merged launches: a read-queue launch of fewer reads than the device has waves (1 024) cannot balance -- every wave
  * holds one read and the launch lasts as long as its slowest. Align tickets of one kind that are WAITING while the GPU
- * still has a launch queued are therefore run as one launch (up to three reads per wave): same results, same
+ * still has a launch queued are therefore run as one launch (at most a quarter of the tickets the caller has had in
+ * flight at once -- 12 in flight: launches of three batches -- and eight reads per wave): same results, same
  * completion order, and each ticket still reports the launch that carried it (dyn_timing, launch_share) and serves its
  * own slice of the device rows (dyn_batch_device_results). A ticket that finds the GPU idle starts at once, alone;
  * training tickets are never merged. Environment variable DYN_NO_MERGE=1 switches the merging off. */
