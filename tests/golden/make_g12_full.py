@@ -45,7 +45,7 @@ def main():
     d = tempfile.mkdtemp(prefix="g12full_")
     mpaths = tie_parity.g12_model_paths(d)
     store = {}
-    for fam, (pore, mkey, gen) in tie_parity.G12_FAMILIES.items():
+    for fam, (pore, mkey, gen) in {**tie_parity.G12_FAMILIES, **tie_parity.EXTRA_FAMILIES}.items():
         _, mean, sd = synth.read_model_file(mpaths[mkey])
         reads = gen(mean, sd)
         with mp.get_context("fork").Pool(workers, initializer=_init, initargs=(mpaths[mkey], pore)) as pool:

@@ -19,17 +19,23 @@ import tie_parity  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=None)
 ap.add_argument("--batch", type=int, default=1000)
+ap.add_argument("--strict", default=None, help="off | ties | all: set the handle's strict mode instead of leaving the default")
+ap.add_argument("--families", default=None, help="comma-separated subset")
 args = ap.parse_args()
 g = np.load(os.path.join(ROOT, "tests", "golden", "_full", "g12_all.npz"))
 d = tempfile.mkdtemp(prefix="g12dev_")
 mpaths = tie_parity.g12_model_paths(d)
 record, t0 = {"families": {}}, time.time()
-for fam, (pore, mkey, gen) in tie_parity.G12_FAMILIES.items():
+for fam, (pore, mkey, gen) in {**tie_parity.G12_FAMILIES, **tie_parity.EXTRA_FAMILIES}.items():
+    if args.families and fam not in args.families.split(","):
+        continue
     _, mean, sd = synth.read_model_file(mpaths[mkey])
     reads = gen(mean, sd)
     assert np.array_equal(g[fam + "_S"], [len(r.signal) for r in reads]), fam   # the regenerated inputs are the generator's
     seg_off, sigpos, seqpos, Z = g[fam + "_seg_off"], g[fam + "_sigpos"], g[fam + "_seqpos"], g[fam + "_Z"]
     al = Aligner(mpaths[mkey], pore, band=400, device=0)
+    if args.strict:
+        al.set_strict(args.strict)
     border_dev, z_dev_flagged, z_dev_plain, flagged, failed, n_strict = [], [], 0, 0, [], 0
     for lo in range(0, len(reads), args.batch):
         part = reads[lo:lo + args.batch]
@@ -68,7 +74,8 @@ record["total"] = dict(reads=sum(r["reads"] for r in tot), borders_differ=sum(le
                        flagged_reads_with_a_different_Z=sum(len(r["flagged_reads_with_a_different_Z"]) for r in tot),
                        unflagged_reads_with_a_different_Z=sum(r["unflagged_reads_with_a_different_Z"] for r in tot),
                        wall_s=round(time.time() - t0, 1))
-record["how"] = "python tests/tie_device_full.py: handle as created (strict mode ties), batches of %d reads through dyn_batch_create/align/fetch" % args.batch
+record["strict_mode"] = args.strict or "default (ties)"
+record["how"] = "python tests/tie_device_full.py: handle as created (strict mode ties) unless --strict says otherwise, batches of %d reads through dyn_batch_create/align/fetch" % args.batch
 print("TOTAL", record["total"], flush=True)
 if args.out:
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

@@ -275,6 +275,32 @@ G12_FAMILIES = {
 }
 
 
+def polya_tail_reads(n: int, mean, sd, pore: str, seed: int):
+    """What a real direct-RNA read looks like to the aligner: the 3' polyA tail is sequenced first, so the reversed
+    basecall STARTS with a long homopolymer -- pad + 20 .. 150 more A's here, then 150 .. 500 random bases. Dozens of
+    neighbouring columns carry the same k-mer from column 0 on (the read-start tie of the G10 families, many columns wide)."""
+    _, rna, k = synth.PORES[pore]
+    mean_c, sd_c = synth.code_order_table(mean, sd, k, rna)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        run = int(rng.integers(20, 151))
+        nb = 9 + run + int(rng.integers(150, 501))
+        digits = rng.integers(0, 4, size=nb)
+        digits[:9 + run] = 0
+        digits[9 + run] = int(rng.integers(1, 4))
+        out.append(synth.read_from_digits(rng, digits, mean_c, sd_c, k, float(rng.choice([5.0, 10.0]))))
+    return out
+
+
+# families beyond the committed fixture: run in full on the device by tests/tie_device_full.py (reference results from
+# tests/golden/make_g12_full.py, not committed)
+EXTRA_FAMILIES = {
+    "rna004_polya_tail": ("rna004", "syn9", lambda m, s: polya_tail_reads(1000, m, s, "rna004", 8100)),
+    "rna002_polya_tail": ("rna002", "syn5_sd015", lambda m, s: polya_tail_reads(1000, m, s, "rna002", 8200)),
+}
+
+
 def g12_model_paths(outdir: str) -> dict:
     out = {}
     for name, (k, sd, decimals) in G12_MODELS.items():
