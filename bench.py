@@ -61,6 +61,7 @@ WORKLOADS = {
     "cfg1": ("cfg1", None, 8),
     "cfg2": ("cfg2", None, 8),
     "cfg2_small": ("cfg2", 64, 8),
+    "cfg2_polya": ("cfg2_polya", None, 8),
     "cfg3": ("cfg3", None, 2),
     "cfg4_share": ("cfg4", 4096, 4),
     "cfg5_share": ("cfg5", 1024, 8),
@@ -249,7 +250,7 @@ def main():
     _, mean, sd = synth.read_model_file(model_path)
     batches = []
     for j in range(n_batches):
-        reads = synth.make_reads(cfg["seed"] + 1000 * rank + 100003 * j, cfg["n_reads"], pore, mean, sd, cfg["n_bases"])
+        reads = synth.make_reads(cfg["seed"] + 1000 * rank + 100003 * j, cfg["n_reads"], pore, mean, sd, cfg["n_bases"], polya=cfg.get("polya"))
         sig, sig_off, seqs, seq_off = synth.pack_reads(reads)
         if args.pinned_inputs:
             ps = pinned_empty(sig.size, np.float64)

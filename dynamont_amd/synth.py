@@ -114,12 +114,17 @@ def _seq_codes(digits: np.ndarray, k: int) -> np.ndarray:
 
 
 def make_read(rng: np.random.Generator, mean_code: np.ndarray, sd_code: np.ndarray, k: int,
-              n_bases: int, dwell: float, rna: bool) -> SynthRead:
+              n_bases: int, dwell: float, rna: bool, polya=None) -> SynthRead:
     """One read: i.i.d. bases, per-k-mer dwell max(2, Poisson(dwell)), samples
-    N(mean_k, (c*stdev_k)^2) with c ~ U(0.8, 2.0). Guarantees S >= 2*Kc."""
+    N(mean_k, (c*stdev_k)^2) with c ~ U(0.8, 2.0). Guarantees S >= 2*Kc. ``polya`` = (lo, hi): the read goes on with that
+    many more A's behind the pad, the way a real direct-RNA read starts with its tail."""
     digits = rng.integers(0, 4, size=n_bases)
     if rna:
         digits[:9] = 0  # aligner-orientation RNA reads start with the polyA pad (segment.py:155-158)
+    if polya is not None:
+        run = int(rng.integers(polya[0], polya[1] + 1))
+        digits[:9 + run] = 0
+        digits[9 + run] = int(rng.integers(1, 4))
     return read_from_digits(rng, digits, mean_code, sd_code, k, dwell)
 
 
@@ -136,7 +141,7 @@ def read_from_digits(rng: np.random.Generator, digits: np.ndarray, mean_code: np
 
 
 def make_reads(seed: int, n_reads: int, pore: str, mean_file: np.ndarray, sd_file: np.ndarray,
-               n_bases, dwell: float | None = None) -> list[SynthRead]:
+               n_bases, dwell: float | None = None, polya=None) -> list[SynthRead]:
     """``n_bases`` is an int or a (lo, hi) range sampled uniformly per read."""
     _, rna, k = PORES[pore]
     if dwell is None:
@@ -146,7 +151,7 @@ def make_reads(seed: int, n_reads: int, pore: str, mean_file: np.ndarray, sd_fil
     out = []
     for _ in range(n_reads):
         nb = n_bases if isinstance(n_bases, int) else int(rng.integers(n_bases[0], n_bases[1] + 1))
-        out.append(make_read(rng, mean_code, sd_code, k, nb, dwell, rna))
+        out.append(make_read(rng, mean_code, sd_code, k, nb, dwell, rna, polya))
     return out
 
 
@@ -157,6 +162,9 @@ CONFIGS = {
     "cfg3": dict(pore="dna_r10_400bps", n_reads=4096, n_bases=(800, 8000), seed=3),
     "cfg4": dict(pore="rna004", n_reads=32768, n_bases=2000, seed=4),
     "cfg5": dict(pore="rna004", n_reads=8192, n_bases=2000, seed=5),
+    # not a BASELINE config: cfg2 with reads that start with a polyA tail of 20-150 bases, as real direct-RNA reads do --
+    # every read carries a structural tie (bench.py --workload cfg2_polya: what bit-exact borders cost on such data)
+    "cfg2_polya": dict(pore="rna004", n_reads=1024, n_bases=2000, seed=2, polya=(20, 150)),
 }
 
 

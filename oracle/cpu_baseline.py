@@ -67,7 +67,7 @@ def main():
     pore_id, _, k = synth.PORES[cfg["pore"]]
     _, mean, sd = synth.read_model_file(a.model)
     n = min(a.reads, cfg["n_reads"])
-    reads = synth.make_reads(cfg["seed"], n, cfg["pore"], mean, sd, cfg["n_bases"])  # first n reads of the workload
+    reads = synth.make_reads(cfg["seed"], n, cfg["pore"], mean, sd, cfg["n_bases"], polya=cfg.get("polya"))  # first n reads of the workload
     jobs = [(r.signal, r.sequence) for r in reads]
     procs = max(1, min(a.procs, n))
     init = (kind, a.model, pore_id, a.mode, 4 ** k)
