@@ -32,7 +32,9 @@ POLYA = "AAAAAAAAA"
 MAX_SAMPLES_IN_FLIGHT = 512 << 20  # ~1 GB of pinned int16 staging + ~4 GB of float64 on the device, whatever --depth says
 LAST_RUN: dict = {}  # what the native sink of the last single-process run reported at close (bench.py's e2e_cli record)
 RAW_CACHE: OrderedDict | None = None
-RAW_CACHE_SIZE = 3  # the pod5 files should more or less be ordered (segment.py:44)
+RAW_CACHE_SIZE = 32  # open readers kept (the reference keeps 3, segment.py:44,123-139: "the pod5 files should more or less be
+                     # ordered"); a basecall file over a directory of pod5 files interleaves them, a batch of 1 024 reads then touches
+                     # many, and re-opening one costs its index -- a memory-mapped reader that is merely kept costs nothing
 ZSTD_WORKERS = 0    # compression threads of the writer (0: up to 8 host cores; level 3 as the reference)
 ZSTD_PARALLEL_FRAMES = False  # --parallel-zstd-frames: consecutive independent frames instead of the reference's one
 
