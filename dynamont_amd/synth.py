@@ -122,7 +122,7 @@ def make_read(rng: np.random.Generator, mean_code: np.ndarray, sd_code: np.ndarr
     if rna:
         digits[:9] = 0  # aligner-orientation RNA reads start with the polyA pad (segment.py:155-158)
     if polya is not None:
-        run = int(rng.integers(polya[0], polya[1] + 1))
+        run = min(int(rng.integers(polya[0], polya[1] + 1)), max(0, n_bases - 11))
         digits[:9 + run] = 0
         digits[9 + run] = int(rng.integers(1, 4))
     return read_from_digits(rng, digits, mean_code, sd_code, k, dwell)
