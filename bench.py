@@ -29,6 +29,9 @@ the rank's segment rows (still resident in HBM) into a send buffer, an ASYNCHRON
 overlaps the next batch, and on rank 0 the copy of all ranks' rows into pinned host memory -- the line says
 "gather_lands_in": "rank0_pinned_host". The clock stops after the last gather and its host copy have completed.
 
+N = 1 also carries `e2e_cli`: the dynamont-resquiggle counterpart itself on a synthetic .pod5 + BAM dataset of 32 768 reads
+(configs[3]'s read count), and `e2e_cli.large` on 131 072 -- file in, compressed CSV out, in this process (run_e2e_cli).
+
 Import order (asserted below): `torch` is imported BEFORE the first dynamont_amd.Aligner is created. PyTorch's wheel
 bundles its own libamdhip64 and refuses to initialise once another copy is mapped; libdynamont_mi.so links the
 system one and is loaded lazily, at the first Aligner (dynamont_amd/_native.py does the same import itself in any
