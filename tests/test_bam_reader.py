@@ -14,6 +14,8 @@ from dynamont_amd.segmentation import segment as seg
 
 from test_format_pinning import _blocks, _records, spec_bam, spec_bgzf_block, spec_record  # the BAM assembled from the SAM specification
 
+pytestmark = pytest.mark.usefixtures("native_lib")   # the reader lives in libdynamont_mi.so (built on demand; no compute call)
+
 
 def python_jobs(data_path, bam, minq=0.0, rank=0, world=1):
     os.environ["DYN_PY_BAM"] = "1"

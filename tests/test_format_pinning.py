@@ -24,6 +24,8 @@ import pytest
 
 from dynamont_amd import bam_io
 
+pytestmark = pytest.mark.usefixtures("native_lib")   # BAM basecalls are read by the library (built on demand; no compute call)
+
 SEQ_CODE = "=ACMGRSVTWYHKDBN"
 
 

@@ -18,6 +18,8 @@ from dynamont_amd.segmentation import train as trn
 from dynamont_amd.segmentation import utils as U
 from oracle.pyoracle import Oracle
 
+pytestmark = pytest.mark.usefixtures("native_lib")   # BAM basecalls are read by the library (built on demand; no compute call)
+
 
 def hampel_loop(x, W=3, ns=3.0):
     """Explicit sliding-window restatement (the shape of the reference test's inline checker)."""

@@ -12,6 +12,8 @@ from dynamont_amd import pod5_io, pod5_native as P, synth
 from dynamont_amd.segmentation import segment as seg
 from conftest import model_for
 
+pytestmark = pytest.mark.usefixtures("native_lib")   # BAM basecalls are read by the library (built on demand; no compute call)
+
 
 def test_svb16_known_bytes():
     # samples 5, 5, 300, 299, -1 -> deltas 5, 0, 295, -1, -300 -> zigzag 10, 0, 590, 1, 599
