@@ -665,8 +665,9 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
             host_preprocess: bool = False, depth: int = 12, strict_ties: str = "ties", host_threads: int = 0,
             zstd_level: int = 3) -> None:
     """Counterpart of segment.py:261-371. Under ``torch.distributed.run`` every rank drives one GPU
-    on the reads ``index % world == rank`` and the formatted rows are gathered to rank 0, which owns
-    the writer (reads are independent; the gather is the only exchange)."""
+    on the reads ``index % world == rank``, formats and compresses its rows into a part of the output
+    frame, and the parts' bytes are gathered to rank 0, which owns the file (reads are independent;
+    that gather at the end is the only exchange)."""
     from dynamont_amd import parallel
     comm, local_rank = parallel.init_from_env()
     rank, world = (comm.rank, comm.world) if comm else (0, 1)
