@@ -397,6 +397,9 @@ int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, cons
     r.kc = r.L >= (uint64_t)m.k ? r.L - (uint64_t)m.k + 1 : 0;
     cap += r.kc;
     r.status = m.validate(r.S, r.L);
+    // 448 band slots per lattice row: a read is computable when its half band min(band / 2, columns / 2) fits them
+    if (r.status == DYN_READ_OK && std::min<uint64_t>(m.half_band, (r.kc + 1) / 2) > (uint64_t)dynk::MAX_HALF_BAND)
+      r.status = DYN_READ_BAND_TOO_WIDE;
     if (r.status == DYN_READ_OK) {
       r.flat_off = flat;
       flat += r.kc;
@@ -501,14 +504,6 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     copy_msg(err, errcap, e.what());
     delete a;
     return DYN_ERR_RUNTIME;
-  }
-  if (a->model.half_band > (uint64_t)dynk::MAX_HALF_BAND) {
-    char msg[160];
-    std::snprintf(msg, sizeof msg, "band %llu exceeds this build's limit of %d (kernels hold %d band slots per row)",
-                  (unsigned long long)band, 2 * dynk::MAX_HALF_BAND + 1, dynk::P);
-    copy_msg(err, errcap, msg);
-    delete a;
-    return DYN_ERR_INVALID_ARGUMENT;
   }
   if (device == DYN_DEVICE_HOST_ONLY) {
     a->host_only = true;
@@ -699,6 +694,7 @@ int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
     case DYN_READ_TOO_LARGE: s = "Read too large for the device memory budget"; break;
     case DYN_READ_NTK_MISMATCH: s = "NTK alignment failed: alignment scores do not match"; break;
     case DYN_READ_BAD_SIGNAL: s = "Signal could not be decoded"; break;
+    case DYN_READ_BAND_TOO_WIDE: s = "Band wider than this build's 448 band slots for a read of this length"; break;
     default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
   }
   copy_msg(buf, cap, s);

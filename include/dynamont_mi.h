@@ -75,6 +75,10 @@ enum dyn_read_status {
   DYN_READ_TOO_LARGE = 8,        /* "Read too large for the device memory budget": this read's lattice alone exceeds
                                     the HBM budget (or 2^31 rows); the reference would raise std::bad_alloc for that
                                     read only (segment.py:172-176), so it is a per-read status, not a batch error */
+  DYN_READ_BAND_TOO_WIDE = 11,   /* "Band wider than this build's 448 band slots for a read of this length": the handle was
+                                    created with band > 447 and the read has more than 447 lattice columns, so that its
+                                    half band min(band / 2, columns / 2) exceeds 223. Shorter reads are computed as the
+                                    reference computes them (for them a band of 448 and a band of 4 000 are the same band). */
   DYN_READ_BAD_SIGNAL = 10       /* "Signal could not be decoded" (dyn_batch_align_vbz_async): a POD5 chunk of this read is
                                     corrupt, truncated or shorter than the read's [start:end) slice. In the reference the
                                     pod5 reader raises inside the worker and the listener gets ONE line for that read,
@@ -198,9 +202,10 @@ int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errca
  * behaves like the reference's does in this snapshot: reads fail validation with the usual messages or get
  * DYN_READ_NTK_MISMATCH, training returns DYN_ERR_RUNTIME "Training is not implemented for this aligner" (aligner.cpp:
  * 38-44); no kernel runs. Any other value -> DYN_ERR_INVALID_ARGUMENT "Unknown aligner mode: <m>".
- * band: the reference takes any value (aligner.cpp:21); this build's kernels hold 448 band slots per lattice row, so
- * band > 447 -> DYN_ERR_INVALID_ARGUMENT "band <b> exceeds this build's limit of 447 ..." (every caller in the
- * reference fixes band = 400: segment.py:45, utils.py:161). device < 0 -> current HIP device. */
+ * band: any value, as in the reference (aligner.cpp:21). The kernels hold 448 band slots per lattice row: a read whose
+ * half band min(band / 2, columns / 2) exceeds 223 -- band > 447 AND more than 447 lattice columns -- gets the per-read
+ * status DYN_READ_BAND_TOO_WIDE, every other read is computed (every caller in the reference fixes band = 400:
+ * segment.py:45, utils.py:161). device < 0 -> current HIP device. */
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap);
 /* The lattice pool of a destroyed handle (up to ~100 GB; allocating or freeing that much takes seconds) is PARKED per

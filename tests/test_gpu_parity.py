@@ -807,3 +807,39 @@ def test_g11_ntk_mode_answers_like_the_reference(models):
             assert str(e.value) == c["train"]
         al.close()
 
+
+
+def test_band_above_447_short_reads_equal_the_oracle_long_reads_get_their_status(models):
+    """The reference takes any band (aligner.cpp:21). A handle created with band 1 000 computes every read whose half band
+    min(band / 2, columns / 2) fits the kernels' 448 band slots -- here reads of 60 .. 446 k-mers, for the longer of which
+    (402+ columns) the band is WIDER than at band 400 -- exactly as the oracle does at band 1 000, train() included; a read
+    with more columns gets DYN_READ_BAND_TOO_WIDE and leaves the others alone."""
+    model = models["syn5"]
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(515, 40, "rna002", mean, sd, (64, 450))
+    reads += synth.make_reads(516, 12, "rna002", mean, sd, (430, 450))     # 426 .. 446 k-mers: half band 213 .. 223
+    long_read = synth.make_reads(517, 1, "rna002", mean, sd, 700)[0]
+    al = Aligner(model, "rna002", band=1000, device=0)
+    orc = Oracle(model, synth.PORES["rna002"][0], 1000)
+    sigs, seqs = [r.signal for r in reads] + [long_read.signal], [r.sequence for r in reads] + [long_read.sequence]
+    res = al.align_batch(sigs, seqs, True)
+    assert res.status[-1] == 11 and res.error(len(reads)) == "Band wider than this build's 448 band slots for a read of this length"
+    for i, r in enumerate(reads):
+        assert res.status[i] == 0, (i, res.error(i))
+        got, want = res.read(i), orc.align(r.signal, r.sequence, True)
+        assert np.array_equal(got["signal_positions"], want["signal_positions"]) and np.array_equal(got["sequence_positions"], want["sequence_positions"]), i
+        assert np.abs(got["probabilities"] - want["probabilities"]).max() <= 1e-6 and abs(got["Z"] - want["Z"]) <= 1e-9 * abs(want["Z"])
+    # the wider band is a different computation for the reads above 401 columns: more lattice cells in the launch
+    wide = [r for r in reads if len(r.sequence) - 4 + 1 > 401]
+    cells = {}
+    for band in (400, 1000):
+        h = al if band == 1000 else Aligner(model, "rna002", band=400, device=0)
+        with h.batch([r.signal for r in wide], [r.sequence for r in wide]) as b:
+            b.align(True)
+            cells[band] = b.timing()["cells"]
+        if h is not al:
+            h.close()
+    assert len(wide) >= 12 and cells[1000] > cells[400]
+    tr = al.train_batch(sigs, seqs)
+    assert tr.status[-1] == 11 and (tr.status[:-1] == 0).all()
+    al.close()
