@@ -811,6 +811,90 @@ __device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, 
   int t = T - 1, n = N - 1;
   int slot = n % P;
   int stM = 0;  // the cell at row t is an M cell (carried across blocks)
+#ifndef DYN_EXP_TB_SERIAL
+  // The blocks follow each other at a fixed stride (a block is left at its lowest row, whatever the path does inside), so
+  // the next block's decision bits are fetched while this one is walked, and a block's path posteriors -- one dependent
+  // load per row -- are finished one block later: the walk pays neither HBM latency.
+  uint64_t nb[CPL];          // the bits of the block about to be walked (row base + lane)
+  uint32_t nprow = 0;
+  auto fetch = [&](int base_) {
+    const int row_ = base_ + lane;
+    nprow = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) nb[j] = 0;
+    if (row_ >= 1) {
+      nprow = pool_row(w, row_);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) nb[j] = bits[(size_t)nprow * CPL + j];
+    }
+  };
+  int pend_row = 0, pend_n = 0, pend_st = -1;   // this lane's path cell of the previous block, its posterior in flight
+  float pend_lp = 0.0f;
+  auto finish = [&]() {
+    if (pend_st >= 0) {
+      if (inplace || pend_st == 0) pp[pend_row] = exp((double)pend_lp);
+      pathn[pend_row] = (uint32_t)pend_n | (pend_st ? 0x80000000u : 0u);
+      if (pend_st) segrow[pend_n - 1] = (uint32_t)pend_row;
+    }
+    pend_st = -1;
+  };
+  if (t > 0 && n > 0) fetch(t - 63);
+  while (t > 0 && n > 0) {
+    const int base = t - 63;
+    const int row = base + lane;
+    const uint32_t prow = nprow;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) sb[lane * CPL + j] = nb[j];
+    wave_lds_sync();
+    if (base > 1) fetch(base - 64);   // (base <= 1: this is the last block)
+    int my_n = 0, my_slot = 0, my_st = -1;
+    const int block_lo = base < 1 ? 1 : base;  // lowest row of this block that exists
+    while (t >= block_lo && n > 0) {
+      if (stM) {  // M(t,n): segment start; continue with E(t-1, n-1)
+        if (row == t) {
+          my_n = n;
+          my_slot = slot;
+          my_st = 1;
+        }
+        --n;
+        slot = slot ? slot - 1 : P - 1;
+        stM = 0;
+        --t;
+        continue;
+      }
+      // state E in column n at row t: every lane tests its own row for this column
+      const uint64_t wd = sb[lane * CPL + (slot % CPL)];  // ballot word of cell index j = slot % CPL
+      const bool bit = (row >= block_lo) && (row <= t) && ((wd >> (slot / CPL)) & 1);  // lane = slot / CPL
+      const uint64_t m = __ballot(bit);
+      const int r = m ? base + (63 - __builtin_clzll(m)) : block_lo - 1;  // highest turning row, or none
+      const int e_lo = m ? r : block_lo;  // rows e_lo..t are E cells of column n
+      if (row >= e_lo && row <= t) {
+        my_n = n;
+        my_slot = slot;
+        my_st = 0;
+      }
+      if (m) {
+        t = r - 1;  // M cell of column n (may lie in the next block: stM carries over)
+        stM = 1;
+      } else {
+        t = block_lo - 1;
+      }
+    }
+    finish();   // the previous block's cells: their loads have had this block's walk to arrive
+    if (my_st >= 0) {
+      // E cell of the path: the forward sweep stored its log-posterior. M cells (segment starts, ~1 row in
+      // 10) get theirs from mpost, one lane per segment, instead of ~6 dependent loads in this walk.
+      const size_t cell = (size_t)prow * P + row_pos(my_slot);
+      if (inplace) pend_lp = lp[2 * cell + (my_st ? 0 : 1)];
+      else if (my_st == 0) pend_lp = lp[cell];
+      pend_row = row;
+      pend_n = my_n;
+      pend_st = my_st;
+    }
+    wave_lds_sync();
+  }
+  finish();
+#else
   while (t > 0 && n > 0) {
     const int base = t - 63;
     const int row = base + lane;
@@ -865,6 +949,7 @@ __device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, 
     }
     wave_lds_sync();
   }
+#endif
   return t == 0 && n == 0;
 }
 
