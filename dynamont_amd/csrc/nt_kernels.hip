@@ -286,6 +286,12 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+// The same for LDS alone: the fence above also waits for every global load and store in flight (s_waitcnt vmcnt(0)),
+// which is what a loop that prefetches through global memory must not do.
+__device__ __forceinline__ void wave_lds_sync_local() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // ---- LDS-DMA row ring (forward sweep) ---------------------------------------------------------------
 // The forward sweep must read one [448]-double bE row per lattice row while it overwrites an older row.
@@ -838,6 +844,7 @@ __device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, 
     }
     pend_st = -1;
   };
+  int sj = slot % CPL, sq = slot / CPL;   // the current column's slot, as (cell index within a lane, lane)
   if (t > 0 && n > 0) fetch(t - 63);
   while (t > 0 && n > 0) {
     const int base = t - 63;
@@ -845,38 +852,66 @@ __device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, 
     const uint32_t prow = nprow;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) sb[lane * CPL + j] = nb[j];
-    wave_lds_sync();
+    wave_lds_sync_local();
     if (base > 1) fetch(base - 64);   // (base <= 1: this is the last block)
-    int my_n = 0, my_slot = 0, my_st = -1;
+    int my_n = 0, my_st = -1;
     const int block_lo = base < 1 ? 1 : base;  // lowest row of this block that exists
+    // The walk is wave-uniform: rows are lanes, sets of rows are 64-bit scalar masks (lane i = row base + i), and a mask
+    // reaches the lanes as a select predicate (inverse ballot) -- the per-lane comparisons of rows against t, e_lo and
+    // block_lo and the division of the slot by CPL per step were most of the 80 instructions a step took.
+    const uint64_t in_block = base >= 1 ? ~0ull : (~0ull << (1 - base));  // lanes whose row exists (>= 1)
     while (t >= block_lo && n > 0) {
-      if (stM) {  // M(t,n): segment start; continue with E(t-1, n-1)
-        if (row == t) {
+      const int tl = t - base;                                        // lane of row t, 0 .. 63
+      if (stM) {  // M(t,n) carried over from the block above: segment start; continue with E(t-1, n-1)
+        if (__builtin_amdgcn_inverse_ballot_w64(1ull << tl)) {
           my_n = n;
-          my_slot = slot;
           my_st = 1;
         }
         --n;
-        slot = slot ? slot - 1 : P - 1;
+        if (sj == 0) {
+          sj = CPL - 1;
+          sq = sq ? sq - 1 : 63;
+        } else {
+          --sj;
+        }
         stM = 0;
         --t;
         continue;
       }
-      // state E in column n at row t: every lane tests its own row for this column
-      const uint64_t wd = sb[lane * CPL + (slot % CPL)];  // ballot word of cell index j = slot % CPL
-      const bool bit = (row >= block_lo) && (row <= t) && ((wd >> (slot / CPL)) & 1);  // lane = slot / CPL
-      const uint64_t m = __ballot(bit);
-      const int r = m ? base + (63 - __builtin_clzll(m)) : block_lo - 1;  // highest turning row, or none
-      const int e_lo = m ? r : block_lo;  // rows e_lo..t are E cells of column n
-      if (row >= e_lo && row <= t) {
-        my_n = n;
-        my_slot = slot;
-        my_st = 0;
-      }
+      // state E in column n at row t: every lane tests its own row's decision bit of this column
+      const uint64_t wd = sb[lane * CPL + sj];                       // ballot word of cell index j = slot % CPL
+      const uint64_t upto = (2ull << tl) - 1ull;                      // lanes 0 .. tl (tl = 63: the shift leaves 0, minus 1: all)
+      const uint64_t m = __ballot((wd >> sq) & 1) & upto & in_block;  // bit of lane slot / CPL; rows block_lo .. t
       if (m) {
-        t = r - 1;  // M cell of column n (may lie in the next block: stM carries over)
-        stM = 1;
+        // the path turns at the highest such row r: rows r .. t are E cells of column n, the M cell lies one row below,
+        // then E in column n-1 -- taken in the same step when that M cell lies in this block
+        const int rl = 63 - __builtin_clzll(m);
+        if (__builtin_amdgcn_inverse_ballot_w64(upto & ~((1ull << rl) - 1ull))) {
+          my_n = n;
+          my_st = 0;
+        }
+        if (base + rl - 1 >= block_lo) {
+          if (__builtin_amdgcn_inverse_ballot_w64(1ull << (rl - 1))) {
+            my_n = n;
+            my_st = 1;
+          }
+          --n;
+          if (sj == 0) {
+            sj = CPL - 1;
+            sq = sq ? sq - 1 : 63;
+          } else {
+            --sj;
+          }
+          t = base + rl - 2;
+        } else {
+          t = base + rl - 1;  // the M cell lies in the next block: stM carries over
+          stM = 1;
+        }
       } else {
+        if (__builtin_amdgcn_inverse_ballot_w64(upto & in_block)) {  // rows block_lo .. t are E cells of column n
+          my_n = n;
+          my_st = 0;
+        }
         t = block_lo - 1;
       }
     }
@@ -884,14 +919,14 @@ __device__ __forceinline__ bool traceback(const ReadDesc& rd, const WaveCtx& w, 
     if (my_st >= 0) {
       // E cell of the path: the forward sweep stored its log-posterior. M cells (segment starts, ~1 row in
       // 10) get theirs from mpost, one lane per segment, instead of ~6 dependent loads in this walk.
-      const size_t cell = (size_t)prow * P + row_pos(my_slot);
+      const size_t cell = (size_t)prow * P + row_pos(my_n % P);
       if (inplace) pend_lp = lp[2 * cell + (my_st ? 0 : 1)];
       else if (my_st == 0) pend_lp = lp[cell];
       pend_row = row;
       pend_n = my_n;
       pend_st = my_st;
     }
-    wave_lds_sync();
+    wave_lds_sync_local();
   }
   finish();
 #else
@@ -1371,12 +1406,19 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     if ((JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE) && status == 0) {
       const float* lp = JOB == JOB_ALIGN ? q.pool.lpe : reinterpret_cast<const float*>(q.pool.ws);
       const bool complete = traceback(rd, w, lp, q.pool.bits, q.tb, JOB == JOB_ALIGN_INPLACE, sb);
+#ifdef DYN_EXP_TRACE_SPLIT  // development: the statistics slots of the certified sweeps carry traceback / mpost cycles instead
+      const uint64_t t4 = __builtin_amdgcn_s_memtime();
+      cyc_bs += t4 - t3;
+#endif
       if (complete) {
         if (JOB == JOB_ALIGN) {
           // segrow was written by other lanes of this wave through global memory
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           mpost(rd, w, q.pool.ws, q.pool.lpe, sig, par, q.tb, Zb, q.m1);
         }
+#ifdef DYN_EXP_TRACE_SPLIT
+        cyc_fs += __builtin_amdgcn_s_memtime() - t4;
+#endif
         n_seg = rd.N - 1;
       } else {
         status = 7;  // DYN_READ_INTERNAL
@@ -1404,7 +1446,11 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
     atomicAdd(&stats[4], life);
     atomicMax(&stats[5], life);
+#ifdef DYN_EXP_TRACE_SPLIT
+    if (true) {
+#else
     if (MIXED) {
+#endif
       atomicAdd(&stats[6], (unsigned long long)cyc_bs);
       atomicAdd(&stats[7], (unsigned long long)cyc_fs);
       atomicAdd(&stats[8], (unsigned long long)n_fallback);
