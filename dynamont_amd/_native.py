@@ -104,6 +104,8 @@ SIGNATURES = {
     "dyn_csv_sink_open_part": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_csv_sink_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DynAlignOut), C.c_uint64, C.c_char_p, c_u64_p,
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_u64_p]),
+    "dyn_csv_sink_submit_bases": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DynAlignOut), C.c_uint64, C.c_char_p, c_u64_p,
+                                            C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_u64_p, C.POINTER(C.c_uint32)]),
     "dyn_csv_sink_error_line": (C.c_int, [C.c_void_p, C.c_char_p]),
     "dyn_csv_sink_completed": (C.c_uint64, [C.c_void_p]),
     "dyn_csv_sink_wait": (C.c_uint64, [C.c_void_p, C.c_uint64, C.c_int]),

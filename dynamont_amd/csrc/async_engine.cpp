@@ -236,12 +236,13 @@ void Pipeline::front_loop() {
       std::unique_lock<std::mutex> lk(m);
       cv_front.wait(lk, [&] { return (stop || !q_front.empty()) && (launches_pending < 2 || (stop && q_front.empty())); });
       if (q_front.empty()) return;  // stop requested and nothing left
-      if (merging && launches_pending >= 1 && mergeable(q_front.front()) && q_front.size() < MERGE_MAX_TICKETS)
-        cv_front.wait_for(lk, std::chrono::milliseconds(2), [&] { return stop || q_front.size() >= MERGE_MAX_TICKETS; });
+      const size_t max_tickets = std::min<size_t>(MERGE_MAX_TICKETS, std::max<size_t>(2, (size_t)(peak_in_flight / 4)));
+      // the linger ends as soon as nothing more can join this launch, or the GPU has run dry (the back thread's notify)
+      if (merging && launches_pending >= 1 && mergeable(q_front.front()) && q_front.size() < max_tickets)
+        cv_front.wait_for(lk, std::chrono::milliseconds(2), [&] { return stop || launches_pending == 0 || q_front.size() >= max_tickets; });
       take.push_back(q_front.front());
       q_front.pop_front();
       uint64_t reads = take[0]->n;
-      const size_t max_tickets = std::min<size_t>(MERGE_MAX_TICKETS, std::max<size_t>(2, (size_t)(peak_in_flight / 4)));
       while (merging && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < max_tickets &&
              mergeable(q_front.front()) && same_kind(take[0], q_front.front()) && reads + q_front.front()->n <= merge_max_reads(a)) {
         reads += q_front.front()->n;

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <future>
 #include <memory>
 #include <string>
@@ -131,8 +132,8 @@ struct dyn_bam_reader {
       b.crc = le32(map + pos + bsize - 8);
       b.isize = le32(map + pos + bsize - 4);
       b.dst = run.total;
-      if (b.isize > (1u << 30)) {  // (the specification caps a block at 64 KiB; a gzip member that inflates to more is still read)
-        run.error = path + ": implausible BGZF block size";
+      if (b.isize > (1u << 16)) {  // SAM specification 4.1: a BGZF block holds at most 64 KiB of data
+        run.error = path + ": BGZF block larger than 64 KiB";
         break;
       }
       run.total += b.isize;
@@ -299,7 +300,8 @@ bool numeric_tag(char typ, const uint8_t* p, double& d, int64_t& i) {
       float f;
       std::memcpy(&f, &u, 4);
       d = (double)f;  // the float32-rounded value, as pysam hands it out
-      i = (int64_t)f;
+      // an integer view only where one exists: the conversion of inf, NaN or |f| >= 2^63 is undefined behaviour
+      i = (f == f && f > -9.2e18f && f < 9.2e18f) ? (int64_t)f : 0;
       return true;
     }
     default: return false;
@@ -331,12 +333,13 @@ const Pairs PAIRS;
 
 extern "C" {
 
-int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_reader** out, char* err, uint64_t errlen) {
+static int bam_open_impl(const char* path, int threads, const char* rna_pad, dyn_bam_reader** out, char* err, uint64_t errlen) {
   if (!path || !out) {
     set_err(err, errlen, "dyn_bam_open: null argument");
     return DYN_ERR_INVALID_ARGUMENT;
   }
-  auto* r = new dyn_bam_reader();
+  std::unique_ptr<dyn_bam_reader> holder(new dyn_bam_reader());  // freed on every early return and on a throw
+  dyn_bam_reader* r = holder.get();
   r->path = path;
   r->threads = threads > 0 ? threads : 4;
   r->pad = rna_pad ? rna_pad : "";
@@ -344,7 +347,6 @@ int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_rea
   struct stat st;
   if (r->fd < 0 || fstat(r->fd, &st) != 0) {
     set_err(err, errlen, std::string(path) + ": cannot open");
-    delete r;
     return DYN_ERR_RUNTIME;
   }
   r->size = (size_t)st.st_size;
@@ -352,7 +354,6 @@ int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_rea
     void* m = mmap(nullptr, r->size, PROT_READ, MAP_PRIVATE, r->fd, 0);
     if (m == MAP_FAILED) {
       set_err(err, errlen, std::string(path) + ": cannot map");
-      delete r;
       return DYN_ERR_RUNTIME;
     }
     r->map = static_cast<const uint8_t*>(m);
@@ -362,10 +363,9 @@ int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_rea
   std::string e;
   if (!r->read_header(e)) {
     set_err(err, errlen, e);
-    delete r;
     return DYN_ERR_RUNTIME;
   }
-  *out = r;
+  *out = holder.release();
   return DYN_OK;
 }
 
@@ -373,8 +373,8 @@ void dyn_bam_close(dyn_bam_reader* r) { delete r; }
 
 uint64_t dyn_bam_skipped(const dyn_bam_reader* r) { return r ? r->skipped : 0; }
 
-int dyn_bam_next(dyn_bam_reader* r, uint64_t max_reads, uint32_t flags, double min_qual, uint32_t rank, uint32_t world, dyn_job_batch* out, char* err,
-                 uint64_t errlen) {
+static int bam_next_impl(dyn_bam_reader* r, uint64_t max_reads, uint32_t flags, double min_qual, uint32_t rank, uint32_t world, dyn_job_batch* out, char* err,
+                         uint64_t errlen) {
   if (!r || !out) {
     set_err(err, errlen, "dyn_bam_next: null argument");
     return DYN_ERR_INVALID_ARGUMENT;
@@ -550,6 +550,32 @@ int dyn_bam_next(dyn_bam_reader* r, uint64_t max_reads, uint32_t flags, double m
   out->signal_ids_bytes = r->sids.size();
   out->files_bytes = r->files.size();
   return DYN_OK;
+}
+
+// No exception crosses the C boundary: a damaged file can make a window's allocation or a worker thread's start fail
+// (std::bad_alloc, std::system_error rethrown by future::get()); the caller gets DYN_ERR_RUNTIME and a message.
+int dyn_bam_open(const char* path, int threads, const char* rna_pad, dyn_bam_reader** out, char* err, uint64_t errlen) {
+  try {
+    return bam_open_impl(path, threads, rna_pad, out, err, errlen);
+  } catch (const std::exception& e) {
+    set_err(err, errlen, std::string(path ? path : "?") + ": " + e.what());
+  } catch (...) {
+    set_err(err, errlen, std::string(path ? path : "?") + ": unknown failure while opening");
+  }
+  if (out) *out = nullptr;
+  return DYN_ERR_RUNTIME;
+}
+
+int dyn_bam_next(dyn_bam_reader* r, uint64_t max_reads, uint32_t flags, double min_qual, uint32_t rank, uint32_t world, dyn_job_batch* out, char* err,
+                 uint64_t errlen) {
+  try {
+    return bam_next_impl(r, max_reads, flags, min_qual, rank, world, out, err, errlen);
+  } catch (const std::exception& e) {
+    set_err(err, errlen, std::string(r ? r->path : "?") + ": " + e.what());
+  } catch (...) {
+    set_err(err, errlen, std::string(r ? r->path : "?") + ": unknown failure while reading");
+  }
+  return DYN_ERR_RUNTIME;
 }
 
 }  // extern "C"

@@ -69,6 +69,7 @@ struct Item {
   const char* const* signalids;
   const int64_t* sig_offsets;
   const uint64_t* signal_lengths;
+  const uint32_t* stored_bases;  // bases of the basecall as stored (before the RNA pad), or nullptr
 };
 
 }  // namespace
@@ -297,7 +298,10 @@ struct dyn_csv_sink {
       const bool worker = it.res->status[i] == DYN_READ_BAD_SIGNAL;
       std::string line = std::string(worker ? "error: worker, " : "error: native, ") + msg +
                          (worker ? std::string() : "\tT: " + std::to_string(it.signal_lengths[i])) + "\tN: " +
-                         std::to_string(it.seq_offsets[i + 1] - it.seq_offsets[i]) + "\tRid: " + it.readids[i] + "\tSid: " + it.signalids[i];
+                         // the reference's worker reports len(read) of the STORED basecall (segment.py:178-187), the aligner's
+                         // failure the read in aligner orientation, RNA pad included (segment.py:172-176)
+                         std::to_string(worker && it.stored_bases ? (uint64_t)it.stored_bases[i] : it.seq_offsets[i + 1] - it.seq_offsets[i]) +
+                         "\tRid: " + it.readids[i] + "\tSid: " + it.signalids[i];
       write_error_line(line);
     }
   }
@@ -386,13 +390,20 @@ int dyn_csv_sink_open_part(const char* csv_zst_path, const char* errors_path, in
 int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
                         const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
                         const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths) {
+  return dyn_csv_sink_submit_bases(s, a, ticket, res, n_reads, seqs, seq_offsets, readids, signalids, sig_offsets, signal_lengths, nullptr);
+}
+
+int dyn_csv_sink_submit_bases(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
+                              const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
+                              const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths,
+                              const uint32_t* stored_bases) {
   if (!s || !a || !ticket || !res || !seq_offsets || (n_reads && (!seqs || !readids || !signalids || !sig_offsets || !signal_lengths)))
     return DYN_ERR_INVALID_ARGUMENT;
   {
     std::lock_guard<std::mutex> lk(s->m);
     if (s->closing) return DYN_ERR_INVALID_ARGUMENT;
     if (s->failed) return DYN_ERR_RUNTIME;  // a batch, the compressor or the file has failed: dyn_csv_sink_close has the message
-    s->items.push_back(Item{a, ticket, res, n_reads, seqs, seq_offsets, readids, signalids, sig_offsets, signal_lengths});
+    s->items.push_back(Item{a, ticket, res, n_reads, seqs, seq_offsets, readids, signalids, sig_offsets, signal_lengths, stored_bases});
   }
   s->cv_items.notify_one();
   return DYN_OK;

@@ -864,6 +864,13 @@ int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count) {
   dyn_aligner* a = b->a;
   int rc = need_device(a);
   if (rc != DYN_OK) return rc;
+  if (b->group && b->group->g) {  // a member of a merged launch: its samples are a slice of the group's signal pool
+    const dyn_batch* g = b->group->g;
+    const uint64_t first = b->n ? g->reads[b->g_read0].sig_off : 0;
+    if ((first + count) * 8 > g->d_sig.bytes) return DYN_ERR_INVALID_ARGUMENT;
+    HIP_TRY(a, hipMemcpy(out, g->d_sig.as<double>() + first, count * 8, hipMemcpyDeviceToHost));
+    return DYN_OK;
+  }
   if (count * 8 > b->d_sig.bytes) return DYN_ERR_INVALID_ARGUMENT;
   HIP_TRY(a, hipMemcpy(out, b->d_sig.p, count * 8, hipMemcpyDeviceToHost));
   return DYN_OK;
@@ -1517,6 +1524,12 @@ namespace {
 
 int run_job_sync(dyn_batch* b, DynJob job) {
   dyn_aligner* a = b->a;
+  if (b->async) {
+    // An asynchronous ticket is a one-shot submission: its inputs were staged by the pipeline, and when it shared a launch
+    // with other tickets it owns neither device buffers nor a read table (dyn_batch.group) -- there is nothing to run again.
+    a->last_error = "dyn_batch_align / dyn_batch_train on an asynchronous ticket: submit a new ticket, or use dyn_batch_create";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
   {
     std::lock_guard<std::mutex> lk(a->mu);
     int rc = need_device(a);
@@ -1575,23 +1588,28 @@ int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out) {
   }
   int rc = need_device(a);
   if (rc != DYN_OK) return rc;
-  std::vector<ReadState> st(b->n);
-  if (b->n) HIP_TRY(a, hipMemcpy(st.data(), b->d_state.p, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
+  // A ticket that shared its launch with others (async_engine.cpp, merged launches) owns no device buffers and no read
+  // table of its own: its results are reads [g_read0, g_read0 + n) and rows [g_seg0, g_seg0 + capacity) of the group's batch.
+  const dyn_batch* src = (b->group && b->group->g) ? b->group->g : b;
+  const uint64_t read0 = src == b ? 0 : b->g_read0, seg0 = src == b ? 0 : b->g_seg0;
+  std::vector<ReadState> st(src->n);
+  if (b->n)
+    HIP_TRY(a, hipMemcpy(st.data() + read0, static_cast<const ReadState*>(src->d_state.p) + read0, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
   const bool want_rows = b->last_calc && (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
   if (want_rows && out->capacity < b->capacity) {
     a->last_error = "dyn_align_out.capacity is smaller than dyn_segment_capacity()";
     return DYN_ERR_INVALID_ARGUMENT;
   }
   const SegRow* rows = nullptr;
-  if (want_rows && b->capacity) {
-    HIP_TRY(a, a->h_rows.ensure(b->capacity * sizeof(SegRow)));
-    HIP_TRY(a, hipMemcpy(a->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost));
-    rows = static_cast<const SegRow*>(a->h_rows.p);
-  }
   static HelperPool pool(4);
   static std::mutex pool_mu;
-  std::lock_guard<std::mutex> lk(pool_mu);
-  unpack_align(b, st.data(), rows, out, &pool);
+  std::lock_guard<std::mutex> lk(pool_mu);  // also guards the handle's h_rows staging
+  if (want_rows && b->capacity) {
+    HIP_TRY(a, a->h_rows.ensure(b->capacity * sizeof(SegRow)));
+    HIP_TRY(a, hipMemcpy(a->h_rows.p, static_cast<const SegRow*>(src->d_rows.p) + seg0, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost));
+    rows = static_cast<const SegRow*>(a->h_rows.p) - seg0;  // unpack_align indexes rows by the batch's own segment offsets
+  }
+  unpack_align(src, st.data(), rows, out, &pool, read0, b->n, seg0);
   return DYN_OK;
 }
 

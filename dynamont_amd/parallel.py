@@ -137,6 +137,25 @@ def broadcast_str(comm: "Comm", text: str, src: int = 0) -> str:
     return bytes(buf.cpu().numpy().tobytes()).decode()
 
 
+_SCRATCH: list[str] = []
+
+
+def register_scratch(*paths: str) -> None:
+    """Files of this rank that must not outlive the job (a rank's part of the output frame in local scratch space can
+    be gigabytes): removed by ``abort`` -- which leaves through ``os._exit``, past every ``finally`` and ``atexit`` --
+    and by ``remove_scratch`` on the ordinary way out."""
+    _SCRATCH.extend(p for p in paths if p)
+
+
+def remove_scratch() -> None:
+    import os
+    while _SCRATCH:
+        try:
+            os.remove(_SCRATCH.pop())
+        except OSError:
+            pass
+
+
 def abort(comm: "Comm | None", exc: BaseException, grace_s: float = 5.0) -> None:
     """A rank that fails must not leave the others waiting in a collective until the process-group timeout: print
     the error, tear the process group down (closing its connections makes peers blocked in a gloo collective fail
@@ -149,6 +168,7 @@ def abort(comm: "Comm | None", exc: BaseException, grace_s: float = 5.0) -> None
     traceback.print_exception(type(exc), exc, exc.__traceback__)
     print(f"rank {comm.rank if comm else 0}: aborting the job", file=sys.stderr, flush=True)
     threading.Timer(grace_s, lambda: os._exit(1)).start()
+    remove_scratch()
     try:
         if comm is not None and comm.dist.is_initialized():
             comm.dist.destroy_process_group()

@@ -300,6 +300,12 @@ def prepare_job(job, is_rna: bool):
     return signal, read
 
 
+def _stored_bases(p) -> int:
+    """bases of the basecall as the BAM stores it -- what the reference's worker line reports as N (segment.py:178-187).
+    ``p`` = (signal, read, job, cal[, stored bases]): the fifth element where job[5] is already in aligner orientation"""
+    return int(p[4]) if len(p) > 4 else len(p[2][5])
+
+
 def prepare_job_raw(job, is_rna: bool, oriented: bool = False):
     """P1 without the arithmetic: the raw [start:end) slice and the aligner-orientation read. The slice is int16 ADC
     counts; ``cal`` = (offset, scale) when the reference would take the calibrated picoampere signal (``shift <= 400``,
@@ -432,7 +438,7 @@ class _Pipeline:
         for i in np.flatnonzero(res.status[:len(g)] != 0):
             signal, read, job = g[i][:3]
             if int(res.status[i]) == 10:  # DYN_READ_BAD_SIGNAL: the reference's worker fails before the aligner (segment.py:178-187)
-                self.sink.put(f"error: worker, {res.error(i)}\tN: {len(read)}\tRid: {job[6]}\tSid: {job[7]}")
+                self.sink.put(f"error: worker, {res.error(i)}\tN: {_stored_bases(g[i])}\tRid: {job[6]}\tSid: {job[7]}")
                 continue
             self.sink.put(f"error: native, {res.error(i)}\tT: {len(signal)}\tN: {len(read)}\tRid: {job[6]}\tSid: {job[7]}")
         t.close()
@@ -536,14 +542,16 @@ class _NativePipeline:
             sid = (C.c_char_p * n)(*[str(p[2][7]).encode() for p in g])
             starts = np.array([p[2][3] for p in g], dtype=np.int64)
             lengths = np.diff(sig_off).astype(np.uint64)
-            rc = self.L.dyn_csv_sink_submit(self.h, self.aligner._h, t._h, C.byref(res._c), n, seqs,
-                                            seq_off.ctypes.data_as(N.c_u64_p), rid, sid,
-                                            starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p))
+            bases = np.array([_stored_bases(p) for p in g], dtype=np.uint32)
+            rc = self.L.dyn_csv_sink_submit_bases(self.h, self.aligner._h, t._h, C.byref(res._c), n, seqs,
+                                                  seq_off.ctypes.data_as(N.c_u64_p), rid, sid,
+                                                  starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p),
+                                                  bases.ctypes.data_as(C.POINTER(C.c_uint32)))
             if rc != N.DYN_OK:
                 t.close()
                 self.check()  # the sink's own failure, with its message
                 raise RuntimeError("dyn_csv_sink_submit failed")
-            self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g)  # g: the slices (and their readers) stay alive
+            self.keep[self.submitted] = (t, res, seqs, seq_off, rid, sid, starts, lengths, g, bases)  # g: the slices (and their readers) stay alive
             self.samples[self.submitted] = int(sig_off[-1])
             self.submitted += 1
 
@@ -588,14 +596,16 @@ class _NativePipeline:
         starts = np.ascontiguousarray(jb.start, dtype=np.int64)
         lengths = np.diff(raw_off).astype(np.uint64)
         seq_off = np.ascontiguousarray(jb.seq_off, dtype=np.uint64)
-        rc = self.L.dyn_csv_sink_submit(self.h, self.aligner._h, t._h, C.byref(res._c), n, jb.seqs, seq_off.ctypes.data_as(N.c_u64_p),
-                                        C.cast(rid.ctypes.data, C.POINTER(C.c_char_p)), C.cast(sid.ctypes.data, C.POINTER(C.c_char_p)),
-                                        starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p))
+        bases = np.ascontiguousarray(jb.bases, dtype=np.uint32)
+        rc = self.L.dyn_csv_sink_submit_bases(self.h, self.aligner._h, t._h, C.byref(res._c), n, jb.seqs, seq_off.ctypes.data_as(N.c_u64_p),
+                                              C.cast(rid.ctypes.data, C.POINTER(C.c_char_p)), C.cast(sid.ctypes.data, C.POINTER(C.c_char_p)),
+                                              starts.ctypes.data_as(C.POINTER(C.c_int64)), lengths.ctypes.data_as(N.c_u64_p),
+                                              bases.ctypes.data_as(C.POINTER(C.c_uint32)))
         if rc != N.DYN_OK:
             t.close()
             self.check()
             raise RuntimeError("dyn_csv_sink_submit failed")
-        self.keep[self.submitted] = (t, res, jb, seq_off, rid, sid, starts, lengths, chunks, raw_off, cal, owners)
+        self.keep[self.submitted] = (t, res, jb, seq_off, rid, sid, starts, lengths, chunks, raw_off, cal, owners, bases)
         self.samples[self.submitted] = int(raw_off[-1])
         self.submitted += 1
 
@@ -716,6 +726,12 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                     fd, part = tempfile.mkstemp(prefix=f"dynamont_part{rank}_", suffix=".zst")
                     os.close(fd)
                     part_err = part + ".errors"
+                    parallel.register_scratch(part, part_err)  # gone with the job however it ends (parallel.abort included)
+                # ONE frame out of every rank's blocks: all of them must be compressed for the window rank 0's frame header
+                # declares, i.e. at rank 0's effective level -- a per-process DYN_SINK_LEVEL must not differ between ranks
+                if comm is not None:
+                    zstd_level = int(parallel.broadcast_str(comm, str(int(os.environ.get("DYN_SINK_LEVEL", zstd_level)))))
+                    os.environ.pop("DYN_SINK_LEVEL", None)
                 local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
                 threads = host_threads or max(2, min(16, available_cpus() // local_world - (4 if local_world == 1 else 2)))
                 pipe = sink = _NativePipeline(aligner, part, raw=not host_preprocess, depth=depth, threads=threads,
@@ -735,7 +751,7 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                             except Exception as error:  # noqa: BLE001  (segment.py:178-187)
                                 sink.put(f"error: worker, {error}\tN: {int(jb.bases[i])}\tRid: {job[6]}\tSid: {job[7]}")
                                 continue
-                            pending.append((signal, read, job, cal))
+                            pending.append((signal, read, job, cal, int(jb.bases[i])))
                         pipe.submit(pending)
                 else:
                     pending = []
@@ -759,6 +775,7 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 pipe = None
                 if comm is not None:
                     _gather_parts(comm, parallel, outfile, part, part_err)
+                parallel.remove_scratch()
                 print("Done with segmentation.", file=sys.stderr, flush=True)
                 return
             pipe = _Pipeline(aligner, sink, raw=not host_preprocess, depth=depth)

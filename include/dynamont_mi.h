@@ -337,6 +337,14 @@ int dyn_csv_sink_open_part(const char* csv_zst_path, const char* errors_path, in
 int dyn_csv_sink_submit(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
                         const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
                         const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths);
+/* The same with stored_bases[i] = the bases of read i's basecall AS STORED (before the RNA reversal and polyA pad), or
+ * NULL: the N of a read that fails like the reference's WORKER does -- its signal cannot be read, DYN_READ_BAD_SIGNAL,
+ * "error: worker, <message>\tN: <len(read)>\tRid: ...\tSid: ..." (segment.py:178-187) -- where the aligner's own failures
+ * report the read in aligner orientation, pad included (segment.py:172-176). Additive: dyn_csv_sink_submit = NULL. */
+int dyn_csv_sink_submit_bases(dyn_csv_sink* s, dyn_aligner* a, dyn_batch* ticket, const dyn_align_out* res, uint64_t n_reads,
+                              const char* seqs, const uint64_t* seq_offsets, const char* const* readids,
+                              const char* const* signalids, const int64_t* sig_offsets, const uint64_t* signal_lengths,
+                              const uint32_t* stored_bases);
 /* one line for `.errors` from the caller (reads that failed before they reached the aligner, segment.py:178-187) */
 int dyn_csv_sink_error_line(dyn_csv_sink* s, const char* line);
 /* 1 once the sink has failed (a batch error, the compressor, the output file): later submits return DYN_ERR_RUNTIME, and
@@ -425,7 +433,10 @@ int dyn_batch_create_raw(dyn_aligner* a, uint64_t n_reads, const void* raw, int 
 /* Device-resident preprocessed signals of a batch copied back to the host (count doubles). */
 int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count);
 void dyn_batch_destroy(dyn_batch* b);
-/* Run the kernels (stream-ordered, returns after the stream is idle). */
+/* Run the kernels (stream-ordered, returns after the stream is idle). Batches made by dyn_batch_create[_raw] only: a
+ * ticket of the asynchronous API is a one-shot submission (it may have shared its launch, and with it every device
+ * buffer, with other tickets) and gets DYN_ERR_INVALID_ARGUMENT here. dyn_batch_fetch, dyn_batch_signals,
+ * dyn_batch_device_results and dyn_batch_timing serve a completed ticket whether or not its launch was shared. */
 int dyn_batch_align(dyn_batch* b, int calc_probabilities);
 int dyn_batch_train(dyn_batch* b);
 /* Copy results of the last dyn_batch_align to the host. */
