@@ -351,6 +351,13 @@ def main():
             # its share of it (dyn_timing.launch_share), so sums over tickets count every launch once
             tm = t.timing()
             share = tm["launch_share"]
+            if tm["launches"] == 0 and tm["reads_ok"]:
+                # a ticket of the RESIDENT read queue: no launch of its own -- ms_* are its reads' wave time / waves, which add up
+                # over tickets; the session kernels' own durations come from al.session_stats() around the timed region
+                share = 1.0
+                launches["resident_tickets"] += 1
+            else:
+                launches["classic_ms_dp"] += tm["ms_dp"] * share
             for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy",
                         "ms_backward_strict", "ms_forward_strict"):
                 kern[key] += tm[key] * share
@@ -386,10 +393,13 @@ def main():
 
     run(0, args.warmup, False)
     sync()
+    sess0 = al.session_stats()  # (closes the warm-up's session: the timed region starts with an idle pipeline and no resident wave)
     t0 = time.perf_counter()
     last = run(args.warmup, args.steps, True)
     sync()
     elapsed = time.perf_counter() - t0
+    sess1 = al.session_stats()
+    sess = {k_: sess1[k_] - sess0[k_] for k_ in sess1 if k_ != "wave_occupancy"}
 
     n_samples = sum(samples_of[s % n_batches] for s in range(args.warmup, args.warmup + args.steps))
     n_reads_done = sum(batches[s % n_batches][4] for s in range(args.warmup, args.warmup + args.steps))
@@ -427,6 +437,7 @@ def main():
         p_steps = min(6, args.steps)
         run(args.warmup + args.steps, 1, False)
         sync()
+        sess1 = al.session_stats()  # baseline of the plain leg (its warm-up step's session is closed and counted here)
         tp = time.perf_counter()
         run(args.warmup + args.steps + 1, p_steps, True)
         sync()
@@ -437,8 +448,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
             p_el = float(t[0].item())
             p_samples *= n_gpus
-        p_launch = max(1e-9, launches["launches"] - keep[1]["launches"])
-        p_cells, p_ms = launches["cells"] - keep[1]["cells"], kern["ms_dp"] - keep[0]["ms_dp"]
+        p_sess = al.session_stats()
+        p_launch = max(1e-9, launches["launches"] - keep[1]["launches"] + (p_sess["sessions"] - sess1["sessions"]))
+        p_cells = launches["cells"] - keep[1]["cells"]
+        p_ms = launches["classic_ms_dp"] - keep[1]["classic_ms_dp"] + (p_sess["ms"] - sess1["ms"])
         plain = {"strict_mode": "off", "steps": p_steps, "value": round(p_samples / p_el / 1e6, 3), "unit": "Msamp/s",
                  "ms_per_step": round(p_el * 1e3 / p_steps, 3),
                  "avg_launch_ms": round(p_ms / p_launch, 3), "batches_per_launch": round(p_steps / p_launch, 3),
@@ -456,8 +469,11 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = total_samples / elapsed / 1e6
         cells_total = launches["cells"]
-        n_launch = max(1e-9, launches["launches"])
-        ms_dp = kern["ms_dp"] / n_launch             # average duration of the dominant kernel (HIP events on its stream)
+        # launches of the dominant kernel in the timed region: one per (merged) batch -- or, with the resident read queue, one
+        # per SESSION: the waves stay on the chip across batches. Duration: HIP events on the kernel's own stream.
+        n_launch = max(1e-9, launches["launches"] + sess["sessions"])
+        kernel_ms_total = launches["classic_ms_dp"] + sess["ms"]
+        ms_dp = kernel_ms_total / n_launch
         cells_per_launch = cells_total / n_launch
         inplace = bool(launches["lp_inplace"])
         traffic = load_traffic() or {}
@@ -465,7 +481,8 @@ def main():
             kname = "k_read_queue<JOB_TRAIN> (per read: backward sweep, forward sweep + Baum-Welch statistics)"
             bpc_f, tkey = KTRAIN_BYTES_PER_CELL, "train"
         else:
-            kname = "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else "")
+            kname = ("k_session (resident waves; per read: backward, forward + posterior + posterior-Viterbi, traceback)" if sess["sessions"] and not launches["launches"]
+                     else "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else ""))
             bpc_f, tkey = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "align"
         bpc = KBWD_BYTES_PER_CELL + bpc_f
         # PMC traffic is only quoted for the workload (and layout) it was measured on
@@ -487,7 +504,7 @@ def main():
             "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
             "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": round(n_launch, 3),
             # totals of the timed region (what a rocprofv3 kernel trace of the same tickets adds up to: launches vary in size)
-            "cells_total": int(cells_total), "kernel_ms_total": round(kern["ms_dp"], 3),
+            "cells_total": int(cells_total), "kernel_ms_total": round(kernel_ms_total, 3),
             "avg_launch_ms": round(ms_dp, 3),
             # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
             "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
@@ -498,7 +515,12 @@ def main():
                                           "frac": round(cells_per_launch * KBWD_BYTES_PER_CELL / (ms_dp * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
                        "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(ms_dp * share("ms_forward"), 3),
                                          "frac": round(cells_per_launch * bpc_f / (ms_dp * share("ms_forward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_forward") else None}},
-            "wave_occupancy": round(kern["wave_occupancy"] / n_launch, 4),
+            # classic launches: sum of wave lifetimes / (waves x longest lifetime), averaged over launches; resident queue: busy /
+            # lifetime wave-cycles of the sessions (a wave is busy from claiming a read to releasing its results)
+            "wave_occupancy": round((kern["wave_occupancy"] + (sess["wave_cycles_busy"] / sess["wave_cycles_life"] * sess["sessions"] if sess["wave_cycles_life"] else 0.0)) / n_launch, 4),
+            "resident_queue": ({"sessions": sess["sessions"], "tickets": sess["tickets"], "reads": sess["reads"], "ms": round(sess["ms"], 3),
+                                "wave_cycles_busy": sess["wave_cycles_busy"], "wave_cycles_idle": sess["wave_cycles_idle"],
+                                "wave_cycles_life": sess["wave_cycles_life"], "aborted": sess["aborted"]} if sess["sessions"] else None),
             # tickets per launch: batches that were waiting while the GPU was busy share one launch (one queue balances
             # what one read per wave cannot)
             "batches_per_launch": round(steps / n_launch, 3),

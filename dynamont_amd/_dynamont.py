@@ -483,6 +483,17 @@ class Aligner:
         if rc != N.DYN_OK:
             raise ValueError(self.last_error() or "strict mode must be 0 (off), 1 (ties) or 2 (all)")
 
+    def session_stats(self) -> dict:
+        """dyn_aligner_session_stats: totals over the closed sessions of the resident read queue (closes an open one and
+        waits for its waves first). ``wave_occupancy`` = busy / lifetime wave-cycles."""
+        t = N.DynSessionStats()
+        rc = self._L.dyn_aligner_session_stats(self._h, C.byref(t))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+        d = {k: getattr(t, k) for k, _ in N.DynSessionStats._fields_}
+        d["wave_occupancy"] = d["wave_cycles_busy"] / d["wave_cycles_life"] if d["wave_cycles_life"] else 0.0
+        return d
+
     def set_train_zcheck(self, on: bool) -> None:
         """dyn_aligner_set_train_zcheck: also refuse the reads the reference's |Zf - Zb| rule refuses (one more Z-only
         forward sweep per read)."""

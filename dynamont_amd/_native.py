@@ -70,6 +70,12 @@ class DynTiming(C.Structure):
                 ("cert_rows", C.c_uint64), ("launch_share", C.c_double)]
 
 
+class DynSessionStats(C.Structure):
+    _fields_ = [("sessions", C.c_uint64), ("tickets", C.c_uint64), ("reads", C.c_uint64), ("cells", C.c_uint64), ("ms", C.c_double),
+                ("wave_cycles_busy", C.c_uint64), ("wave_cycles_idle", C.c_uint64), ("wave_cycles_life", C.c_uint64),
+                ("waves", C.c_uint64), ("aborted", C.c_uint64)]
+
+
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "dyn_pore_from_string": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_uint64]),
@@ -81,6 +87,7 @@ SIGNATURES = {
     "dyn_format_model": (C.c_uint64, [C.c_char_p, C.c_int, c_double_p, c_double_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
+    "dyn_aligner_session_stats": (C.c_int, [C.c_void_p, C.POINTER(DynSessionStats)]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
     "dyn_aligner_set_train_zcheck": (C.c_int, [C.c_void_p, C.c_int]),

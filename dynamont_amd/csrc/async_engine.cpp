@@ -234,16 +234,21 @@ void Pipeline::front_loop() {
     std::vector<dyn_batch*> take;
     {
       std::unique_lock<std::mutex> lk(m);
-      cv_front.wait(lk, [&] { return (stop || !q_front.empty()) && (launches_pending < 2 || (stop && q_front.empty())); });
+      // A ticket for the resident read queue (session_candidate) is neither held back nor merged: it is published into the
+      // running session as soon as its inputs are staged -- the waves take its reads when they get there.
+      cv_front.wait(lk, [&] {
+        return (stop || !q_front.empty()) && (launches_pending < 2 || (stop && q_front.empty()) || (!q_front.empty() && session_candidate(q_front.front())));
+      });
       if (q_front.empty()) return;  // stop requested and nothing left
+      const bool resident = session_candidate(q_front.front());
       const size_t max_tickets = std::min<size_t>(MERGE_MAX_TICKETS, std::max<size_t>(2, (size_t)(peak_in_flight / 4)));
       // the linger ends as soon as nothing more can join this launch, or the GPU has run dry (the back thread's notify)
-      if (merging && launches_pending >= 1 && mergeable(q_front.front()) && q_front.size() < max_tickets)
+      if (merging && !resident && launches_pending >= 1 && mergeable(q_front.front()) && q_front.size() < max_tickets)
         cv_front.wait_for(lk, std::chrono::milliseconds(2), [&] { return stop || launches_pending == 0 || q_front.size() >= max_tickets; });
       take.push_back(q_front.front());
       q_front.pop_front();
       uint64_t reads = take[0]->n;
-      while (merging && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < max_tickets &&
+      while (merging && !resident && launches_pending >= 1 && mergeable(take[0]) && !q_front.empty() && take.size() < max_tickets &&
              mergeable(q_front.front()) && same_kind(take[0], q_front.front()) && reads + q_front.front()->n <= merge_max_reads(a)) {
         reads += q_front.front()->n;
         take.push_back(q_front.front());
@@ -287,6 +292,11 @@ void Pipeline::back_loop() {
     }
     int rc = w.rc;
     if (rc == DYN_OK) rc = back_stage(w.b, w.grp);
+    if (rc != DYN_OK && w.b->in_session && !a->host_only) {  // a session that lost a ticket takes no more of them
+      std::lock_guard<std::mutex> lk(a->mu);
+      (void)hipSetDevice(a->device);
+      (void)session_close(a);
+    }
     {
       std::lock_guard<std::mutex> lk(m);
       if (w.grp) {
@@ -306,7 +316,25 @@ void Pipeline::back_loop() {
     }
     cv_done.notify_all();
     cv_front.notify_all();  // the gate on launches_pending
+    close_idle_session();
   }
+}
+
+// Nothing left in the pipeline: the resident waves are told to leave (they would only poll). A ticket submitted a moment
+// later opens the next session behind this one.
+void Pipeline::close_idle_session() {
+  if (a->host_only || !a->sess_open_hint.load()) return;
+  {
+    std::lock_guard<std::mutex> lk(m);
+    if (in_flight != 0) return;
+  }
+  std::lock_guard<std::mutex> lk(a->mu);
+  {
+    std::lock_guard<std::mutex> lk2(m);
+    if (in_flight != 0) return;  // (a ticket that arrives from here on finds the session closed and opens the next one)
+  }
+  (void)hipSetDevice(a->device);
+  (void)session_close(a);
 }
 
 // Host prepare, H2D and every kernel launch of one batch; returns without waiting for the GPU.
@@ -436,19 +464,38 @@ int Pipeline::front_stage(dyn_batch* b) {
     P_TRY(b, hipMemcpyAsync(b->d_kmers.p, b->h_kmers.p, b->total_cols * 4, hipMemcpyHostToDevice, a->s_in));
   P_TRY(b, hipEventRecord(b->ev_in, a->s_in));
   const double t4 = now_ms();
-  P_TRY(b, hipStreamWaitEvent(a->stream, b->ev_in, 0));
+  // The resident read queue (engine.hpp: Session)? Then the ticket's small kernels run on the copy-in stream, behind its
+  // copies, and its record is published behind them; otherwise everything goes to the compute stream as one launch -- for
+  // which the lattice pool must be free: an open session is closed and waited for first.
+  bool resident = false;
+  rc = session_plan(b, &resident);
+  if (rc == DYN_OK && !resident) rc = session_quiesce(a);
+  if (rc != DYN_OK) {
+    b->error = a->last_error;
+    return rc;
+  }
+  hipStream_t s_pre = resident ? a->s_in : a->stream;
+  if (!resident) P_TRY(b, hipStreamWaitEvent(a->stream, b->ev_in, 0));
   if (total_sig && b->has_raw) {
     const RawSource& rs = b->raw_src;
     const uint64_t* d_offs = b->d_meta.as<uint64_t>();
     const double* d_shift = reinterpret_cast<const double*>(d_offs + n + 1);
     const float* d_cal = reinterpret_cast<const float*>(d_shift + 2 * n);
     dynk::launch_preprocess(reinterpret_cast<const char*>(d_cal + 2 * n), rs.dtype, rs.compute_f32, d_offs, d_shift, d_shift + n,
-                            d_cal, d_cal + n, b->d_norm.p, b->d_sig.as<double>(), (int)n, raw_max_len, rs.window, rs.n_sigmas, a->stream);
+                            d_cal, d_cal + n, b->d_norm.p, b->d_sig.as<double>(), (int)n, raw_max_len, rs.window, rs.n_sigmas, s_pre);
     P_TRY(b, hipGetLastError());
   }
   if (b->total_cols) {
-    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, (uint32_t)a->model.num_kmers, a->stream);
+    dynk::launch_prep_params(b->d_kmers.as<int32_t>(), a->d_model.as<Emis>(), b->d_par.as<Emis>(), b->total_cols, (uint32_t)a->model.num_kmers, s_pre);
     P_TRY(b, hipGetLastError());
+  }
+  if (resident) {
+    rc = session_publish(b);
+    if (rc != DYN_OK) b->error = a->last_error;
+    if (g_trace)
+      std::fprintf(stderr, "[dyn] front %p: start %.2f prepare %.2f lock %.2f alloc %.2f h2d %.2f publish %.2f ms (resident)\n", (void*)b, t0, t1 - t0,
+                   t2 - t1, t3 - t2, t4 - t3, now_ms() - t4);
+    return rc;  // the copies out are enqueued by the back thread, once the ticket's completion word has been seen
   }
   rc = enqueue_job(b, b->job);  // records ev_done behind the batch's last kernel
   if (rc != DYN_OK) {
@@ -483,12 +530,57 @@ int Pipeline::front_stage(dyn_batch* b) {
   return DYN_OK;
 }
 
+// A ticket of the resident read queue is complete when the wave that finished its last read has raised the ticket's word
+// in pinned host memory. Polled with short sleeps; every few milliseconds the ticket's own counter and the session's abort
+// word are copied out as a second opinion (a word that never arrives must not hang the pipeline), and the wait is bounded.
+int Pipeline::wait_resident(dyn_batch* b) {
+  const double t0 = now_ms();
+  const double limit_ms = 1e3 * (std::getenv("DYN_SESSION_WAIT_S") ? std::atof(std::getenv("DYN_SESSION_WAIT_S")) : 300.0);
+  uint32_t* h = b->h_stats.as<uint32_t>();  // pinned; the statistics copy overwrites it afterwards
+  for (uint64_t spin = 0;; ++spin) {
+    if (*b->sess_flag == b->sess_reads) return DYN_OK;
+    if ((spin & 63) == 63) {
+      P_TRY(b, hipMemcpyAsync(h, b->d_tctl.p, 4, hipMemcpyDeviceToHost, a->s_out));
+      P_TRY(b, hipMemcpyAsync(h + 1, a->sess_ctl[b->sess_blk].as<uint32_t>() + dynk::S_ABORT, 4, hipMemcpyDeviceToHost, a->s_out));
+      P_TRY(b, hipStreamSynchronize(a->s_out));
+      if (h[0] == b->sess_reads) return DYN_OK;  // the counter is there; the word is on its way
+      if (h[1] != 0) {
+        b->error = "the resident read queue aborted: its waves found no work for DYN_SESSION_IDLE_S seconds while this ticket was pending";
+        return DYN_ERR_DEVICE;
+      }
+      if (now_ms() - t0 > limit_ms) {
+        b->error = "the resident read queue did not finish a ticket within DYN_SESSION_WAIT_S seconds";
+        return DYN_ERR_DEVICE;
+      }
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 // Wait for the batch's last D2H, then turn the device records into the caller's arrays.
 int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
   const double t0 = now_ms();
+  int rc = DYN_OK;
+  if (b->in_session) {
+    rc = wait_resident(b);
+    if (rc != DYN_OK) return rc;
+    // the per-segment kernels and the copies out, beside the resident waves
+    rc = session_finish_enqueue(b, a->s_out);
+    if (rc != DYN_OK) {
+      b->error = a->last_error;
+      return rc;
+    }
+    const uint64_t n = b->n;
+    if (n) P_TRY(b, hipMemcpyAsync(b->h_state.p, b->d_state.p, n * sizeof(ReadState), hipMemcpyDeviceToHost, a->s_out));
+    if (b->capacity) {
+      P_TRY(b, b->h_rows.ensure(b->capacity * sizeof(SegRow)));
+      P_TRY(b, hipMemcpyAsync(b->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost, a->s_out));
+    }
+    P_TRY(b, hipEventRecord(b->ev_out, a->s_out));
+  }
   P_TRY(b, hipEventSynchronize(b->ev_out));
   const double t1 = now_ms();
-  int rc = collect_timing(b);
+  rc = b->in_session ? session_collect_timing(b) : collect_timing(b);
   if (rc != DYN_OK) {
     b->error = a->last_error;
     return rc;

@@ -132,10 +132,14 @@ struct dyn_bam_reader {
       b.crc = le32(map + pos + bsize - 8);
       b.isize = le32(map + pos + bsize - 4);
       b.dst = run.total;
-      if (b.isize > (1u << 16)) {  // SAM specification 4.1: a BGZF block holds at most 64 KiB of data
-        run.error = path + ": BGZF block larger than 64 KiB";
+      // SAM specification 4.1 caps a block's data at 64 KiB; a gzip member that inflates to more is still read, within what
+      // deflate can make of a member of at most 64 KiB (1 032 : 1) -- and a window never asks for more than 256 MiB at once,
+      // so that a damaged ISIZE field cannot demand gigabytes (128 blocks x 1 GiB before round 5)
+      if (b.isize > (68u << 20)) {
+        run.error = path + ": implausible BGZF block size";
         break;
       }
+      if (!run.blocks.empty() && run.total + b.isize > ((size_t)256 << 20)) break;  // the next window starts with this block
       run.total += b.isize;
       run.blocks.push_back(b);
       pos += bsize;

@@ -513,8 +513,9 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   auto fail = [&](hipError_t e, const char* what) {
     copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
                               " (the MI355X build has no CPU compute path)");
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_session})
       if (s) (void)hipStreamDestroy(s);
+    if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->d_model.release();
     a->d_sptab.release();
     delete a;
@@ -533,6 +534,25 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  // The resident read queue needs a hardware queue of its own: plain streams share four per process, and a kernel that stays
+  // resident blocks whatever is queued behind it in the same one -- the copies and small kernels it is waiting for included
+  // (tools/ubench/resident_probe.hip). A CU-masked stream (all CUs enabled) always gets its own. No such stream, or
+  // DYN_NO_SESSION=1: the handle runs one launch per batch, as before round 5.
+  if (!std::getenv("DYN_NO_SESSION")) {
+    std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0xffffffffu);
+    if (a->n_cus % 32) mask.back() = (1u << (a->n_cus % 32)) - 1u;
+    if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      a->s_session = nullptr;
+    }
+    if (a->s_session && hipHostMalloc(reinterpret_cast<void**>(&a->sess_flags), SESSION_FLAGS * 4, hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(a->s_session);
+      a->s_session = nullptr;
+      a->sess_flags = nullptr;
+    }
+    if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.05, std::atof(f));
+  }
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
   if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
                      hipMemcpyHostToDevice)) != hipSuccess)
@@ -565,8 +585,17 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->free_list.release();
     a->ctl.release();
     a->h_rows.release();
+    a->sess_anchor.release();
+    for (int k = 0; k < 2; ++k) {
+      a->sess_ctl[k].release();
+      a->sess_ring[k].release();
+      for (hipEvent_t ev : {a->sess.ev_begin[k], a->sess.ev_end[k]})
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    a->sess_hctl.release();
+    if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->cache.park(a->device);
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_session})
       if (s) (void)hipStreamDestroy(s);
   }
   delete a;
@@ -610,6 +639,7 @@ int dyn_aligner_set_model(dyn_aligner* a, const double* in2n) {
   if (a->strict_mode != 0 && !model_allows_strict(m)) a->strict_mode = 0;
   if (!a->host_only) {
     HIP_TRY(a, hipSetDevice(a->device));
+    if (int rc = session_quiesce(a)) return rc;  // (a device-wide wait would never return while resident waves are waiting for tickets)
     HIP_TRY(a, hipDeviceSynchronize());  // nothing that reads the old table may still be running
     HIP_TRY(a, hipMemcpy(a->d_model.p, m.table.data(), sizeof(dynmath::Emis) * m.table.size(), hipMemcpyHostToDevice));
   }
@@ -627,6 +657,15 @@ int dyn_aligner_set_strict(dyn_aligner* a, int mode) {
   if (mode != 0 && !model_allows_strict(a->model)) {
     a->last_error = "strict mode: a model stdev with an all-ones significand has no division-free exact quotient";
     return DYN_ERR_INVALID_ARGUMENT;
+  }
+  if (mode != a->strict_mode && !a->host_only) {
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (a->sess.open) {  // the resident kernel's variant was chosen for the mode it was opened in
+      (void)hipSetDevice(a->device);
+      if (int rc = session_quiesce(a)) return rc;
+    }
+    a->strict_mode = mode;
+    return DYN_OK;
   }
   a->strict_mode = mode;
   return DYN_OK;
@@ -882,7 +921,7 @@ void dyn_batch_destroy(dyn_batch* b) {
   if (b->a && !b->a->host_only) (void)hipSetDevice(b->a->device);
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_poolwork, &b->d_pooltemp, &b->d_pp,
-                    &b->d_pathn, &b->d_norm, &b->d_meta})
+                    &b->d_pathn, &b->d_norm, &b->d_meta, &b->d_tctl})
     d->release();
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->release();
   for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
@@ -1081,6 +1120,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     a->last_error = "Training is not implemented for this aligner";
     return DYN_ERR_RUNTIME;
   }
+  // one launch per batch on the compute stream: the lattice pool must not be in the hands of resident waves
+  if (int rc = session_quiesce(a)) return rc;
   // Strict reads (align(calc=true) only; dyn_aligner_set_strict) take the sweeps whose every sum is certified to be the
   // reference's bit for bit (dp_math_strict.hpp). Mode 2: every read, every row. Mode 1 (the default): the reads that carry
   // a structural tie (tie_rows above) -- their backward sweep in full and their forward sweep up to the row in which the
@@ -1408,6 +1449,395 @@ int collect_timing(dyn_batch* b) {
   }
   return DYN_OK;
 }
+
+// ==== the resident read queue (engine.hpp: Session; nt_kernels.hpp: k_session) ============================================
+namespace {
+
+constexpr uint64_t SESSION_ROW_BYTES = (uint64_t)dynk::P * 12 + dynk::CPL * 8;  // separate LPE layout
+
+uint32_t session_pages_of(uint64_t S, int log_r) { return (uint32_t)((S + 2 + (1ull << log_r) - 1) >> log_r); }
+
+struct SessionNeed {
+  uint64_t n_ok = 0;
+  uint64_t max_S = 0;
+};
+SessionNeed session_need(const dyn_batch* b) {
+  SessionNeed n;
+  for (uint64_t i = 0; i < b->n; ++i)
+    if (b->reads[i].status == DYN_READ_OK) {
+      ++n.n_ok;
+      n.max_S = std::max(n.max_S, b->reads[i].S);
+    }
+  return n;
+}
+
+// statistics of the session that ran on control block `blk` (its kernel has finished: ev_end has been waited for)
+int session_collect(dyn_aligner* a, int blk) {
+  Session& ss = a->sess;
+  if (!ss.pending[blk]) return DYN_OK;
+  float ms = 0.f;
+  HIP_TRY(a, hipEventElapsedTime(&ms, ss.ev_begin[blk], ss.ev_end[blk]));
+  HIP_TRY(a, a->sess_hctl.ensure(dynk::SESSION_CTL_WORDS * 4));
+  HIP_TRY(a, hipMemcpy(a->sess_hctl.p, a->sess_ctl[blk].p, dynk::SESSION_CTL_WORDS * 4, hipMemcpyDeviceToHost));
+  const uint32_t* cw = a->sess_hctl.as<uint32_t>();
+  const uint64_t* st = reinterpret_cast<const uint64_t*>(cw + dynk::SESSION_STATS);
+  dyn_session_stats& t = a->sess_total;
+  t.sessions += 1;
+  t.tickets += ss.pend_tickets[blk];
+  t.reads += ss.pend_reads[blk];
+  t.cells += ss.pend_cells[blk];
+  t.ms += ms;
+  t.wave_cycles_busy += st[0];
+  t.wave_cycles_idle += st[1];
+  t.wave_cycles_life += st[2];
+  t.waves += ss.pend_waves[blk];
+  if (cw[dynk::S_ABORT]) t.aborted += 1;
+  ss.pending[blk] = false;
+  return DYN_OK;
+}
+
+int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r, uint32_t arena_pages, uint32_t n_pages_total) {
+  Session& ss = a->sess;
+  const int blk = ss.blk ^ 1;
+  // the session before the last one used this block: it has long ended, but its statistics may still be waiting
+  if (ss.pending[blk]) {
+    HIP_TRY(a, hipEventSynchronize(ss.ev_end[blk]));
+    if (int rc = session_collect(a, blk)) return rc;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (!ss.ev_begin[k]) HIP_TRY(a, hipEventCreate(&ss.ev_begin[k]));
+    if (!ss.ev_end[k]) HIP_TRY(a, hipEventCreate(&ss.ev_end[k]));
+  }
+  HIP_TRY(a, a->sess_anchor.ensure(256, 1.0));
+  HIP_TRY(a, a->sess_ctl[blk].ensure(dynk::SESSION_CTL_WORDS * 4, 1.0));
+  HIP_TRY(a, a->sess_ring[blk].ensure((size_t)SESSION_RING * sizeof(dynk::SessionTicket), 1.0));
+  // The lattice pool: an arena for every wave. Growing releases the old buffers -- whatever used them must have left: the
+  // classic launches of the compute stream and the previous session (its kernel precedes this one on the session stream
+  // anyway; the host-side wait is for the hipFree).
+  const uint64_t page_rows = 1ull << log_r;
+  const uint64_t ws_pp = page_rows * dynk::P * 8, lpe_pp = page_rows * dynk::P * 4, bits_pp = page_rows * dynk::CPL * 8;
+  HIP_TRY(a, hipStreamSynchronize(a->stream));
+  if (a->ws.bytes < n_pages_total * ws_pp || a->lpe.bytes < n_pages_total * lpe_pp || a->bits.bytes < n_pages_total * bits_pp) {
+    if (ss.pending[ss.blk]) HIP_TRY(a, hipEventSynchronize(ss.ev_end[ss.blk]));
+    HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, n_pages_total * ws_pp, 1.0));
+    HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
+    HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, n_pages_total * bits_pp, 1.0));
+  }
+  // control words cleared IN the session stream, and waited for: the first publish (copy-in stream) must not be wiped
+  HIP_TRY(a, hipMemsetAsync(a->sess_ctl[blk].p, 0, dynk::SESSION_CTL_WORDS * 4, a->s_session));
+  HIP_TRY(a, hipStreamSynchronize(a->s_session));  // (also: the previous session's kernel has left -- a->s_session is in order)
+  if (ss.pending[ss.blk]) {
+    if (int rc = session_collect(a, ss.blk)) return rc;
+  }
+  dynk::SessionArgs sa{};
+  sa.ring = a->sess_ring[blk].as<dynk::SessionTicket>();
+  sa.ring_size = SESSION_RING;
+  sa.arena_pages = arena_pages;
+  sa.ctl = a->sess_ctl[blk].as<uint32_t>();
+  sa.pool.ws = a->ws.as<double>();
+  sa.pool.lpe = a->lpe.as<float>();
+  sa.pool.bits = a->bits.as<uint64_t>();
+  sa.pool.free_list = nullptr;
+  sa.pool.ctl = nullptr;
+  sa.pool.log_rows = log_r;
+  sa.pool.n_pages = n_pages_total;
+  sa.m1 = a->model.log_m1;
+  sa.e2 = a->model.log_e2;
+  sa.idle_limit_ticks = (uint64_t)(a->sess_idle_s * 1e8);
+  HIP_TRY(a, hipEventRecord(ss.ev_begin[blk], a->s_session));
+  dynk::launch_session(mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), a->n_cus, a->s_session);
+  HIP_TRY(a, hipGetLastError());
+  HIP_TRY(a, hipEventRecord(ss.ev_end[blk], a->s_session));
+  ss.open = true;
+  a->sess_open_hint.store(true);
+  ss.mixed = mixed;
+  ss.blk = blk;
+  ss.published = 0;
+  ss.next_base = 0;
+  ss.log_r = log_r;
+  ss.arena_pages = arena_pages;
+  ss.n_waves = (uint32_t)a->n_cus * dynk::WAVES_PER_CU;
+  ss.cells = ss.reads = ss.tickets = 0;
+  (void)need;
+  return DYN_OK;
+}
+
+}  // namespace
+
+bool session_candidate(const dyn_batch* b) {
+  const dyn_aligner* a = b->a;
+  return a->s_session && !a->host_only && !a->ntk && b->job == DynJob::AlignFull && (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
+}
+
+int session_close(dyn_aligner* a) {
+  Session& ss = a->sess;
+  if (!ss.open) return DYN_OK;
+  dynk::launch_session_close(a->sess_ctl[ss.blk].as<uint32_t>(), a->s_in);  // behind every publish: same stream
+  HIP_TRY(a, hipGetLastError());
+  ss.open = false;
+  a->sess_open_hint.store(false);
+  ss.pending[ss.blk] = true;
+  ss.pend_cells[ss.blk] = ss.cells;
+  ss.pend_reads[ss.blk] = ss.reads;
+  ss.pend_tickets[ss.blk] = ss.tickets;
+  ss.pend_waves[ss.blk] = ss.n_waves;
+  return DYN_OK;
+}
+
+int session_quiesce(dyn_aligner* a) {
+  if (!a->s_session) return DYN_OK;
+  if (int rc = session_close(a)) return rc;
+  Session& ss = a->sess;
+  for (int k = 0; k < 2; ++k)
+    if (ss.pending[k]) {
+      HIP_TRY(a, hipEventSynchronize(ss.ev_end[k]));
+      if (int rc = session_collect(a, k)) return rc;
+    }
+  return DYN_OK;
+}
+
+// The arena geometry a ticket asks for: pages of 2^log_r rows such that its longest read (plus an eighth: later tickets
+// of the same kind should fit as well) stays within a wave's PT_MAX-entry page table.
+static void session_geometry(uint64_t max_S, int* log_r, uint32_t* arena_pages) {
+  const uint64_t cap_S = max_S + max_S / 8 + 64;
+  int lr = 8;
+  while (session_pages_of(cap_S, lr) > (uint32_t)dynk::PT_MAX) ++lr;
+  *log_r = lr;
+  *arena_pages = session_pages_of(cap_S, lr);
+}
+
+int session_plan(dyn_batch* b, bool* use) {
+  dyn_aligner* a = b->a;
+  *use = false;
+  if (!session_candidate(b)) return DYN_OK;
+  const SessionNeed need = session_need(b);
+  if (!need.n_ok) return DYN_OK;  // nothing to launch
+  Session& ss = a->sess;
+  const bool strict_reads = a->strict_mode != 0;
+  if (ss.open) {
+    const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
+                      (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull && (ss.mixed || !strict_reads);
+    if (fits) {
+      *use = true;
+      return DYN_OK;
+    }
+    if (int rc = session_close(a)) return rc;  // a new one is opened below if this ticket deserves it
+  }
+  if (need.n_ok < SESSION_MIN_READS) return DYN_OK;
+  // an arena for every wave, inside the memory budget?
+  int log_r = 8;
+  uint32_t arena = 0;
+  session_geometry(need.max_S, &log_r, &arena);
+  const uint64_t n_waves = (uint64_t)a->n_cus * dynk::WAVES_PER_CU;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
+  const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + parked_bytes(a->device);
+  uint64_t budget = (uint64_t)((double)(free_b + pool) * 0.90);
+  if (a->mem_budget && a->mem_budget < budget) budget = a->mem_budget;
+  const uint64_t want = n_waves * arena * ((1ull << log_r) * SESSION_ROW_BYTES);
+  if (want > budget || n_waves * arena > (0xfffffff0ull >> log_r)) return DYN_OK;  // page-starved: the planned classic launch
+  *use = true;
+  return DYN_OK;
+}
+
+int session_publish(dyn_batch* b) {
+  dyn_aligner* a = b->a;
+  const PoreModel& m = a->model;
+  Session& ss = a->sess;
+  // strict reads and the queue order: as enqueue_job
+  const int32_t* km = b->kmers();
+  std::vector<uint32_t> strict_rows(b->n, 0), order;
+  uint64_t n_strict = 0, max_S = 0;
+  for (uint64_t i = 0; i < b->n; ++i) {
+    const HostRead& r = b->reads[i];
+    if (r.status != DYN_READ_OK) continue;
+    if (a->strict_mode == 2) strict_rows[i] = 0xffffffffu;
+    else if (a->strict_mode == 1) strict_rows[i] = tie_rows(a->model, km + r.flat_off, r.kc, r.S);
+    n_strict += strict_rows[i] != 0;
+    max_S = std::max(max_S, r.S);
+    order.push_back((uint32_t)i);
+  }
+  auto cost_rows = [&](uint32_t i) -> uint64_t {
+    const uint64_t T = b->reads[i].S + 1;
+    if (!strict_rows[i]) return T;
+    const uint64_t fr = std::min<uint64_t>(T, strict_rows[i]);
+    return (T * 100 + T * 12 + fr * 24) / 100;
+  };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost_rows(x) > cost_rows(y); });
+  const size_t n_ok = order.size();
+
+  if (!ss.open) {
+    int log_r = 8;
+    uint32_t arena = 0;
+    session_geometry(max_S, &log_r, &arena);
+    const uint64_t n_waves = (uint64_t)a->n_cus * dynk::WAVES_PER_CU;
+    SessionNeed need;
+    need.n_ok = n_ok;
+    need.max_S = max_S;
+    if (int rc = session_open(a, need, a->strict_mode != 0, log_r, arena, (uint32_t)(n_waves * arena))) return rc;
+  }
+
+  HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
+  HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));
+  HIP_TRY(a, b->d_medlo.ensure(std::max<uint64_t>(8, b->capacity * 8)));
+  ReadState* st = b->h_state.as<ReadState>();
+  for (uint64_t i = 0; i < b->n; ++i) {
+    st[i].Zb = 0.0;
+    st[i].Zf = 0.0;
+    st[i].status = b->reads[i].status;
+    st[i].n_segments = 0;
+  }
+  HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st, b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->s_in));
+  HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
+  ReadDesc* descs = b->h_descs.as<ReadDesc>();
+  dyn_timing tm{};
+  uint64_t rows_total = 0;
+  uint32_t max_N = 0;
+  for (size_t k = 0; k < n_ok; ++k) {
+    const uint32_t i = order[k];
+    const HostRead& r = b->reads[i];
+    ReadDesc d{};
+    d.T = (uint32_t)(r.S + 1);
+    d.N = (uint32_t)(r.kc + 1);
+    d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
+    d.read = i;
+    d.ratio = (double)d.N / (double)d.T;
+    d.sig_off = r.sig_off;
+    d.par_off = r.flat_off;
+    d.seg_off = r.seg_off;
+    d.path_off = rows_total;
+    d.n_pages = session_pages_of(r.S, ss.log_r);
+    d.first_page = dynk::NO_PAGE;  // the wave's own arena
+    d.flags = !strict_rows[i] ? 0u : strict_rows[i] == 0xffffffffu ? dynk::READ_STRICT : dynk::READ_STRICT_START;
+    d.strict_rows = strict_rows[i];
+    rows_total += d.T;
+    max_N = std::max(max_N, d.N);
+    descs[k] = d;
+    tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
+    tm.samples += r.S;
+  }
+  HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
+  HIP_TRY(a, b->d_pathn.ensure(std::max<uint64_t>(4, rows_total * 4)));
+  HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
+  HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, n_ok * sizeof(ReadDesc), hipMemcpyHostToDevice, a->s_in));
+  b->d_tctl.cache = &a->cache;
+  HIP_TRY(a, b->d_tctl.ensure(dynk::SESSION_TCTL_WORDS * 4));
+  HIP_TRY(a, hipMemsetAsync(b->d_tctl.p, 0, dynk::SESSION_TCTL_WORDS * 4, a->s_in));
+  HIP_TRY(a, b->h_stats.ensure(dynk::SESSION_TCTL_WORDS * 4));
+  std::memset(b->h_stats.p, 0, dynk::SESSION_TCTL_WORDS * 4);
+  volatile uint32_t* flag = a->sess_flags + (ss.flag_seq++ % SESSION_FLAGS);
+  *flag = 0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+
+  const char* in_base = static_cast<const char*>(a->d_model.p);
+  const char* out_base = static_cast<const char*>(a->sess_anchor.p);
+  auto off_in = [&](const void* p) { return (int64_t)(static_cast<const char*>(p) - in_base); };
+  auto off_out = [&](const volatile void* p) { return (int64_t)(static_cast<const char*>(const_cast<const void*>(p)) - out_base); };
+  dynk::SessionTicket tk{};
+  tk.descs_off = off_in(b->d_descs.p);
+  tk.sig_off = off_in(b->d_sig.p);
+  tk.par_off = off_in(b->d_par.p);
+  tk.st_off = off_out(b->d_state.p);
+  tk.pp_off = off_out(b->d_pp.p);
+  tk.pathn_off = off_out(b->d_pathn.p);
+  tk.segrow_off = off_out(b->d_segrow.p);
+  tk.medhi_off = off_out(b->d_medhi.p);
+  tk.medlo_off = off_out(b->d_medlo.p);
+  tk.tctl_off = off_out(b->d_tctl.p);
+  tk.flag_off = off_out(flag);
+  tk.n_reads = (uint32_t)n_ok;
+  tk.base = ss.next_base;
+  tk.z_fail_status = DYN_READ_Z_MISMATCH;
+  dynk::launch_session_publish(a->sess_ring[ss.blk].as<dynk::SessionTicket>(), a->sess_ctl[ss.blk].as<uint32_t>(), tk, ss.published, SESSION_RING,
+                               a->s_in);
+  HIP_TRY(a, hipGetLastError());
+  ss.published += 1;
+  ss.next_base += (uint32_t)n_ok;
+  ss.cells += tm.cells;
+  ss.reads += n_ok;
+  ss.tickets += 1;
+
+  while (b->events.size() < 3) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(a, hipEventCreate(&e));
+    b->events.push_back(e);
+  }
+  tm.reads_ok = n_ok;
+  tm.reads_strict = (uint32_t)n_strict;
+  tm.launch_share = 0.0;
+  tm.launches = 0;
+  tm.lp_inplace = 0;
+  tm.pool_pages = ss.arena_pages * ss.n_waves;
+  tm.page_rows = 1u << ss.log_r;
+  tm.n_static = 0;
+  tm.n_waves = ss.n_waves;
+  b->strict_flag.assign(b->n, 0);
+  for (uint64_t i = 0; i < b->n; ++i) b->strict_flag[i] = strict_rows[i] != 0;
+  b->timing = tm;
+  b->n_chunks = 1;
+  b->aligned = true;
+  b->trained = false;
+  b->last_calc = 1;
+  b->in_session = true;
+  b->sess_reads = (uint32_t)n_ok;
+  b->sess_waves = ss.n_waves;
+  b->sess_blk = ss.blk;
+  b->sess_flag = flag;
+  b->sess_max_N = max_N;
+  b->sess_rows_total = rows_total;
+  return DYN_OK;
+}
+
+// the ticket's reads are done (its completion word has been seen): per-segment kernels, statistics
+int session_finish_enqueue(dyn_batch* b, hipStream_t s) {
+  dyn_aligner* a = b->a;
+  hipEvent_t* ev = b->events.data();
+  HIP_TRY(a, hipEventRecord(ev[1], s));
+  dynk::TraceBuffers tb{b->d_pp.as<double>(), b->d_pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(), b->d_medhi.as<double>(),
+                        b->d_medlo.as<double>()};
+  dynk::launch_segments(b->d_descs.as<ReadDesc>(), (int)b->sess_reads, b->sess_rows_total, b->sess_max_N, b->d_state.as<ReadState>(), tb,
+                        b->d_rows.as<SegRow>(), a->model.k, s);
+  HIP_TRY(a, hipGetLastError());
+  HIP_TRY(a, hipEventRecord(ev[2], s));
+  HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, b->d_tctl.p, dynk::SESSION_TCTL_WORDS * 4, hipMemcpyDeviceToHost, s));
+  return DYN_OK;
+}
+
+int session_collect_timing(dyn_batch* b) {
+  dyn_aligner* a = b->a;
+  dyn_timing& tm = b->timing;
+  float ms12 = 0;
+  HIP_TRY(a, hipEventElapsedTime(&ms12, b->events[1], b->events[2]));
+  const uint64_t* st = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::SESSION_TSTATS);
+  const double per_ms = 1e5 * (double)std::max<uint32_t>(1, b->sess_waves);  // s_memtime: 100 MHz
+  tm.ms_backward = (double)st[0] / per_ms;
+  tm.ms_forward = (double)st[1] / per_ms;
+  tm.ms_dp = (double)(st[0] + st[1] + st[2]) / per_ms;
+  tm.ms_trace = (double)st[2] / per_ms + ms12;
+  tm.ms_total = tm.ms_dp + ms12;
+  tm.wave_wait_share = 0.0;
+  tm.wave_occupancy = 0.0;  // a session's, not a ticket's: dyn_aligner_session_stats
+  tm.ms_backward_strict = (double)st[6] / per_ms;
+  tm.ms_forward_strict = (double)st[7] / per_ms;
+  tm.cert_fallbacks = st[8];
+  tm.cert_rows = st[9];
+  return DYN_OK;
+}
+
+}  // namespace dyneng
+
+extern "C" int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out) {
+  if (!a || !out) return DYN_ERR_INVALID_ARGUMENT;
+  if (!a->host_only && a->s_session) {
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (int rc = need_device(a)) return rc;
+    if (int rc = session_quiesce(a)) return rc;
+  }
+  *out = a->sess_total;
+  return DYN_OK;
+}
+
+namespace dyneng {
 
 // array-of-rows -> the caller's columns; reads are independent, so contiguous ranges of reads go to
 // the helper threads (2 M segments per 1 024-read batch take ~10 ms on one core)

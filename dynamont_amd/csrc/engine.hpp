@@ -92,6 +92,33 @@ class HelperPool {
 
 struct Pipeline;
 
+// ---- the resident read queue of a handle (nt_kernels.hpp: k_session) -------------------------------------------------
+// A SESSION is one launch of resident waves on the handle's session stream (a CU-masked stream: it owns its hardware
+// queue, so the small kernels and copies that feed the waves can never queue up behind them -- tools/ubench/resident_probe).
+// The pipeline's front thread opens one when an align(calc=true) ticket arrives whose reads fit a static arena per wave,
+// publishes that ticket and every later one that fits, and the session is closed when the pipeline has run dry (or a
+// ticket of another kind must use the lattice pool). Two control blocks alternate, so that a new session can be set up
+// while the last waves of the previous one are leaving.
+constexpr uint32_t SESSION_RING = 1024;        // tickets per session (the ring is never reused within one)
+constexpr uint64_t SESSION_MIN_READS = 512;    // a session is OPENED only for a ticket of at least this many reads
+constexpr uint32_t SESSION_FLAGS = 4096;       // completion words in pinned host memory (a ring: far more than tickets in flight)
+struct Session {
+  bool open = false;
+  bool mixed = false;           // the kernel variant that carries the certified sweeps
+  int blk = 0;                  // control block / ticket ring in use
+  uint32_t published = 0;       // tickets of the open session
+  uint32_t next_base = 0;       // global read index of the next ticket's first read
+  int log_r = 8;
+  uint32_t arena_pages = 0;     // lattice pages per wave
+  uint32_t n_waves = 0;
+  uint64_t cells = 0, reads = 0, tickets = 0;   // of the open session
+  bool pending[2] = {false, false};             // a session ran on this block and its statistics have not been collected
+  uint64_t pend_cells[2] = {0, 0}, pend_reads[2] = {0, 0}, pend_tickets[2] = {0, 0};
+  uint32_t pend_waves[2] = {0, 0};
+  hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
+  uint64_t flag_seq = 0;        // next completion word
+};
+
 }  // namespace dyneng
 
 struct dyn_aligner {
@@ -119,6 +146,17 @@ struct dyn_aligner {
   // serialises GPU enqueue work on this handle between the caller's thread and the pipeline threads
   std::mutex mu;
   std::unique_ptr<dyneng::Pipeline> pipe;  // started by the first asynchronous submit
+  // the resident read queue (guarded by mu)
+  hipStream_t s_session = nullptr;   // CU-masked: a hardware queue of its own; nullptr = no sessions on this handle
+  dyneng::DevBuf sess_ctl[2], sess_ring[2];
+  dyneng::DevBuf sess_anchor;        // out_base of k_session: the address the ticket records' output offsets count from
+  std::atomic<bool> sess_open_hint{false};  // mirrors sess.open for readers that do not hold mu
+  uint32_t* sess_flags = nullptr;    // [SESSION_FLAGS] pinned, coherent
+  dyneng::PinnedBuf sess_hctl;       // D2H target of a control block
+  dyneng::Session sess;
+  dyn_session_stats sess_total{};    // closed and collected sessions
+  // the idle watchdog of the resident waves, seconds (DYN_SESSION_IDLE_S)
+  double sess_idle_s = 20.0;
 };
 
 struct HostRead {
@@ -202,6 +240,15 @@ struct dyn_batch {
   uint64_t g_read0 = 0, g_seg0 = 0;
   // merged batches (the group's own batch): no contiguous signal array -- one pointer per read (float64 samples)
   const double* const* in_sig_ptrs = nullptr;
+  // ---- a ticket of the resident read queue (Session) ----
+  bool in_session = false;
+  uint32_t sess_reads = 0;             // reads published (the value its completion word reaches)
+  uint32_t sess_waves = 0;
+  int sess_blk = 0;                    // the session's control block
+  volatile uint32_t* sess_flag = nullptr;
+  dyneng::DevBuf d_tctl;               // the ticket's control block (reads done, wave-cycle statistics)
+  uint32_t sess_max_N = 0;
+  uint64_t sess_rows_total = 0;
   const int32_t* kmers() const { return h_kmers.as<int32_t>(); }
 };
 
@@ -236,6 +283,22 @@ int host_prepare(dyn_batch* b, const dynhost::PoreModel& m, bool pinned, uint64_
 int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig);
 // enqueue every kernel of `job` on the handle's compute stream without synchronising the host
 int enqueue_job(dyn_batch* b, DynJob job);
+// ---- resident read queue (dynamont_mi.cpp); all under a->mu ----
+// could this ticket run in a session at all? (before host_prepare: kind and size only)
+bool session_candidate(const dyn_batch* b);
+// After host_prepare: will the ticket be published into a session (the open one, or one opened for it)? Closes an open
+// session that cannot take it. *use = false: the classic launch (the caller quiesces the session first).
+int session_plan(dyn_batch* b, bool* use);
+// descriptors, per-read state, control block -> copy-in stream; the ticket's record published behind them (opens the
+// session first if none is open). The ticket's inputs must already be enqueued on the copy-in stream.
+int session_publish(dyn_batch* b);
+// the per-segment kernels and the statistics copy of a COMPLETED session ticket, on `s`
+int session_finish_enqueue(dyn_batch* b, hipStream_t s);
+int session_collect_timing(dyn_batch* b);
+// no ticket will follow: the resident waves leave once what is published is done (returns at once)
+int session_close(dyn_aligner* a);
+// close, wait until the kernel has left, collect its statistics: the lattice pool is free for a classic launch afterwards
+int session_quiesce(dyn_aligner* a);
 // after the compute stream has passed the batch: read the event timings into b->timing
 int collect_timing(dyn_batch* b);
 // rows/state (host copies) -> the caller's columns; reads [read0, read0 + n) of b, whose segment rows start at seg0, land at
@@ -277,6 +340,8 @@ struct Pipeline {
   void back_loop();
   int front_stage(dyn_batch* b);
   int back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp);
+  int wait_resident(dyn_batch* b);
+  void close_idle_session();
   std::shared_ptr<BatchGroup> merge(const std::vector<dyn_batch*>& tickets);
 };
 

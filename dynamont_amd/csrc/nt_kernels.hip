@@ -1251,6 +1251,115 @@ __device__ __forceinline__ bool pages_take(const QueueArgs& q, const WaveCtx& w,
   return ok;
 }
 
+// ---- one read's whole pipeline (the body both read queues share) -----------------------------------------
+// What a read touches beside the lattice pool: the arrays of its batch (classic launch: the launch's; resident queue: its
+// ticket's) and the model's transition constants.
+struct ReadIO {
+  ReadState* st;
+  TraceBuffers tb;
+  TrainBuffers tr;
+  double m1, e2;
+  int z_fail_status;
+};
+
+// wave-cycles per phase, accumulated over the reads of a wave
+struct WaveStats {
+  uint64_t cyc_b = 0, cyc_f = 0, cyc_t = 0, cyc_w = 0, cyc_bs = 0, cyc_fs = 0, rows_cert = 0;
+  uint32_t n_fallback = 0;
+};
+
+// t1: s_memtime when the read's pages were in place. sig / par are `const __restrict__` kernel parameters (or pointers
+// derived from one): see k_read_queue.
+template <int JOB, bool MIXED>
+__device__ __forceinline__ void run_read(const ReadDesc& rd, const WaveCtx& w, const PagePool& pool, const ReadIO& io,
+                                         const double* __restrict__ sig, const Emis* __restrict__ par,
+                                         const SoftplusNode* s_tab, unsigned ring_base, lds_u64_t* sb, WaveStats& ws, uint64_t t1) {
+  constexpr bool LATTICE = JOB != JOB_Z;
+  // READ_STRICT: every row bit for bit. READ_STRICT_START: the backward sweep and the first rd.strict_rows rows of the
+  // forward sweep -- every decision up to that row is then the reference's own (see forward_sweep), which is what a
+  // read-start structural tie needs, at about half the price
+  const bool strict = MIXED && (rd.flags & (READ_STRICT | READ_STRICT_START)) != 0;  // wave-uniform
+  double Zb, Zf;
+  uint64_t t2;
+  if constexpr (MIXED) {
+    static_assert(JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE, "strict reads exist for align(calc=true) only");
+  }
+  if (MIXED && strict) {
+    const int strict_rows = (rd.flags & READ_STRICT) ? 0x7fffffff : (int)rd.strict_rows;
+    Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, pool.ws, io.m1, io.e2, s_tab, &ws.n_fallback);
+    t2 = __builtin_amdgcn_s_memtime();
+    ws.rows_cert += (uint64_t)rd.T + (uint64_t)min((int)rd.T, strict_rows);
+    if (JOB == JOB_ALIGN_INPLACE)
+      Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, pool.ws, reinterpret_cast<float*>(pool.ws), pool.bits, Zb, io.m1, io.e2, s_tab, ring_base, strict_rows, &ws.n_fallback);
+    else
+      Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, pool.ws, pool.lpe, pool.bits, Zb, io.m1, io.e2, s_tab, ring_base, strict_rows, &ws.n_fallback);
+  } else {
+    if constexpr (JOB == JOB_TRAIN || JOB == JOB_TRAIN_ZCHECK) {
+      // backward sweep in the log domain (the emission's constant folded), then the posterior chain
+      Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, pool.ws, io.m1, io.e2, s_tab);
+      t2 = __builtin_amdgcn_s_memtime();
+      Zf = forward_train_chain(rd, w, sig, pool.ws, io.tr, Zb, s_tab, ring_base);
+      if constexpr (JOB == JOB_TRAIN_ZCHECK) {
+        // dyn_aligner_set_train_zcheck: the reference's own refusal rule (NT_aligner_api.cpp:619-625) on top of the
+        // chain's -- a forward value of Z (the cheap Z-only sweep: no lattice traffic) must agree with the backward one
+        // to 1e-8 per lattice cell, so that `.errors` lists the reads the reference lists (|Z| ~ 1e12 and beyond)
+        const double Zf_log = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, io.m1, io.e2, s_tab, ring_base);
+        if (!z_ok(rd, Zf_log, Zb)) Zf = NEG_INF;
+      }
+    } else {
+      Zb = backward_sweep<LATTICE, JOB == JOB_Z ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, pool.ws, io.m1, io.e2, s_tab);
+      t2 = __builtin_amdgcn_s_memtime();
+      if (JOB == JOB_ALIGN) {
+        Zf = forward_sweep<true, false, false>(rd, w, sig, par, pool.ws, pool.lpe, pool.bits, Zb, io.m1, io.e2, s_tab, ring_base);
+      } else if (JOB == JOB_ALIGN_INPLACE) {
+        Zf = forward_sweep<true, true, false>(rd, w, sig, par, pool.ws, reinterpret_cast<float*>(pool.ws), pool.bits, Zb, io.m1, io.e2, s_tab, ring_base);
+      } else {
+        Zf = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, io.m1, io.e2, s_tab, ring_base);
+      }
+    }
+  }
+  ws.cyc_b += t2 - t1;
+  const uint64_t t3 = __builtin_amdgcn_s_memtime();
+  ws.cyc_f += t3 - t2;
+  if (MIXED && strict) {
+    ws.cyc_bs += t2 - t1;
+    ws.cyc_fs += t3 - t2;
+  }
+
+  int status = z_ok(rd, Zf, Zb) ? 0 : io.z_fail_status;
+  uint32_t n_seg = 0;
+  if ((JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE) && status == 0) {
+    const float* lp = JOB == JOB_ALIGN ? pool.lpe : reinterpret_cast<const float*>(pool.ws);
+    const bool complete = traceback(rd, w, lp, pool.bits, io.tb, JOB == JOB_ALIGN_INPLACE, sb);
+#ifdef DYN_EXP_TRACE_SPLIT  // development: the statistics slots of the certified sweeps carry traceback / mpost cycles instead
+    const uint64_t t4 = __builtin_amdgcn_s_memtime();
+    ws.cyc_bs += t4 - t3;
+#endif
+    if (complete) {
+      if (JOB == JOB_ALIGN) {
+        // segrow was written by other lanes of this wave through global memory
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        mpost(rd, w, pool.ws, pool.lpe, sig, par, io.tb, Zb, io.m1);
+      }
+#ifdef DYN_EXP_TRACE_SPLIT
+      ws.cyc_fs += __builtin_amdgcn_s_memtime() - t4;
+#endif
+      n_seg = rd.N - 1;
+    } else {
+      status = 7;  // DYN_READ_INTERNAL
+    }
+  }
+  if (w.lane == 0) {
+    ReadState s;
+    s.Zb = Zb;
+    s.Zf = Zf;
+    s.status = status;
+    s.n_segments = n_seg;
+    io.st[rd.read] = s;
+  }
+  ws.cyc_t += __builtin_amdgcn_s_memtime() - t3;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,8 +1418,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
   const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[wave][0][0];
   lds_u64_t* sb = (lds_u64_t*)&s_ring[wave][0][0];  // traceback staging: the ring is idle by then
 
-  uint64_t cyc_b = 0, cyc_f = 0, cyc_t = 0, cyc_w = 0, cyc_bs = 0, cyc_fs = 0, rows_cert = 0;
-  uint32_t n_fallback = 0;
+  WaveStats ws;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
   uint32_t* ctl = q.pool.ctl;
   uint32_t have = 0;  // pages in this wave's table
@@ -1348,101 +1456,18 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
     first = false;
     wave_lds_sync();
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
-    cyc_w += t1 - t0;
-
-    // READ_STRICT: every row bit for bit. READ_STRICT_START: the backward sweep and the first rd.strict_rows rows of the
-    // forward sweep -- every decision up to that row is then the reference's own (see forward_sweep), which is what a
-    // read-start structural tie needs, at about half the price
-    const bool strict = MIXED && (rd.flags & (READ_STRICT | READ_STRICT_START)) != 0;  // wave-uniform
-    double Zb, Zf;
-    uint64_t t2;
-    if constexpr (MIXED) {
-      static_assert(JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE, "strict reads exist for align(calc=true) only");
-    }
-    if (MIXED && strict) {
-      const int strict_rows = (rd.flags & READ_STRICT) ? 0x7fffffff : (int)rd.strict_rows;
-      Zb = backward_sweep<LATTICE, ARITH_STRICT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab, &n_fallback);
-      t2 = __builtin_amdgcn_s_memtime();
-      rows_cert += (uint64_t)rd.T + (uint64_t)min((int)rd.T, strict_rows);
-      if (JOB == JOB_ALIGN_INPLACE)
-        Zf = forward_sweep<true, true, MIXED>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows, &n_fallback);
-      else
-        Zf = forward_sweep<true, false, MIXED>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base, strict_rows, &n_fallback);
-    } else {
-      if constexpr (JOB == JOB_TRAIN || JOB == JOB_TRAIN_ZCHECK) {
-        // backward sweep in the log domain (the emission's constant folded), then the posterior chain
-        Zb = backward_sweep<LATTICE, ARITH_FOLDED>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
-        t2 = __builtin_amdgcn_s_memtime();
-        Zf = forward_train_chain(rd, w, sig, q.pool.ws, q.tr, Zb, s_tab, ring_base);
-        if constexpr (JOB == JOB_TRAIN_ZCHECK) {
-          // dyn_aligner_set_train_zcheck: the reference's own refusal rule (NT_aligner_api.cpp:619-625) on top of the
-          // chain's -- a forward value of Z (the cheap Z-only sweep: no lattice traffic) must agree with the backward one
-          // to 1e-8 per lattice cell, so that `.errors` lists the reads the reference lists (|Z| ~ 1e12 and beyond)
-          const double Zf_log = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
-          if (!z_ok(rd, Zf_log, Zb)) Zf = NEG_INF;
-        }
-      } else {
-        Zb = backward_sweep<LATTICE, JOB == JOB_Z ? ARITH_FOLDED : ARITH_DEFAULT>(rd, w, sig, par, q.pool.ws, q.m1, q.e2, s_tab);
-        t2 = __builtin_amdgcn_s_memtime();
-        if (JOB == JOB_ALIGN) {
-          Zf = forward_sweep<true, false, false>(rd, w, sig, par, q.pool.ws, q.pool.lpe, q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
-        } else if (JOB == JOB_ALIGN_INPLACE) {
-          Zf = forward_sweep<true, true, false>(rd, w, sig, par, q.pool.ws, reinterpret_cast<float*>(q.pool.ws), q.pool.bits, Zb, q.m1, q.e2, s_tab, ring_base);
-        } else {
-          Zf = forward_sweep<false, false, false>(rd, w, sig, par, nullptr, nullptr, nullptr, 0.0, q.m1, q.e2, s_tab, ring_base);
-        }
-      }
-    }
-    cyc_b += t2 - t1;
-    const uint64_t t3 = __builtin_amdgcn_s_memtime();
-    cyc_f += t3 - t2;
-    if (MIXED && strict) {
-      cyc_bs += t2 - t1;
-      cyc_fs += t3 - t2;
-    }
-
-    int status = z_ok(rd, Zf, Zb) ? 0 : q.z_fail_status;
-    uint32_t n_seg = 0;
-    if ((JOB == JOB_ALIGN || JOB == JOB_ALIGN_INPLACE) && status == 0) {
-      const float* lp = JOB == JOB_ALIGN ? q.pool.lpe : reinterpret_cast<const float*>(q.pool.ws);
-      const bool complete = traceback(rd, w, lp, q.pool.bits, q.tb, JOB == JOB_ALIGN_INPLACE, sb);
-#ifdef DYN_EXP_TRACE_SPLIT  // development: the statistics slots of the certified sweeps carry traceback / mpost cycles instead
-      const uint64_t t4 = __builtin_amdgcn_s_memtime();
-      cyc_bs += t4 - t3;
-#endif
-      if (complete) {
-        if (JOB == JOB_ALIGN) {
-          // segrow was written by other lanes of this wave through global memory
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-          mpost(rd, w, q.pool.ws, q.pool.lpe, sig, par, q.tb, Zb, q.m1);
-        }
-#ifdef DYN_EXP_TRACE_SPLIT
-        cyc_fs += __builtin_amdgcn_s_memtime() - t4;
-#endif
-        n_seg = rd.N - 1;
-      } else {
-        status = 7;  // DYN_READ_INTERNAL
-      }
-    }
-    if (w.lane == 0) {
-      ReadState s;
-      s.Zb = Zb;
-      s.Zf = Zf;
-      s.status = status;
-      s.n_segments = n_seg;
-      q.st[rd.read] = s;
-    }
-    cyc_t += __builtin_amdgcn_s_memtime() - t3;
+    ws.cyc_w += t1 - t0;
+    run_read<JOB, MIXED>(rd, w, q.pool, ReadIO{q.st, q.tb, q.tr, q.m1, q.e2, q.z_fail_status}, sig, par, s_tab, ring_base, sb, ws, t1);
   }
   // leaving: while a claimed read still lacks its pages, somebody may be waiting for these
   if (LATTICE && have && (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_PROVISIONED])) < (uint32_t)q.n_reads)
     pages_give(q, w, 0, have);
   if (w.lane == 0) {
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(q.pool.ctl + QUEUE_STATS);
-    atomicAdd(&stats[0], (unsigned long long)cyc_b);
-    atomicAdd(&stats[1], (unsigned long long)cyc_f);
-    atomicAdd(&stats[2], (unsigned long long)cyc_t);
-    atomicAdd(&stats[3], (unsigned long long)cyc_w);
+    atomicAdd(&stats[0], (unsigned long long)ws.cyc_b);
+    atomicAdd(&stats[1], (unsigned long long)ws.cyc_f);
+    atomicAdd(&stats[2], (unsigned long long)ws.cyc_t);
+    atomicAdd(&stats[3], (unsigned long long)ws.cyc_w);
     const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
     atomicAdd(&stats[4], life);
     atomicMax(&stats[5], life);
@@ -1451,12 +1476,172 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
 #else
     if (MIXED) {
 #endif
-      atomicAdd(&stats[6], (unsigned long long)cyc_bs);
-      atomicAdd(&stats[7], (unsigned long long)cyc_fs);
-      atomicAdd(&stats[8], (unsigned long long)n_fallback);
-      atomicAdd(&stats[9], (unsigned long long)rows_cert);
+      atomicAdd(&stats[6], (unsigned long long)ws.cyc_bs);
+      atomicAdd(&stats[7], (unsigned long long)ws.cyc_fs);
+      atomicAdd(&stats[8], (unsigned long long)ws.n_fallback);
+      atomicAdd(&stats[9], (unsigned long long)ws.rows_cert);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The RESIDENT read queue (nt_kernels.hpp, SessionArgs): the waves of k_read_queue<JOB_ALIGN>, kept on the chip across
+// batches. A wave claims global read indices one at a time; index g belongs to the ticket whose [base, base + n_reads)
+// holds it, and a wave that has claimed an index nobody has published yet waits for that ticket to appear -- or for the
+// host to close the session.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ uint32_t sctl_load(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(p)); }
+
+// the record of ticket `index`: 32 lanes load a dword each (agent scope: the record was written by a kernel of another
+// stream, possibly on another XCD), the values are handed round as scalars
+__device__ __forceinline__ SessionTicket load_ticket(const SessionTicket* ring, uint32_t index, uint32_t ring_size, int lane) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + (index % ring_size));
+  const uint32_t v = ctl_load(src + (lane & 31));
+  uint32_t wds[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wds[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+  SessionTicket t;
+  __builtin_memcpy(&t, wds, sizeof t);
+  return t;
+}
+
+}  // namespace
+
+template <bool MIXED>
+__global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char* __restrict__ in_base, char* out_base,
+                                                const SoftplusNode* __restrict__ sp_tab) {
+  constexpr int TAB_NODES = SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2;
+  __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[TAB_NODES];
+  __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
+  __shared__ uint32_t s_pt[DYN_WAVES_PER_GROUP][PT_MAX];
+  for (int i = threadIdx.x; i < TAB_NODES; i += 64 * DYN_WAVES_PER_GROUP) s_tab[i] = sp_tab[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t slot = blockIdx.x * DYN_WAVES_PER_GROUP + wave;
+  WaveCtx w;
+  w.lane = threadIdx.x & 63;
+  w.pt = (lds_u32_t*)&s_pt[wave][0];
+  w.log_r = sa.pool.log_rows;
+  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[wave][0][0];
+  lds_u64_t* sb = (lds_u64_t*)&s_ring[wave][0][0];
+  // this wave's arena, for the whole session
+  for (uint32_t k = w.lane; k < sa.arena_pages; k += 64) w.pt[k] = slot * sa.arena_pages + k;
+  wave_lds_sync();
+
+  uint32_t* ctl = sa.ctl;
+  const uint64_t t_start = __builtin_amdgcn_s_memtime();
+  uint64_t cyc_busy = 0, cyc_idle = 0, n_done = 0;
+  uint32_t cur = 0, tail_seen = 0;   // the ticket this wave looks at; tickets it knows to be published
+  bool have = false;
+  SessionTicket tk{};
+  for (;;) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t h = 0;
+    if (w.lane == 0) h = __hip_atomic_fetch_add(&ctl[S_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    // the ticket that holds read g (indices only grow, so it is `cur` or a later one)
+    bool leave = false;
+    for (;;) {
+      if (have && g - tk.base < tk.n_reads) break;
+      if (have) {
+        ++cur;
+        have = false;
+      }
+      while (cur >= tail_seen) {
+        // closed BEFORE tail: the host closes behind its last publish, so a tail read after a set `closed` is final
+        const uint32_t closed = sctl_load(&ctl[S_CLOSED]) | sctl_load(&ctl[S_ABORT]);
+        tail_seen = sctl_load(&ctl[S_TAIL]);
+        if (cur < tail_seen) break;
+        if (closed) {
+          leave = true;
+          break;
+        }
+        if (__builtin_amdgcn_s_memtime() - t0 > sa.idle_limit_ticks) {  // the host is gone, or stuck: never spin for ever
+          if (w.lane == 0) ctl_store(&ctl[S_ABORT], 2u);
+          leave = true;
+          break;
+        }
+        for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);  // ~2 us: one lane's poll per wave, agent scope
+      }
+      if (leave) break;
+      tk = load_ticket(sa.ring, cur, sa.ring_size, w.lane);
+      have = true;
+    }
+    if (leave) break;
+    // The ticket's inputs were written while this kernel runs, into buffers earlier tickets used: drop what the scalar
+    // cache and this CU's L1 may still hold of them (MI355X_MICROARCH.md, inter-workgroup visibility)
+    __builtin_amdgcn_s_dcache_inv();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const ReadDesc* __restrict__ descs = reinterpret_cast<const ReadDesc*>(in_base + tk.descs_off);
+    const double* __restrict__ sig = reinterpret_cast<const double*>(in_base + tk.sig_off);
+    const Emis* __restrict__ par = reinterpret_cast<const Emis*>(in_base + tk.par_off);
+    const ReadDesc rd = descs[g - tk.base];
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    cyc_idle += t1 - t0;
+    WaveStats ws;
+    ReadIO io{};
+    io.st = reinterpret_cast<ReadState*>(out_base + tk.st_off);
+    io.tb = TraceBuffers{reinterpret_cast<double*>(out_base + tk.pp_off), reinterpret_cast<uint32_t*>(out_base + tk.pathn_off),
+                         reinterpret_cast<uint32_t*>(out_base + tk.segrow_off), reinterpret_cast<double*>(out_base + tk.medhi_off),
+                         reinterpret_cast<double*>(out_base + tk.medlo_off)};
+    io.m1 = sa.m1;
+    io.e2 = sa.e2;
+    io.z_fail_status = tk.z_fail_status;
+    run_read<JOB_ALIGN, MIXED>(rd, w, sa.pool, io, sig, par, s_tab, ring_base, sb, ws, t1);
+    // everything this wave wrote for the read (state, path arrays, segment rows) must have left this XCD's L2 before the
+    // ticket's counter says so: the per-segment kernels and the copies that follow run elsewhere
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w.lane == 0) {
+      uint32_t* tctl = reinterpret_cast<uint32_t*>(out_base + tk.tctl_off);
+      unsigned long long* ts = reinterpret_cast<unsigned long long*>(tctl + SESSION_TSTATS);
+      atomicAdd(&ts[0], (unsigned long long)ws.cyc_b);
+      atomicAdd(&ts[1], (unsigned long long)ws.cyc_f);
+      atomicAdd(&ts[2], (unsigned long long)ws.cyc_t);
+      if (MIXED) {
+        atomicAdd(&ts[6], (unsigned long long)ws.cyc_bs);
+        atomicAdd(&ts[7], (unsigned long long)ws.cyc_fs);
+        atomicAdd(&ts[8], (unsigned long long)ws.n_fallback);
+        atomicAdd(&ts[9], (unsigned long long)ws.rows_cert);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t before = __hip_atomic_fetch_add(&tctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before + 1u == tk.n_reads)  // the ticket is complete: tell the host (fine-grained pinned memory)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(out_base + tk.flag_off), tk.n_reads, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    ++n_done;
+    cyc_busy += __builtin_amdgcn_s_memtime() - t1;
+  }
+  if (w.lane == 0) {
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(ctl + SESSION_STATS);
+    const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
+    atomicAdd(&stats[0], (unsigned long long)cyc_busy);
+    atomicAdd(&stats[1], (unsigned long long)cyc_idle);
+    atomicAdd(&stats[2], life);
+    atomicMax(&stats[3], life);
+    atomicAdd(&stats[4], (unsigned long long)n_done);
+  }
+}
+
+// one wave: lanes 0..31 store a dword of the record each, then lane 0 moves the tail
+__global__ void k_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket tk, uint32_t index, uint32_t ring_size) {
+  const int lane = threadIdx.x;
+  uint32_t wds[32];
+  __builtin_memcpy(wds, &tk, sizeof tk);
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) mine = (lane == k) ? wds[k] : mine;
+  if (lane < 32) ctl_store(reinterpret_cast<uint32_t*>(ring + (index % ring_size)) + lane, mine);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) ctl_store(&ctl[S_TAIL], index + 1u);
+}
+
+__global__ void k_session_close(uint32_t* ctl) {
+  if (threadIdx.x == 0) ctl_store(&ctl[S_CLOSED], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1754,6 +1939,21 @@ void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n
     case JOB_TRAIN_ZCHECK: hipLaunchKernelGGL((k_read_queue<JOB_TRAIN_ZCHECK, false>), grid, block, 0, s, q, q.descs, q.sig, q.par, q.sp_tab); break;
   }
 }
+
+void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+                    int n_cus, hipStream_t s) {
+  const dim3 grid(std::max(1, n_cus)), block(64 * DYN_WAVES_PER_GROUP);
+  if (with_strict)
+    hipLaunchKernelGGL((k_session<true>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
+  else
+    hipLaunchKernelGGL((k_session<false>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
+}
+
+void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s) {
+  hipLaunchKernelGGL(k_session_publish, dim3(1), dim3(64), 0, s, ring, ctl, tk, index, ring_size);
+}
+
+void launch_session_close(uint32_t* ctl, hipStream_t s) { hipLaunchKernelGGL(k_session_close, dim3(1), dim3(64), 0, s, ctl); }
 
 void launch_segments(const ReadDesc* descs, int n_reads, uint64_t rows_total, uint32_t max_N, const ReadState* st,
                      TraceBuffers tb, SegRow* rows, int kmer_size, hipStream_t s) {

@@ -117,6 +117,63 @@ struct QueueArgs {
   int z_fail_status;
 };
 
+// ---- the RESIDENT read queue (round 5) ---------------------------------------------------------------------------
+// k_read_queue drains ONE batch per launch: its waves finish up to one read apart, and the next launch -- queued on the same
+// stream -- waits for the last of them (wave occupancy 0.89-0.91 at 2-3 batches per launch). k_session keeps the waves
+// RESIDENT: the host publishes batch after batch ("tickets") into a ring while the kernel runs, a wave that has finished a
+// read takes the next one of whatever ticket is next, and the kernel leaves only when the host closes the session (nothing
+// left in its pipeline). Tickets complete one by one (a counter per ticket; the wave whose read completes it raises a word
+// in pinned host memory), their per-segment kernels and copies run beside the resident waves on other streams.
+//  * every wave owns a STATIC arena of `arena_pages` lattice pages (page numbers slot * arena_pages + k): no free list, no
+//    lock; the host only opens a session when the pool holds an arena for every wave (separate LPE layout);
+//  * inputs of a ticket (descriptors, samples, per-column parameters) were written by H2D copies and small kernels of other
+//    streams WHILE this kernel runs, into buffers that earlier tickets used: a wave starts every read with s_dcache_inv and
+//    an agent-scope acquire (this CU's L1), and it reads them through ONE `const __restrict__` kernel parameter (in_base +
+//    a byte offset from the ticket record), so that wave-uniform loads stay scalar loads (see k_read_queue);
+//  * what a wave wrote for a read (state, path arrays) is released (agent scope) before the ticket's counter moves;
+//  * every wait is bounded: a wave that has found nothing to do for `idle_limit_ticks` raises the abort word and leaves.
+// Validated in isolation by tools/ubench/resident_probe.hip (co-scheduling of the small kernels beside a resident kernel of
+// this footprint, freshness of rewritten buffers, and that the resident kernel needs a hardware queue of its own).
+struct SessionTicket {      // 128 bytes in device memory, written once per ticket by k_session_publish
+  // Byte offsets, not pointers: an address the kernel forms from one of its own pointer PARAMETERS is known to be global
+  // memory (global_load / global_store; a pointer loaded from memory is a generic one: flat_ instructions), and loads
+  // through the `const __restrict__` in_base stay scalar loads where the address is wave-uniform.
+  int64_t descs_off;        // from in_base: ReadDesc[n_reads] in processing order,
+  int64_t sig_off;          //   the ticket's signal pool (ReadDesc::sig_off counts doubles from here),
+  int64_t par_off;          //   its per-column emission table (ReadDesc::par_off counts entries from here)
+  int64_t st_off;           // from out_base: ReadState[], then the five TraceBuffers arrays
+  int64_t pp_off, pathn_off, segrow_off, medhi_off, medlo_off;
+  int64_t tctl_off;         // the ticket's control block: [0] reads finished; 64-bit statistics from word SESSION_TSTATS on
+  int64_t flag_off;         // a word of pinned host memory: set to n_reads by the wave whose read completes the ticket
+  uint32_t n_reads;
+  uint32_t base;            // the ticket's reads are global indices [base, base + n_reads)
+  int32_t z_fail_status;
+  uint32_t pad_[7];
+};
+static_assert(sizeof(SessionTicket) == 128, "one cache line pair per record");
+constexpr int SESSION_TSTATS = 2;        // first statistics word of a ticket's control block (as uint32 index, 8-byte aligned)
+constexpr int SESSION_TCTL_WORDS = 32;
+// session control words (device memory, 32-bit): next global read index, tickets published, closed, abort; 64-bit statistics
+// from word SESSION_STATS on: wave-cycles busy (claim to release), idle, lifetime, longest lifetime, reads done
+constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS = 8, SESSION_CTL_WORDS = 32;
+
+struct SessionArgs {
+  const SessionTicket* ring;   // [ring_size]; slot i holds ticket i of the session (never reused within one)
+  uint32_t ring_size;
+  uint32_t arena_pages;        // pages per wave
+  uint32_t* ctl;
+  PagePool pool;               // ws, lpe, bits, log_rows (free_list and ctl unused)
+  double m1, e2;
+  uint64_t idle_limit_ticks;   // s_memtime ticks (100 MHz)
+};
+
+// n_cus workgroups of four waves on `s` -- which must own its hardware queue (hipExtStreamCreateWithCUMask)
+void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+                    int n_cus, hipStream_t s);
+// record `tk` as ticket `index` and make it visible (tail = index + 1); closed: no ticket will follow
+void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s);
+void launch_session_close(uint32_t* ctl, hipStream_t s);
+
 // P1/P2 on the device: out[i] = hampel((REAL(raw[i]) - shift) / scale); REAL = float when compute_f32.
 // raw_dtype: 0 float32, 1 int16, 2 float64, 3 int16 ADC with per-read float32 calibration (pA = (adc + cal_offset) *
 // cal_scale in float32; cal_* may be null otherwise). norm_tmp: scratch of total samples * sizeof(REAL).

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 5 /* 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
+#define DYN_ABI_VERSION 6 /* 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -192,6 +192,25 @@ typedef struct dyn_timing {
   double launch_share;
 } dyn_timing;
 
+/* (ABI 6, additive) The RESIDENT read queue. Asynchronous align(calc_probabilities=1) tickets of at least 512 reads whose
+ * lattices fit one static arena per wave do not get a kernel launch each: the handle keeps ONE launch of resident waves
+ * (a "session") on a stream that owns its hardware queue, publishes ticket after ticket into it while it runs, and closes
+ * it when its pipeline has run dry -- no wave idles between batches (a launch per batch, or per two or three, ends with
+ * its waves up to one read apart; k_session, dynamont_amd/csrc/nt_kernels.hip). Results are those of separate launches bit
+ * for bit. Such a ticket's dyn_timing reports its own wave time: ms_dp = (wave-cycles its reads took) / waves, launches =
+ * 0, launch_share = 0; the sessions themselves are accounted for here -- ms is the sum of the session kernels' durations
+ * (HIP events on the session stream), which is what the roofline of a run must be taken over. Everything else (training,
+ * Z-only jobs, small or page-starved batches, the synchronous calls) runs as one launch per batch as before; a handle
+ * whose session stream cannot be created, or with DYN_NO_SESSION=1 in the environment, never opens a session. */
+typedef struct dyn_session_stats {
+  uint64_t sessions;       /* closed sessions */
+  uint64_t tickets, reads, cells;
+  double ms;               /* sum of their kernels' durations */
+  uint64_t wave_cycles_busy, wave_cycles_idle, wave_cycles_life;   /* 100 MHz ticks, summed over waves and sessions */
+  uint64_t waves;          /* sum over sessions of waves launched */
+  uint64_t aborted;        /* sessions whose waves raised the abort word (idle watchdog) */
+} dyn_session_stats;
+
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,
  * message "Unknown pore type: <s>". */
 int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errcap);
@@ -215,6 +234,9 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
 void dyn_aligner_destroy(dyn_aligner* a);
 void dyn_release_cached_memory(void);
 int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
+/* Totals over the handle's CLOSED sessions (dyn_session_stats above). Closes an open session first and waits until its
+ * waves have left -- call it when the tickets of interest have been waited for. */
+int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out);
 /* Dense model table in k-mer-code order, (mean, stdev) interleaved, 2*num_kmers doubles. */
 int dyn_aligner_model(const dyn_aligner* a, double* out2n);
 /* Replace the model table (same layout as dyn_aligner_model: k-mer-code order, (mean, stdev) interleaved). The handle

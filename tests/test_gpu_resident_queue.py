@@ -1,0 +1,112 @@
+"""GPU (-m gpu): the RESIDENT read queue (k_session; include/dynamont_mi.h, dyn_session_stats). Asynchronous
+align(calc_probabilities=True) tickets of >= 512 reads are published into one launch of resident waves instead of getting
+a launch each; every result must be the one-launch-per-batch result BIT FOR BIT (Z bits, integer columns, probabilities),
+whatever else goes through the handle meanwhile."""
+import numpy as np
+import pytest
+
+from dynamont_amd import Aligner, synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib", "oracle_built")]
+
+
+def _same(a, b):
+    assert np.array_equal(a.status, b.status)
+    assert np.array_equal(a.Z.view(np.uint64), b.Z.view(np.uint64))
+    assert np.array_equal(a.n_segments, b.n_segments)
+    assert np.array_equal(a.seg_offsets, b.seg_offsets)
+    for i in range(a.n):
+        lo, hi = int(a.seg_offsets[i]), int(a.seg_offsets[i]) + int(a.n_segments[i])
+        assert np.array_equal(a.signal_positions[lo:hi], b.signal_positions[lo:hi])
+        assert np.array_equal(a.sequence_positions[lo:hi], b.sequence_positions[lo:hi])
+        assert np.array_equal(a.probabilities[lo:hi].view(np.uint64), b.probabilities[lo:hi].view(np.uint64))
+
+
+def _data(models, n_batches, n_reads, seed0, bases=(200, 420)):
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    out = []
+    for j in range(n_batches):
+        reads = synth.make_reads(seed0 + j, n_reads, "rna004", mean, sd, bases)
+        if j == 2:  # a read that fails in sequenceToKmers stays with its own ticket
+            reads[11] = synth.SynthRead(reads[11].signal, reads[11].sequence[:40] + "N" + reads[11].sequence[41:])
+        out.append((reads, synth.pack_reads(reads)))
+    return out
+
+
+def test_resident_queue_equals_one_launch_per_batch(models):
+    al = Aligner(models["syn9"], "rna004", device=0)
+    data = _data(models, 6, 640, 4100)
+    want = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data]
+    before = al.session_stats()
+    assert before["sessions"] == 0  # the synchronous calls are one launch per batch
+    for rnd in range(2):  # the second round opens a new session behind the first
+        tickets = [al.align_async(*packed, True) for _, packed in data]
+        for t, w in zip(tickets, want):
+            _same(t.wait(), w)
+            tm = t.timing()
+            assert tm["launches"] == 0 and tm["launch_share"] == 0.0  # no launch of its own
+            assert tm["reads_ok"] == int((w.status == 0).sum()) and tm["ms_dp"] > 0 and tm["ms_total"] > tm["ms_dp"]
+            assert tm["reads_strict"] > 0 and tm["cert_rows"] > 0  # rna004: pad + A reads run the certified sweeps
+            ptr, cap, st = t.device_results()
+            assert ptr and st and cap == w.seg_offsets[-1]
+        for t in tickets:
+            t.close()
+        s = al.session_stats()
+        assert s["aborted"] == 0
+        assert s["sessions"] >= rnd + 1 and s["tickets"] == 6 * (rnd + 1)
+        assert s["reads"] == (rnd + 1) * sum(int((w.status == 0).sum()) for w in want)
+        assert s["ms"] > 0 and 0.0 < s["wave_occupancy"] <= 1.0
+    al.close()
+
+
+def test_other_jobs_between_resident_tickets(models):
+    """Z-only tickets, training, small batches and the synchronous calls use the lattice pool as one launch per batch: the
+    session is closed and waited for in front of them, and opened again behind them."""
+    al = Aligner(models["syn9"], "rna004", device=0)
+    data = _data(models, 4, 600, 4300)
+    small = _data(models, 1, 24, 4400, bases=(60, 200))[0]
+    want = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data]
+    want_small = al.align_batch([r.signal for r in small[0]], [r.sequence for r in small[0]], True)
+    want_z = al.align_batch([r.signal for r in data[1][0]], [r.sequence for r in data[1][0]], False)
+    want_tr = al.train_batch([r.signal for r in small[0]], [r.sequence for r in small[0]])
+    t0 = al.align_async(*data[0][1], True)
+    t1 = al.align_async(*data[1][1], True)
+    tz = al.align_async(*data[1][1], False)        # Z only: a classic launch
+    ts = al.align_async(*small[1], True)           # 24 reads join the session that is open, or run alone
+    t2 = al.align_async(*data[2][1], True)
+    ttr = al.train_async(*small[1])
+    t3 = al.align_async(*data[3][1], True)
+    for t, w in ((t0, want[0]), (t1, want[1]), (t2, want[2]), (t3, want[3]), (ts, want_small)):
+        _same(t.wait(), w)
+    rz = tz.wait()
+    assert np.array_equal(rz.status, want_z.status) and np.array_equal(rz.Z, want_z.Z)
+    rt = ttr.wait()
+    assert np.array_equal(rt.status, want_tr.status) and np.allclose(rt.Z, want_tr.Z, rtol=1e-12)
+    # a synchronous call while nothing is in flight, then the plain arithmetic: another kernel variant, another session
+    _same(al.align_batch([r.signal for r in data[0][0]], [r.sequence for r in data[0][0]], True), want[0])
+    for t in (t0, t1, t2, t3, tz, ts, ttr):
+        t.close()
+    al.set_strict("off")
+    plain = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data[:2]]
+    tickets = [al.align_async(*packed, True) for _, packed in data[:2]]
+    for t, w in zip(tickets, plain):
+        _same(t.wait(), w)
+        assert t.timing()["reads_strict"] == 0
+        t.close()
+    s = al.session_stats()
+    assert s["aborted"] == 0 and s["sessions"] >= 2
+    al.close()
+
+
+def test_no_session_environment_switch(models, monkeypatch):
+    monkeypatch.setenv("DYN_NO_SESSION", "1")
+    al = Aligner(models["syn9"], "rna004", device=0)
+    data = _data(models, 3, 600, 4500)
+    want = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data]
+    tickets = [al.align_async(*packed, True) for _, packed in data]
+    for t, w in zip(tickets, want):
+        _same(t.wait(), w)
+        assert t.timing()["launches"] == 1
+        t.close()
+    assert al.session_stats()["sessions"] == 0
+    al.close()
