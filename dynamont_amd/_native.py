@@ -11,7 +11,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libdynamont_mi.so")
+# DYN_LIB_PATH: another build of the SAME sources (tools/sanitize: the host side under ASan / UBSan / TSan on the CPU)
+LIB_PATH = os.environ.get("DYN_LIB_PATH") or os.path.join(HERE, "libdynamont_mi.so")
 SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "bam_reader.cpp", "rccl_comm.cpp", "model_format.cpp",
            "nt_kernels.hip", "pool_stats.hip"]
 HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
@@ -192,8 +193,8 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> dynamont_amd/libdynamont_mi.so (in-tree, so it travels)."""
-    if not force and not needs_build():
-        return LIB_PATH
+    if os.environ.get("DYN_LIB_PATH") or (not force and not needs_build()):
+        return LIB_PATH  # (a library named by DYN_LIB_PATH is built by whoever named it)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-ldl", "-lz", "-o", LIB_PATH + ".tmp"]
     cmd += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...

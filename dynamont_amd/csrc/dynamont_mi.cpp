@@ -1566,7 +1566,10 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
 
 bool session_candidate(const dyn_batch* b) {
   const dyn_aligner* a = b->a;
-  return a->s_session && !a->host_only && !a->ntk && b->job == DynJob::AlignFull && (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
+  // (b->async: a caller's ticket. The batch of a MERGED launch is the engine's own and stays one launch: its members report
+  //  that launch and their share of it.)
+  return a->s_session && !a->host_only && !a->ntk && b->async && b->job == DynJob::AlignFull &&
+         (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
 }
 
 int session_close(dyn_aligner* a) {
@@ -1809,16 +1812,19 @@ int session_collect_timing(dyn_batch* b) {
   float ms12 = 0;
   HIP_TRY(a, hipEventElapsedTime(&ms12, b->events[1], b->events[2]));
   const uint64_t* st = reinterpret_cast<const uint64_t*>(b->h_stats.as<uint32_t>() + dynk::SESSION_TSTATS);
-  const double per_ms = 1e5 * (double)std::max<uint32_t>(1, b->sess_waves);  // s_memtime: 100 MHz
-  tm.ms_backward = (double)st[0] / per_ms;
-  tm.ms_forward = (double)st[1] / per_ms;
-  tm.ms_dp = (double)(st[0] + st[1] + st[2]) / per_ms;
-  tm.ms_trace = (double)st[2] / per_ms + ms12;
+  // the ticket's wave time: its reads' durations (10 ns ticks) spread over the session's waves; the phases by their share of
+  // the shader-clock cycles
+  tm.ms_dp = (double)st[3] / 1e5 / (double)std::max<uint32_t>(1, b->sess_waves);
+  const double cyc = (double)(st[0] + st[1] + st[2]);
+  const double per_cyc = cyc > 0 ? tm.ms_dp / cyc : 0.0;
+  tm.ms_backward = (double)st[0] * per_cyc;
+  tm.ms_forward = (double)st[1] * per_cyc;
+  tm.ms_trace = (double)st[2] * per_cyc + ms12;
   tm.ms_total = tm.ms_dp + ms12;
   tm.wave_wait_share = 0.0;
   tm.wave_occupancy = 0.0;  // a session's, not a ticket's: dyn_aligner_session_stats
-  tm.ms_backward_strict = (double)st[6] / per_ms;
-  tm.ms_forward_strict = (double)st[7] / per_ms;
+  tm.ms_backward_strict = (double)st[6] * per_cyc;
+  tm.ms_forward_strict = (double)st[7] * per_cyc;
   tm.cert_fallbacks = st[8];
   tm.cert_rows = st[9];
   return DYN_OK;

@@ -220,10 +220,16 @@ __device__ __forceinline__ void log_plus_finish_certified(const SoftplusLookup<C
                                                           uint32_t& fallbacks) {
   double hi[CPL];
   dynmath::log_plus_finish_cert<CPL>(L, out, hi);
-  unsigned amb = 0;  // wave-uniform: bit j = some lane's certificate failed in register j
+  // One branch per row, not one test per register: the seven comparison masks are OR-ed (7 v_cmp + 6 s_or_b64, where the
+  // per-register form took a compare, a select and an OR of SALU each), and which registers hold the ambiguous sums is only
+  // worked out on the rare path.
+  uint64_t any_amb = 0;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) amb |= __any(out[j] != hi[j]) ? 1u << j : 0u;
-  if (__builtin_expect(amb != 0, 0)) {
+  for (int j = 0; j < CPL; ++j) any_amb |= __ballot(out[j] != hi[j]);
+  if (__builtin_expect(any_amb != 0, 0)) {
+    unsigned amb = 0;  // wave-uniform: bit j = some lane's certificate failed in register j
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) amb |= __any(out[j] != hi[j]) ? 1u << j : 0u;
     // ONE copy of the restated glibc (M = 1) for whichever registers need it: the operands are picked by the uniform
     // register number (a select chain: ~30 instructions per pass, next to ~130 of the restatement itself). Unrolled by
     // register, the seven copies cost the hot loop 100 spilled VGPRs.
@@ -1537,7 +1543,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   bool have = false;
   SessionTicket tk{};
   for (;;) {
-    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();      // shader clock: phase shares
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: durations
     uint32_t h = 0;
     if (w.lane == 0) h = __hip_atomic_fetch_add(&ctl[S_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
@@ -1558,7 +1565,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
           leave = true;
           break;
         }
-        if (__builtin_amdgcn_s_memtime() - t0 > sa.idle_limit_ticks) {  // the host is gone, or stuck: never spin for ever
+        if (__builtin_amdgcn_s_memrealtime() - r0 > sa.idle_limit_ticks) {  // the host is gone, or stuck: never spin for ever
           if (w.lane == 0) ctl_store(&ctl[S_ABORT], 2u);
           leave = true;
           break;
@@ -1580,6 +1587,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const Emis* __restrict__ par = reinterpret_cast<const Emis*>(in_base + tk.par_off);
     const ReadDesc rd = descs[g - tk.base];
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     cyc_idle += t1 - t0;
     WaveStats ws;
     ReadIO io{};
@@ -1601,6 +1609,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
       atomicAdd(&ts[0], (unsigned long long)ws.cyc_b);
       atomicAdd(&ts[1], (unsigned long long)ws.cyc_f);
       atomicAdd(&ts[2], (unsigned long long)ws.cyc_t);
+      // the read's duration in 10 ns ticks (s_memtime runs with the shader clock: good for shares, not for times)
+      atomicAdd(&ts[3], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r1));
       if (MIXED) {
         atomicAdd(&ts[6], (unsigned long long)ws.cyc_bs);
         atomicAdd(&ts[7], (unsigned long long)ws.cyc_fs);

@@ -143,7 +143,9 @@ struct SessionTicket {      // 128 bytes in device memory, written once per tick
   int64_t par_off;          //   its per-column emission table (ReadDesc::par_off counts entries from here)
   int64_t st_off;           // from out_base: ReadState[], then the five TraceBuffers arrays
   int64_t pp_off, pathn_off, segrow_off, medhi_off, medlo_off;
-  int64_t tctl_off;         // the ticket's control block: [0] reads finished; 64-bit statistics from word SESSION_TSTATS on
+  int64_t tctl_off;         // the ticket's control block: [0] reads finished; 64-bit statistics from word SESSION_TSTATS on:
+                            //   wave-cycles (shader clock) in backward / forward / traceback, [3] the reads' durations in 10 ns
+                            //   ticks (s_memrealtime), [6..9] the certified sweeps apart (as QUEUE_STATS)
   int64_t flag_off;         // a word of pinned host memory: set to n_reads by the wave whose read completes the ticket
   uint32_t n_reads;
   uint32_t base;            // the ticket's reads are global indices [base, base + n_reads)
@@ -164,7 +166,7 @@ struct SessionArgs {
   uint32_t* ctl;
   PagePool pool;               // ws, lpe, bits, log_rows (free_list and ctl unused)
   double m1, e2;
-  uint64_t idle_limit_ticks;   // s_memtime ticks (100 MHz)
+  uint64_t idle_limit_ticks;   // s_memrealtime ticks (100 MHz)
 };
 
 // n_cus workgroups of four waves on `s` -- which must own its hardware queue (hipExtStreamCreateWithCUMask)

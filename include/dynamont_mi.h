@@ -206,7 +206,7 @@ typedef struct dyn_session_stats {
   uint64_t sessions;       /* closed sessions */
   uint64_t tickets, reads, cells;
   double ms;               /* sum of their kernels' durations */
-  uint64_t wave_cycles_busy, wave_cycles_idle, wave_cycles_life;   /* 100 MHz ticks, summed over waves and sessions */
+  uint64_t wave_cycles_busy, wave_cycles_idle, wave_cycles_life;   /* shader-clock cycles, summed over waves and sessions */
   uint64_t waves;          /* sum over sessions of waves launched */
   uint64_t aborted;        /* sessions whose waves raised the abort word (idle watchdog) */
 } dyn_session_stats;

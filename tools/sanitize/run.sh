@@ -1,0 +1,47 @@
+#!/bin/bash
+# The host side of the library under the sanitizers, on the CPU (no GPU needed; ~15 minutes on 8 cores):
+#   1. ASan + UBSan and TSan builds of every .cpp translation unit (Makefile beside this script)
+#   2. the CPU tests of the file readers, the formatter and the sink against those builds
+#      (DYN_LIB_PATH selects the library dynamont_amd/_native.py loads; the sanitizer runtime is preloaded into python)
+#   3. the byte-level fuzz of BGZF / BAM records / VBZ chunks / model TSV / CSV rows (fuzz_host.cpp), >= 1e5 mutations
+# Output: profiles/r05/sanitizers.txt (summary) + fuzz_asan_ubsan.txt / fuzz_tsan.txt. Exit code 0 = no report anywhere.
+set -u
+cd "$(dirname "$0")/../.."
+OUT=profiles/r05
+mkdir -p "$OUT"
+N_ASAN=${N_ASAN:-40000}
+N_TSAN=${N_TSAN:-4000}
+TESTS="tests/test_bam_reader.py tests/test_pod5_native.py tests/test_format_pinning.py tests/test_harness.py tests/test_abi_host.py"
+fail=0
+make -s -C tools/sanitize -j"$(nproc)" all || exit 2
+{
+  echo "# host-side sanitizer runs ($(date -u +%Y-%m-%dT%H:%MZ), $(g++ --version | head -1))"
+  for kind in asan tsan; do
+    if [ $kind = asan ]; then
+      rt=$(g++ -print-file-name=libasan.so)
+      export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+    else
+      rt=$(g++ -print-file-name=libtsan.so)
+      export TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"
+    fi
+    echo "## $kind: pytest -m 'not gpu' $TESTS"
+    LD_PRELOAD="$rt" DYN_LIB_PATH="$PWD/build/sanitize/libdynamont_mi_$kind.so" timeout 1500 python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4
+    rc=${PIPESTATUS[0]}
+    echo "exit code $rc"
+    [ "$rc" = 0 ] || fail=1
+  done
+  echo "## asan+ubsan: fuzz_host tests/fuzz_corpus $N_ASAN (seed 5)"
+  ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 timeout 3000 build/sanitize/fuzz_host_asan tests/fuzz_corpus "$N_ASAN" 5 > "$OUT/fuzz_asan_ubsan.txt" 2>&1
+  rc=$?
+  tail -6 "$OUT/fuzz_asan_ubsan.txt"
+  echo "exit code $rc"
+  [ "$rc" = 0 ] || fail=1
+  echo "## tsan: fuzz_host tests/fuzz_corpus $N_TSAN (seed 6)"
+  TSAN_OPTIONS="halt_on_error=1" timeout 3000 build/sanitize/fuzz_host_tsan tests/fuzz_corpus "$N_TSAN" 6 > "$OUT/fuzz_tsan.txt" 2>&1
+  rc=$?
+  tail -6 "$OUT/fuzz_tsan.txt"
+  echo "exit code $rc"
+  [ "$rc" = 0 ] || fail=1
+  echo "## result: $([ $fail = 0 ] && echo 'no sanitizer report, every run exit code 0' || echo 'FAILURES above')"
+} 2>&1 | tee "$OUT/sanitizers.txt"
+exit $fail
