@@ -58,6 +58,7 @@ KBWD_BYTES_PER_CELL = 8.0        # backward sweep: write bE
 KFWD_BYTES_PER_CELL = 12.125     # forward sweep: read bE 8 B + write float LPE 4 B + 1 decision bit
 KFWD_INPLACE_BYTES_PER_CELL = 16.125  # page-starved layout: read bE 8 B + write (float LPM, float LPE) 8 B + 1 bit
 KTRAIN_BYTES_PER_CELL = 8.0      # forward sweep of train(): read bE
+VALU_F64_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # fp64 VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz
 
 WORKLOADS = {
     # name -> (synth config, reads per batch, default number of distinct batches)
@@ -97,6 +98,11 @@ def parse():
     ap.add_argument("--e2e-batch-reads", type=int, default=0, help="--batch-reads of the e2e_cli run (0 = the CLI's default)")
     ap.add_argument("--no-resident", action="store_true", help="skip the kernel_resident leg (profiling runs: every launch of the process then belongs to the timed region)")
     ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
+    ap.add_argument("--no-polya", action="store_true", help="skip the `cfg2_polya` record (N = 1: cfg2 with every read flagged)")
+    ap.add_argument("--no-scale-ref", action="store_true", help="skip the `scale_ref` record (N = 1: configs[3]'s per-GPU share on one GPU)")
+    ap.add_argument("--no-sessions", action="store_true", help="experiment: one launch per batch (no resident read queue)")
+    ap.add_argument("--reserve-cus", type=int, default=8,
+                    help="N > 1: compute units kept free of the resident read queue for RCCL's kernels (dyn_aligner_set_session_mode)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
                     help="align = the headline metric; train = Baum-Welch statistics pass (config 5 shape, secondary)")
     return ap.parse_args()
@@ -184,6 +190,264 @@ def launch_ranks(args) -> int:
     return proc.wait()
 
 
+class Workload:
+    """the stream of distinct batches of one workload, in caller-owned host arrays (cached per name)"""
+    _cache: dict = {}
+
+    def __init__(self, name: str, rank: int, args, model_cache: dict, workdir: str):
+        from dynamont_amd import synth
+        import numpy as np
+        cfgname, per_batch, n_batches = WORKLOADS[name]
+        cfg = dict(synth.CONFIGS[cfgname])
+        if per_batch:
+            cfg["n_reads"] = per_batch
+        if args.reads:
+            cfg["n_reads"] = args.reads
+        self.name, self.cfg = name, cfg
+        self.n_batches = max(1, args.batches or n_batches)
+        self.pore = cfg["pore"]
+        _, _rna, self.k = synth.PORES[self.pore]
+        if self.k not in model_cache:
+            model_cache[self.k] = synth.write_model(os.path.join(workdir, f"syn{self.k}.model"), self.k, seed=7, stdev=0.25 if self.k == 5 else 0.15)
+        self.model_path = model_cache[self.k]
+        _, mean, sd = synth.read_model_file(self.model_path)
+        self.batches = []
+        for j in range(self.n_batches):
+            reads = synth.make_reads(cfg["seed"] + 1000 * rank + 100003 * j, cfg["n_reads"], self.pore, mean, sd, cfg["n_bases"], polya=cfg.get("polya"))
+            sig, sig_off, seqs, seq_off = synth.pack_reads(reads)
+            if args.pinned_inputs:
+                from dynamont_amd._dynamont import pinned_empty
+                ps = pinned_empty(sig.size, np.float64)
+                ps[:] = sig
+                sig = ps
+            self.batches.append((sig, sig_off, seqs, seq_off, len(reads)))
+            del reads
+        self.samples_of = [int(b[1][-1]) for b in self.batches]
+
+    @classmethod
+    def get(cls, name, rank, args, model_cache, workdir):
+        key = (name, rank)
+        if key not in cls._cache:
+            cls._cache[key] = cls(name, rank, args, model_cache, workdir)
+        return cls._cache[key]
+
+
+def measure(al, wl: Workload, args, steps: int, warmup: int, step0: int, mode: str, exch, sync):
+    """`warmup` untimed steps, then exactly `steps` timed ones (barrier + device synchronisation on both sides). Returns the
+    raw sums; `exch` (N > 1) is the exchange of every step: the library's own RCCL path (dyn_comm_*)."""
+    depth = max(1, args.depth)
+    if max(b[4] for b in wl.batches) > 1536:
+        # each ticket in flight holds its samples twice (pinned staging, device): 4 batches of 4 096 reads overlap everything
+        depth = min(depth, 4)
+    free_results: list = []  # result objects are reused: fresh 50 MB arrays per batch would be page-faulted in every time
+    kern = collections.Counter()
+    launches = collections.Counter()
+    done_steps = [0]
+    exch_ms: list = []
+
+    def submit(j):
+        sig, sig_off, seqs, seq_off, _n = wl.batches[j % wl.n_batches]
+        if mode == "train":
+            return al.train_async(sig, sig_off, seqs, seq_off, pooled=False, emissions=False)
+        out = free_results.pop() if free_results else None
+        return al.align_async(sig, sig_off, seqs, seq_off, True, out=out)
+
+    def finish(t, timed):
+        res = t.wait()  # results are in host arrays from here on
+        if exch is not None:
+            te = time.perf_counter()
+            exch.step(t, mode)
+            exch_ms.append((time.perf_counter() - te) * 1e3)
+        if timed:
+            tm = t.timing()
+            share = tm["launch_share"]
+            if tm["launches"] == 0 and tm["reads_ok"]:
+                # a ticket of the RESIDENT read queue: no launch of its own -- ms_* are its reads' wave time / waves, which add up
+                # over tickets; the session kernels' own durations come from al.session_stats() around the timed region
+                share = 1.0
+                launches["resident_tickets"] += 1
+            else:
+                # tickets that waited together were merged into ONE launch: each reports that launch's timing and its share of it
+                launches["classic_ms_dp"] += tm["ms_dp"] * share
+            for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy",
+                        "ms_backward_strict", "ms_forward_strict"):
+                kern[key] += tm[key] * share
+            for key in ("launches", "lp_inplace", "cert_fallbacks", "cert_rows"):
+                launches[key] += tm[key] * share
+            for key in ("cells", "reads_strict"):
+                launches[key] += tm[key]
+            launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
+            launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
+            done_steps[0] += 1
+        t.close()
+        if mode == "align":
+            free_results.append(res)
+        return res
+
+    def run(first, count, timed):
+        q = collections.deque()
+        last = None
+        for s_ in range(first, first + count):
+            if len(q) >= depth:
+                last = finish(q.popleft(), timed)
+            q.append(submit(s_))
+        while q:
+            last = finish(q.popleft(), timed)
+        return last
+
+    run(step0, warmup, False)
+    sync()
+    warm_exch = list(exch_ms)
+    exch_ms.clear()
+    sess0 = al.session_stats()  # (closes the warm-up's session: the timed region starts with an idle pipeline and no resident wave)
+    t0 = time.perf_counter()
+    last = run(step0 + warmup, steps, True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    sess1 = al.session_stats()
+    sess = {k_: sess1[k_] - sess0[k_] for k_ in sess1 if k_ != "wave_occupancy"}
+    n_samples = sum(wl.samples_of[s_ % wl.n_batches] for s_ in range(step0 + warmup, step0 + warmup + steps))
+    n_reads = sum(wl.batches[s_ % wl.n_batches][4] for s_ in range(step0 + warmup, step0 + warmup + steps))
+    return {"elapsed": elapsed, "kern": kern, "launches": launches, "sess": sess, "steps_done": done_steps[0], "last": last, "depth": depth,
+            "samples": n_samples, "reads": n_reads, "exchange_ms": exch_ms, "warmup_exchange_ms": warm_exch}
+
+
+def roofline_of(m: dict, workload: str, mode: str, args, profile: dict) -> dict:
+    """the dominant kernel's ALGORITHMIC bytes over its duration (HIP events on the kernel's own stream: one
+    interval per launch -- with the resident read queue one per SESSION, the waves stay on the chip across batches -- and
+    launches on one stream never overlap, so the sum is the union of the intervals)."""
+    kern, launches, sess = m["kern"], m["launches"], m["sess"]
+    steps = max(1, m["steps_done"])
+    cells_total = launches["cells"]
+    n_launch = max(1e-9, launches["launches"] + sess["sessions"])
+    kernel_ms_total = launches["classic_ms_dp"] + sess["ms"]
+    ms_dp = kernel_ms_total / n_launch
+    cells_per_launch = cells_total / n_launch
+    inplace = bool(launches["lp_inplace"])
+    resident = bool(sess["sessions"]) and not launches["launches"]
+    if mode == "train":
+        kname = "k_read_queue<JOB_TRAIN> (per read: backward sweep, forward sweep + Baum-Welch statistics)"
+        bpc_f, tkey, survey_bpc = KTRAIN_BYTES_PER_CELL, "train", 32.0
+    else:
+        kname = ("k_session (resident waves; per read: backward, forward + posterior + posterior-Viterbi, traceback)" if resident
+                 else "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else ""))
+        bpc_f, tkey, survey_bpc = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "align", 64.125
+    bpc = KBWD_BYTES_PER_CELL + bpc_f
+    secs = kernel_ms_total * 1e-3
+    achieved = cells_total * bpc / secs / 1e9 if secs else 0.0
+    # counters are quoted from the committed rocprofv3 --pmc passes over this command, per lattice cell, and only for the
+    # workload and layout they were measured on (profiles/traffic.json: what was run, the units, the gfx950 correction)
+    tinfo = (profile or {}).get(tkey) or {}
+    per_cell_ok = workload == tinfo.get("workload") and not args.reads and not inplace and tinfo.get("cells_per_launch")
+    t_per_cell = tinfo["bytes_per_launch"] / tinfo["cells_per_launch"] if per_cell_ok else None
+    valu_per_cell = tinfo.get("valu_wave_instructions_per_cell") if per_cell_ok else None
+    share = lambda key: kern[key] / kern["ms_dp"] if kern["ms_dp"] else 0.0
+    occ = (kern["wave_occupancy"] + (sess["wave_cycles_busy"] / sess["wave_cycles_life"] * sess["sessions"] if sess["wave_cycles_life"] else 0.0)) / n_launch
+    r = {
+        # the roofline `frac` is taken against (the contract's "hbm" | "mfma"); what actually binds the kernel is named beside it
+        "bound": "hbm",
+        "binding_limit": "fp64 VALU issue under the package power cap (DESIGN.md section 7: the access pattern alone tops out at 5.4-7.0 TB/s, "
+                         "the kernel issues at valu_issue_frac of the fp64 rate while the shader clock sits at ~2.1 of 2.4 GHz): neither HBM nor MFMA",
+        "kernel": kname,
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": int(round(t_per_cell * cells_per_launch)) if t_per_cell else None,
+        "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per lattice cell, round %s) x cells_per_launch" % (profile or {}).get("round")) if t_per_cell else None,
+        "traffic_over_algorithmic": round(t_per_cell / bpc, 3) if t_per_cell else None,
+        # the same launches priced at the HBM bytes the counters saw, and at SURVEY 8(d)'s own three-pass accounting
+        "frac_counter_traffic": round(cells_total * t_per_cell / secs / 1e9 / HBM_PEAK_GBPS, 4) if t_per_cell and secs else None,
+        "survey_accounting": {"bytes_per_cell": survey_bpc, "frac": round(cells_total * survey_bpc / secs / 1e9 / HBM_PEAK_GBPS, 4) if secs else None,
+                              "note": "SURVEY.md 8(d) prices the reference's formulation (forward, backward + posterior, Viterbi as separate passes "
+                                      "over stored matrices); this design runs backward first and fuses the rest into one sweep: %.3g B per cell "
+                                      "instead of %.3g (the counters confirm it), so priced at the survey's bytes the same launches read above "
+                                      "1 of peak -- not a fraction, the stated deviation" % (bpc, survey_bpc)},
+        # VALU wave-instructions per cell (committed SQ counter pass) x 64 lanes over the fp64 issue peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+        "valu_issue_frac": round(cells_total * valu_per_cell * 64 / secs / VALU_F64_PEAK_LANE_OPS, 4) if valu_per_cell and secs else None,
+        "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": round(n_launch, 3),
+        "cells_total": int(cells_total), "kernel_ms_total": round(kernel_ms_total, 3), "avg_launch_ms": round(ms_dp, 3),
+        # share of wave time per phase (device cycle counters)
+        "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
+                            "waiting_for_pages": round(kern["wave_wait_share"] / n_launch, 4)},
+        "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(kernel_ms_total * share("ms_backward"), 3),
+                                      "frac": round(cells_total * KBWD_BYTES_PER_CELL / (kernel_ms_total * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
+                   "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(kernel_ms_total * share("ms_forward"), 3),
+                                     "frac": round(cells_total * bpc_f / (kernel_ms_total * share("ms_forward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_forward") else None}},
+        # classic launches: sum of wave lifetimes / (waves x longest lifetime), averaged over launches; resident queue: busy /
+        # lifetime wave-cycles of the sessions (a wave is busy from claiming a read to releasing its results)
+        "wave_occupancy": round(occ, 4),
+        "batches_per_launch": round(steps / n_launch, 3),
+        "resident_queue": ({"sessions": sess["sessions"], "tickets": sess["tickets"], "reads": sess["reads"], "ms": round(sess["ms"], 3),
+                            "wave_cycles_busy": sess["wave_cycles_busy"], "wave_cycles_idle": sess["wave_cycles_idle"],
+                            "wave_cycles_life": sess["wave_cycles_life"], "waves": sess["waves"], "aborted": sess["aborted"]} if sess["sessions"] else None),
+        "page_pool": {"pages": launches["pool_pages"], "rows_per_page": launches["page_rows"],
+                      "reads_with_reserved_pages": launches["n_static"], "waves": launches["n_waves"]},
+    }
+    return r
+
+
+class Exchange:
+    """N > 1: the exchange BASELINE.json names, through the library's OWN RCCL path (dyn_comm_*, rccl_comm.cpp) -- not
+    torch.distributed, which only hands the 128-byte communicator id round and brackets the timed region.
+    align: dyn_comm_gather_counts + dyn_comm_gather_rows (8-byte count all-gather, then ONE ncclSend per peer / ncclRecv per
+    peer on the root inside a group: each peer's rows cross its own xGMI link once, straight from the batch's device rows; on
+    rank 0 they land in page-locked host memory). train: dyn_comm_allreduce_pooled (ncclAllReduce, sum, in place on the
+    device-resident (w, s1, s2)[4^k])."""
+
+    def __init__(self, dist, torch, rank, world, device, coll_dev, cap_rows_per_rank, num_kmers):
+        from dynamont_amd._dynamont import RcclComm, pinned_empty
+        import numpy as np
+        uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        self.comm = RcclComm(bytes(uid.cpu().numpy().tobytes()), rank, world, device)
+        self.rank, self.world, self.num_kmers = rank, world, num_kmers
+        self.rows = pinned_empty(max(1, cap_rows_per_rank * world), RcclComm.ROW) if rank == 0 else None
+        self.rows_gathered = 0
+
+    def step(self, ticket, mode):
+        if mode == "train":
+            self.comm.allreduce_pooled(ticket, self.num_kmers)
+        else:
+            _rows, counts = self.comm.gather_rows(ticket, root=0, out=self.rows)
+            self.rows_gathered += int(counts.sum())
+
+    def close(self):
+        self.comm.close()
+
+
+class RehearsalExchange:
+    """DYN_BENCH_ONE_DEVICE=1 only (control-flow rehearsal of N ranks on a 1-GPU box, never a measurement): RCCL cannot put
+    two ranks on one device, so the exchange is stood in for by a torch.distributed gather / all-reduce of the ticket's HOST
+    results, padded to the largest batch. The line says so (`exchange.implementation`)."""
+
+    def __init__(self, dist, torch, rank, world, cap_rows_per_rank, num_kmers):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.cap, self.num_kmers = max(1, cap_rows_per_rank), num_kmers
+        self.n_ranks = dist.get_world_size()
+        self.rows_gathered = 0
+        self.comm = self  # (.n_ranks)
+
+    def step(self, ticket, mode):
+        torch, dist = self.torch, self.dist
+        if mode == "train":
+            t = torch.zeros(3 * self.num_kmers, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        res = ticket.result
+        n = int(res.seg_offsets[res.n]) if hasattr(res, "seg_offsets") else 0
+        buf = torch.zeros(1 + self.cap, dtype=torch.float64)
+        buf[0] = n
+        if n:
+            buf[1:1 + n] = torch.from_numpy(res.probabilities[:n].copy())
+        out = [torch.zeros_like(buf) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(buf, out, dst=0)
+        if self.rank == 0:
+            self.rows_gathered += int(sum(float(o[0]) for o in out))
+
+    def close(self):
+        pass
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -195,38 +459,27 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): the line would not be an N = {args.gpus} measurement")
     n_gpus = world
     workload = args.workload or ("cfg5_share" if args.mode == "train" else ("cfg2" if n_gpus == 1 else "cfg4_share"))
-
-    from dynamont_amd import synth
-    cfgname, per_batch, n_batches = WORKLOADS[workload]
-    cfg = dict(synth.CONFIGS[cfgname])
-    if per_batch:
-        cfg["n_reads"] = per_batch
-    if args.reads:
-        cfg["n_reads"] = args.reads
-    n_batches = max(1, args.batches or n_batches)
-    pore = cfg["pore"]
-    _, rna, k = synth.PORES[pore]
     workdir = tempfile.mkdtemp(prefix=f"dyn_bench_r{rank}_")
-    model_path = synth.write_model(os.path.join(workdir, f"syn{k}.model"), k, seed=7, stdev=0.25 if k == 5 else 0.15)
+    model_cache: dict = {}
+    wl = Workload.get(workload, rank, args, model_cache, workdir)
 
     cpu_proc = cpu_out = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cpu_proc, cpu_out = start_cpu_baseline(args, workload, model_path, workdir)
+        cpu_proc, cpu_out = start_cpu_baseline(args, workload, wl.model_path, workdir)
         # the CPU sample uses every host core: let it finish before timing the GPU
         _, err = cpu_proc.communicate()
         if cpu_proc.returncode != 0:
             print("cpu baseline failed:\n" + err.decode(errors="replace")[-2000:], file=sys.stderr)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: dynamont_amd has no CPU compute path")
     # Rehearsal hooks (control-flow checks on a 1-GPU box; never set by the driver):
-    #   DYN_BENCH_BACKEND=gloo   use gloo instead of nccl/RCCL
+    #   DYN_BENCH_BACKEND=gloo   torch's bracket collectives over gloo instead of nccl/RCCL (the exchange itself is always dyn_comm_*)
     #   DYN_BENCH_ONE_DEVICE=1   every rank uses cuda:0
-    #   DYN_BENCH_FORCE_DIST=1   run the collectives even with a single rank (exercises RCCL on one GPU)
+    #   DYN_BENCH_FORCE_DIST=1   run the exchange even with a single rank (exercises dyn_comm_* on one GPU)
     backend = os.environ.get("DYN_BENCH_BACKEND", "nccl")
     if os.environ.get("DYN_BENCH_ONE_DEVICE"):
         local_rank = 0
@@ -246,163 +499,41 @@ def main():
     coll_dev = dev if backend == "nccl" else "cpu"
 
     from dynamont_amd import Aligner, _native
-    from dynamont_amd._dynamont import AlignBatchResult, pinned_empty
     assert "torch" in sys.modules and _native._lib is None, "torch must be imported before libdynamont_mi.so is loaded"
-
-    # ---- the stream of distinct batches, in caller-owned host arrays ----------------------------
-    _, mean, sd = synth.read_model_file(model_path)
-    batches = []
-    for j in range(n_batches):
-        reads = synth.make_reads(cfg["seed"] + 1000 * rank + 100003 * j, cfg["n_reads"], pore, mean, sd, cfg["n_bases"], polya=cfg.get("polya"))
-        sig, sig_off, seqs, seq_off = synth.pack_reads(reads)
-        if args.pinned_inputs:
-            ps = pinned_empty(sig.size, np.float64)
-            ps[:] = sig
-            sig = ps
-        batches.append((sig, sig_off, seqs, seq_off, len(reads)))
-        del reads
-    samples_of = [int(b[1][-1]) for b in batches]
-
-    al = Aligner(model_path, pore, mode="basic", band=400, device=local_rank)
-    al.set_strict(args.strict)
-    depth = max(1, args.depth)
-    if max(b[4] for b in batches) > 1536:
-        # batches of more reads than the engine merges (its cap: three reads per wave slot, two tickets at least) gain nothing
-        # from waiting tickets; each ticket in flight holds its samples twice (pinned staging, device): 4 overlap everything
-        depth = min(depth, 4)
-    free_results: list = []  # result objects are reused: fresh 50 MB arrays per batch would be page-faulted in every time
-
-    # ---- N > 1: fixed-size buffers for the gather (sizes differ per rank and batch), two sets: the gather of step k
-    # is in flight while step k+1 fills the other set
-    NBUF = 2
-    send_bufs = gather_sets = host_sets = None
-    gather_pending = [None] * NBUF
-    if use_dist and args.mode == "align":
-        cap_local = max(al.segment_capacity(b[3]) for b in batches)
-        t = torch.tensor([cap_local], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cap_max = int(t.item())
-        # [16-byte header: valid bytes][rows ...]
-        send_bufs = [torch.zeros(16 + cap_max * 16, dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-        if rank == 0:
-            gdev = dev if backend == "nccl" else "cpu"
-            gather_sets = [[torch.empty(16 + cap_max * 16, dtype=torch.uint8, device=gdev) for _ in range(n_gpus)] for _ in range(NBUF)]
-            if backend == "nccl":  # where the gathered rows end up: page-locked host memory of rank 0
-                host_sets = [[torch.empty(16 + cap_max * 16, dtype=torch.uint8).pin_memory() for _ in range(n_gpus)] for _ in range(NBUF)]
-
-    def drain_gather(slot):
-        """complete the gather that last used this buffer set; rank 0 then brings the rows to host memory"""
-        work = gather_pending[slot]
-        if work is None:
-            return
-        gather_pending[slot] = None
-        work.wait()  # NCCL: the current stream waits for the collective
-        if rank == 0 and host_sets is not None:
-            for r in range(n_gpus):
-                host_sets[slot][r].copy_(gather_sets[slot][r], non_blocking=True)
-
-    def wrap(ptr, nbytes, typestr="|u1", count=None):
-        class _A:
-            __cuda_array_interface__ = {"shape": (count if count is not None else nbytes,), "typestr": typestr,
-                                        "data": (ptr, False), "version": 2}
-        return torch.as_tensor(_A(), device=dev)
-
-    kern = collections.Counter()
-    launches = collections.Counter()
-    done_steps = [0]
-    gather_step = [0]
-
-    def submit(j):
-        sig, sig_off, seqs, seq_off, _n = batches[j % n_batches]
-        if args.mode == "train":
-            return al.train_async(sig, sig_off, seqs, seq_off, pooled=False, emissions=False)
-        out = free_results.pop() if free_results else None
-        return al.align_async(sig, sig_off, seqs, seq_off, True, out=out)
-
-    def finish(t, timed):
-        res = t.wait()  # results are in host arrays from here on
-        if use_dist:
-            if args.mode == "train":  # config 5: sum all-reduce of the pooled sufficient statistics (3 * 4^k doubles)
-                ptr, cnt = t.device_pooled()
-                pooled_t = wrap(ptr, cnt * 8, "<f8", cnt)
-                if backend == "nccl":
-                    dist.all_reduce(pooled_t, op=dist.ReduceOp.SUM)
-                    torch.cuda.current_stream().synchronize()  # the batch's buffers are recycled after close()
-                else:
-                    h = pooled_t.cpu()
-                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            else:  # config 4: gather of the segment rows to rank 0, device to device over xGMI, asynchronous
-                slot = gather_step[0] % NBUF
-                gather_step[0] += 1
-                drain_gather(slot)
-                ptr, cap, _ = t.device_results()
-                nbytes = cap * 16
-                sb = send_bufs[slot]
-                sb[:8].copy_(torch.tensor([nbytes], dtype=torch.int64).view(torch.uint8))
-                if nbytes:
-                    sb[16:16 + nbytes].copy_(wrap(ptr, nbytes))
-                torch.cuda.current_stream().synchronize()  # the batch's device buffers are recycled after close()
-                if backend == "nccl":
-                    gather_pending[slot] = dist.gather(sb, gather_sets[slot] if rank == 0 else None, dst=0, async_op=True)
-                else:  # gloo rehearsal: host hop
-                    gather_pending[slot] = dist.gather(sb.cpu(), gather_sets[slot] if rank == 0 else None, dst=0, async_op=True)
-        if timed:
-            # tickets that waited together are merged into ONE launch by the engine: each reports that launch's timing and
-            # its share of it (dyn_timing.launch_share), so sums over tickets count every launch once
-            tm = t.timing()
-            share = tm["launch_share"]
-            if tm["launches"] == 0 and tm["reads_ok"]:
-                # a ticket of the RESIDENT read queue: no launch of its own -- ms_* are its reads' wave time / waves, which add up
-                # over tickets; the session kernels' own durations come from al.session_stats() around the timed region
-                share = 1.0
-                launches["resident_tickets"] += 1
-            else:
-                launches["classic_ms_dp"] += tm["ms_dp"] * share
-            for key in ("ms_dp", "ms_backward", "ms_forward", "ms_trace", "ms_total", "wave_wait_share", "wave_occupancy",
-                        "ms_backward_strict", "ms_forward_strict"):
-                kern[key] += tm[key] * share
-            for key in ("launches", "lp_inplace", "cert_fallbacks", "cert_rows"):
-                launches[key] += tm[key] * share
-            for key in ("cells", "reads_strict"):
-                launches[key] += tm[key]
-            launches["pool_pages"], launches["page_rows"] = tm["pool_pages"], tm["page_rows"]
-            launches["n_static"], launches["n_waves"] = tm["n_static"], tm["n_waves"]
-            done_steps[0] += 1
-        t.close()
-        if args.mode == "align":
-            free_results.append(res)
-        return res
-
-    def run(first, count, timed):
-        q = collections.deque()
-        last = None
-        for s in range(first, first + count):
-            if len(q) >= depth:
-                last = finish(q.popleft(), timed)
-            q.append(submit(s))
-        while q:
-            last = finish(q.popleft(), timed)
-        for slot in range(NBUF):  # the gathers still in flight (and rank 0's host copies) belong to these steps
-            drain_gather(slot)
-        return last
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(0, args.warmup, False)
-    sync()
-    sess0 = al.session_stats()  # (closes the warm-up's session: the timed region starts with an idle pipeline and no resident wave)
-    t0 = time.perf_counter()
-    last = run(args.warmup, args.steps, True)
-    sync()
-    elapsed = time.perf_counter() - t0
-    sess1 = al.session_stats()
-    sess = {k_: sess1[k_] - sess0[k_] for k_ in sess1 if k_ != "wave_occupancy"}
+    profile = load_traffic()
+    al = Aligner(wl.model_path, wl.pore, mode="basic", band=400, device=local_rank)
+    al.set_strict(args.strict)
+    exch = None
+    reserved_cus = 0
+    if use_dist:
+        # RCCL's kernels (37 KB of LDS, 248-256 registers) do not fit beside a resident session: a few CUs stay free for them
+        reserved_cus = args.reserve_cus
+        al.set_session_mode(not args.no_sessions, reserved_cus)
+        cap_local = max(al.segment_capacity(b[3]) for b in wl.batches) if args.mode == "align" else 0
+        t = torch.tensor([cap_local], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if os.environ.get("DYN_BENCH_ONE_DEVICE") and n_gpus > 1:
+            exch = RehearsalExchange(dist, torch, rank, n_gpus, int(t.item()), al.num_kmers)
+        else:
+            exch = Exchange(dist, torch, rank, n_gpus, local_rank, coll_dev, int(t.item()), al.num_kmers)
+    elif args.no_sessions:
+        al.set_session_mode(False)
 
-    n_samples = sum(samples_of[s % n_batches] for s in range(args.warmup, args.warmup + args.steps))
-    n_reads_done = sum(batches[s % n_batches][4] for s in range(args.warmup, args.warmup + args.steps))
+    m = measure(al, wl, args, args.steps, args.warmup, 0, args.mode, exch, sync)
+    sessions_with_exchange = None
+    if use_dist and not args.no_sessions:
+        # were the exchanges of the WARM-UP steps served beside the resident waves? One that had to wait for a session to end
+        # takes tens of milliseconds (a session only ends when the pipeline has run dry): then the timed steps ran like that too,
+        # and the line says so
+        we = sorted(m["warmup_exchange_ms"] + m["exchange_ms"])
+        sessions_with_exchange = {"median_exchange_ms": round(we[len(we) // 2], 3) if we else None, "max_exchange_ms": round(we[-1], 3) if we else None}
+    elapsed = m["elapsed"]
     per_rank_ms = [elapsed * 1e3]
     if use_dist:
         t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
@@ -410,17 +541,18 @@ def main():
         dist.all_gather(allt, t)
         per_rank_ms = [float(x.item()) * 1e3 for x in allt]
         elapsed = max(per_rank_ms) / 1e3
-        tot = torch.tensor([n_samples, n_reads_done], device=coll_dev, dtype=torch.float64)
+        tot = torch.tensor([m["samples"], m["reads"]], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_samples, total_reads = float(tot[0].item()), float(tot[1].item())
     else:
-        total_samples, total_reads = float(n_samples), float(n_reads_done)
+        total_samples, total_reads = float(m["samples"]), float(m["reads"])
+    last = m["last"]
     ok = int((last.status == 0).sum()) if last is not None else 0
 
-    # ---- secondary: kernels only, inputs resident in HBM (the round-1 headline) -----------------
+    # ---- secondary: kernels only, inputs resident in HBM, ONE batch in one launch (the round-1 headline) -----------------
     resident = None
     if (rank == 0 or use_dist) and not args.no_resident:
-        sig, sig_off, seqs, seq_off, _n = batches[0]
+        sig, sig_off, seqs, seq_off, _n = wl.batches[0]
         with al.batch_packed(sig, sig_off, seqs, seq_off) as b0:
             best = None
             for _ in range(3):
@@ -429,114 +561,48 @@ def main():
                 best = tm0 if best is None or tm0["ms_total"] < best["ms_total"] else best
             resident = best
 
+    def side_record(al_, wl_, steps_, strict_, note):
+        """a secondary workload / mode on the same terms as the headline: own warm-up, own timed region, own roofline"""
+        al_.set_strict(strict_)
+        mm = measure(al_, wl_, args, steps_, 1, 0, args.mode, exch, sync)
+        el, smp, rds = mm["elapsed"], mm["samples"], mm["reads"]
+        if use_dist:
+            t_ = torch.tensor([el, -float(smp)], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
+            el = float(t_[0].item())
+            smp, rds = smp * n_gpus, rds * n_gpus
+        rf = roofline_of(mm, wl_.name, args.mode, args, profile)
+        return {"workload": wl_.name, "strict_mode": {"start": "ties"}.get(strict_, strict_), "steps": steps_, "value": round(smp / el / 1e6, 3), "unit": "Msamp/s",
+                "ms_per_step": round(el * 1e3 / steps_, 3), "reads_per_s": round(rds / el, 1),
+                "strict_reads_per_step": mm["launches"]["reads_strict"] / max(1, mm["steps_done"]),
+                "roofline_frac": rf["frac"], "wave_occupancy": rf["wave_occupancy"], "kernel_ms_total": rf["kernel_ms_total"],
+                "launches": rf["launches"], "batches_per_launch": rf["batches_per_launch"], "batches_in_flight": mm["depth"], "note": note}
+
     # ---- what bit-exactness costs: the same steps on the plain arithmetic (strict mode off), outside the headline region
     plain = None
     if args.mode == "align" and args.strict != "off" and not args.no_plain:
-        keep = (collections.Counter(kern), collections.Counter(launches), done_steps[0])
-        al.set_strict("off")
-        p_steps = min(6, args.steps)
-        run(args.warmup + args.steps, 1, False)
-        sync()
-        sess1 = al.session_stats()  # baseline of the plain leg (its warm-up step's session is closed and counted here)
-        tp = time.perf_counter()
-        run(args.warmup + args.steps + 1, p_steps, True)
-        sync()
-        p_el = time.perf_counter() - tp
-        p_samples = sum(samples_of[s % n_batches] for s in range(args.warmup + args.steps + 1, args.warmup + args.steps + 1 + p_steps))
-        if use_dist:
-            t = torch.tensor([p_el, -float(p_samples)], device=coll_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
-            p_el = float(t[0].item())
-            p_samples *= n_gpus
-        p_sess = al.session_stats()
-        p_launch = max(1e-9, launches["launches"] - keep[1]["launches"] + (p_sess["sessions"] - sess1["sessions"]))
-        p_cells = launches["cells"] - keep[1]["cells"]
-        p_ms = launches["classic_ms_dp"] - keep[1]["classic_ms_dp"] + (p_sess["ms"] - sess1["ms"])
-        plain = {"strict_mode": "off", "steps": p_steps, "value": round(p_samples / p_el / 1e6, 3), "unit": "Msamp/s",
-                 "ms_per_step": round(p_el * 1e3 / p_steps, 3),
-                 "avg_launch_ms": round(p_ms / p_launch, 3), "batches_per_launch": round(p_steps / p_launch, 3),
-                 "cells": p_cells, "kernel_ms": round(p_ms, 3),
-                 "note": "the table softplus alone: equal to the reference on every read without a structural tie, and on "
-                         "3 397 of the 3 400 tie-bearing reads of tests/golden/g10_ties.npz"}
+        plain = side_record(al, wl, min(args.steps, max(6, args.steps // 2)), "off",
+                            "the table softplus alone: equal to the reference on every read without a structural tie, and on "
+                            "3 397 of the 3 400 tie-bearing reads of tests/golden/g10_ties.npz")
         al.set_strict(args.strict)
-        kern.clear(); kern.update(keep[0])
-        launches.clear(); launches.update(keep[1])
-        done_steps[0] = keep[2]
 
     line = None
     if rank == 0:
-        steps = max(1, done_steps[0])
+        steps = max(1, m["steps_done"])
+        kern, launches = m["kern"], m["launches"]
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = total_samples / elapsed / 1e6
-        cells_total = launches["cells"]
-        # launches of the dominant kernel in the timed region: one per (merged) batch -- or, with the resident read queue, one
-        # per SESSION: the waves stay on the chip across batches. Duration: HIP events on the kernel's own stream.
-        n_launch = max(1e-9, launches["launches"] + sess["sessions"])
-        kernel_ms_total = launches["classic_ms_dp"] + sess["ms"]
-        ms_dp = kernel_ms_total / n_launch
-        cells_per_launch = cells_total / n_launch
-        inplace = bool(launches["lp_inplace"])
-        traffic = load_traffic() or {}
-        if args.mode == "train":
-            kname = "k_read_queue<JOB_TRAIN> (per read: backward sweep, forward sweep + Baum-Welch statistics)"
-            bpc_f, tkey = KTRAIN_BYTES_PER_CELL, "train"
-        else:
-            kname = ("k_session (resident waves; per read: backward, forward + posterior + posterior-Viterbi, traceback)" if sess["sessions"] and not launches["launches"]
-                     else "k_read_queue<JOB_ALIGN%s> (per read: backward, forward + posterior + posterior-Viterbi, traceback)" % ("_INPLACE" if inplace else ""))
-            bpc_f, tkey = (KFWD_INPLACE_BYTES_PER_CELL if inplace else KFWD_BYTES_PER_CELL), "align"
-        bpc = KBWD_BYTES_PER_CELL + bpc_f
-        # PMC traffic is only quoted for the workload (and layout) it was measured on
-        tinfo = traffic.get(tkey) or {}
-        tbytes = tinfo.get("bytes_per_launch") if (workload == tinfo.get("workload") and not args.reads and not inplace) else None
-        if tbytes and tinfo.get("cells_per_launch"):
-            # the PMC passes measured launches of ONE batch; a merged launch moves the same bytes per cell
-            tbytes = int(round(tbytes * cells_per_launch / tinfo["cells_per_launch"]))
-        achieved = cells_per_launch * bpc / (ms_dp * 1e-3) / 1e9 if ms_dp else 0.0
-        share = lambda key: kern[key] / kern["ms_dp"] if kern["ms_dp"] else 0.0
-        roofline = {
-            "bound": "hbm", "kernel": kname,
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": tbytes,
-            # NOT a counter of this run: the committed rocprofv3 --pmc passes over the same command (plain arithmetic: the
-            # certified rows move the same bytes), quoted only for the workload and layout they were measured on
-            "traffic_source": ("profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per lattice cell, round %s) x cells_per_launch" % traffic.get("round")) if tbytes else None,
-            "traffic_over_algorithmic": round(tbytes / (cells_per_launch * bpc), 3) if tbytes else None,
-            "bytes_per_cell": bpc, "cells_per_launch": round(cells_per_launch), "launches": round(n_launch, 3),
-            # totals of the timed region (what a rocprofv3 kernel trace of the same tickets adds up to: launches vary in size)
-            "cells_total": int(cells_total), "kernel_ms_total": round(kernel_ms_total, 3),
-            "avg_launch_ms": round(ms_dp, 3),
-            # share of wave time per phase (device cycle counters) and how well the persistent waves were kept busy
-            "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
-                                "waiting_for_pages": round(kern["wave_wait_share"] / n_launch, 4)},
-            # the two sweeps apart: their algorithmic bytes over their share of the launch (they overlap in time only
-            # when waves are out of phase, i.e. in batches of more reads than waves)
-            "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(ms_dp * share("ms_backward"), 3),
-                                          "frac": round(cells_per_launch * KBWD_BYTES_PER_CELL / (ms_dp * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
-                       "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(ms_dp * share("ms_forward"), 3),
-                                         "frac": round(cells_per_launch * bpc_f / (ms_dp * share("ms_forward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_forward") else None}},
-            # classic launches: sum of wave lifetimes / (waves x longest lifetime), averaged over launches; resident queue: busy /
-            # lifetime wave-cycles of the sessions (a wave is busy from claiming a read to releasing its results)
-            "wave_occupancy": round((kern["wave_occupancy"] + (sess["wave_cycles_busy"] / sess["wave_cycles_life"] * sess["sessions"] if sess["wave_cycles_life"] else 0.0)) / n_launch, 4),
-            "resident_queue": ({"sessions": sess["sessions"], "tickets": sess["tickets"], "reads": sess["reads"], "ms": round(sess["ms"], 3),
-                                "wave_cycles_busy": sess["wave_cycles_busy"], "wave_cycles_idle": sess["wave_cycles_idle"],
-                                "wave_cycles_life": sess["wave_cycles_life"], "aborted": sess["aborted"]} if sess["sessions"] else None),
-            # tickets per launch: batches that were waiting while the GPU was busy share one launch (one queue balances
-            # what one read per wave cannot)
-            "batches_per_launch": round(steps / n_launch, 3),
-            "page_pool": {"pages": launches["pool_pages"], "rows_per_page": launches["page_rows"],
-                          "reads_with_reserved_pages": launches["n_static"], "waves": launches["n_waves"]},
-        }
+        roofline = roofline_of(m, workload, args.mode, args, profile)
         what = "calc_probabilities=true" if args.mode == "align" else "train()"
         line = {
             "metric": "signal samples resquiggled/sec" if args.mode == "align" else "signal samples trained/sec (Baum-Welch statistics)",
             "value": round(value, 3), "unit": "Msamp/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{workload}: {cfg['n_reads']} synthetic {pore} reads x ~{samples_of[0] // batches[0][4]} samples per batch and GPU, "
-                                   f"synthetic {k}-mer model, --mode basic, band 400, {what}; host arrays -> H2D -> kernels -> D2H -> host arrays",
-                       "reads_per_batch": cfg["n_reads"], "samples_per_batch": samples_of[0], "distinct_batches": n_batches,
-                       "batches_in_flight": depth, "caller_memory": "pinned" if args.pinned_inputs else "pageable",
+            "config": {"workload": f"{workload}: {wl.cfg['n_reads']} synthetic {wl.pore} reads x ~{wl.samples_of[0] // wl.batches[0][4]} samples per batch and GPU, "
+                                   f"synthetic {wl.k}-mer model, --mode basic, band 400, {what}; host arrays -> H2D -> kernels -> D2H -> host arrays",
+                       "reads_per_batch": wl.cfg["n_reads"], "samples_per_batch": wl.samples_of[0], "distinct_batches": wl.n_batches,
+                       "batches_in_flight": m["depth"], "caller_memory": "pinned" if args.pinned_inputs else "pageable",
                        "strict_mode": {"start": "ties"}.get(args.strict, args.strict),
                        "parallelism": f"reads sharded x{n_gpus}" + ((", RCCL gather of segment rows to rank 0" if args.mode == "align" else ", RCCL all-reduce of pooled statistics") if use_dist else "")},
             "reads_per_s": round(total_reads / elapsed, 1),
@@ -546,30 +612,56 @@ def main():
             # restated glibc (7 registers per row)
             "certified_rows_per_step": launches["cert_rows"] / steps,
             "certificate_fallbacks_per_row": round(launches["cert_fallbacks"] / launches["cert_rows"], 5) if launches["cert_rows"] else None,
+            # per step: the tickets' wave time / waves (resident queue) or launch time x share (one launch per batch)
             "kernel_ms_per_step": {k_: round(v / steps, 3) for k_, v in kern.items() if k_.startswith("ms_")},
+            # ONE batch alone in one launch, inputs resident in HBM (the round-1 headline; no ratio is formed with it: a launch of
+            # 1 024 reads on 1 024 waves lasts as long as its slowest read, the resident queue has no such tail)
             "kernel_resident_Msamp_s": round(resident["samples"] / resident["ms_total"] / 1e3, 3) if resident and resident["ms_total"] else None,
-            "pipeline_efficiency": round((total_samples / n_gpus / elapsed / 1e6) / (resident["samples"] / resident["ms_total"] / 1e3), 4) if resident and resident["ms_total"] else None,
             "roofline": roofline,
         }
         if use_dist:
-            line["rccl_ranks"] = dist.get_world_size()
-            line["collective_backend"] = backend
+            line["rccl_ranks"] = exch.comm.n_ranks
+            assert line["rccl_ranks"] == n_gpus, "the exchange must span every rank of the measurement"
+            line["exchange"] = {
+                "implementation": "REHEARSAL on one device (DYN_BENCH_ONE_DEVICE): torch.distributed stand-in for the exchange, not a measurement"
+                                  if isinstance(exch, RehearsalExchange) else "dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp): " +
+                                  ("dyn_comm_gather_counts + dyn_comm_gather_rows -- 8-byte count all-gather, then one ncclSend per peer / ncclRecv per peer "
+                                   "on rank 0 in one group, from the batch's device rows; rank 0 copies the gathered rows to page-locked host memory"
+                                   if args.mode == "align" else "dyn_comm_allreduce_pooled -- ncclAllReduce(sum, double) in place on the device-resident (w, s1, s2)[4^k]"),
+                "bracket_collectives": f"torch.distributed ({backend}): communicator id broadcast, barriers, the reduction of the ranks' clocks",
+                "per_step_ms_rank0": {"median": round(sorted(m["exchange_ms"])[len(m["exchange_ms"]) // 2], 3), "max": round(max(m["exchange_ms"]), 3)} if m["exchange_ms"] else None,
+                "rows_gathered_rank0": exch.rows_gathered if args.mode == "align" else None,
+                "resident_queue": (not args.no_sessions), "reserved_cus": reserved_cus, "observed": sessions_with_exchange,
+            }
+            line["collective_backend"] = "rehearsal" if isinstance(exch, RehearsalExchange) else "rccl (dyn_comm_*)"
             if args.mode == "align":
-                line["gather_lands_in"] = "rank0_pinned_host" if backend == "nccl" else "rank0_host"
+                line["gather_lands_in"] = "rank0_pinned_host"
             line["per_rank_ms"] = [round(x, 2) for x in per_rank_ms]
         if cpu_out and os.path.exists(cpu_out):
             line["cpu_baseline"] = json.load(open(cpu_out))
         elif n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         if plain is not None:
-            # the same algorithmic bytes over the plain kernel's launch time: what `roofline.frac` was before bit-exact
-            # borders became the default (in cfg2 every wave holds ONE read, so the default launch lasts as long as its
-            # slowest, certified read)
-            if plain.get("kernel_ms"):
-                plain["roofline_frac"] = round(plain.pop("cells") * bpc / (plain.pop("kernel_ms") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             line["plain_arithmetic"] = plain
         assert line["n_gpus"] == args.gpus
+
+    # ---- N = 1: the workloads the headline does not show (same clock discipline, each with its own roofline) -------------
+    if n_gpus == 1 and not use_dist and args.mode == "align" and workload == "cfg2" and not args.reads:
+        if not args.no_polya:
+            # real direct-RNA reads start with their polyA tail: EVERY read then carries a structural tie and runs the certified
+            # sweeps (segment.py:155-158 pads every RNA read; the tail follows the pad) -- the headline's synthetic reads: 26 %
+            wl_p = Workload.get("cfg2_polya", rank, args, model_cache, workdir)
+            line["cfg2_polya"] = side_record(al, wl_p, args.steps, args.strict,
+                                             "cfg2 with 20-150 A's behind the pad: every read flagged, the certified sweeps' full price")
+        if not args.no_scale_ref:
+            # what `bench.py --gpus N` runs per rank (configs[3]'s per-GPU share), on this one GPU: the N = 1 point of the
+            # scaling curve, like for like
+            wl_s = Workload.get("cfg4_share", rank, args, model_cache, workdir)
+            line["scale_ref"] = side_record(al, wl_s, max(4, min(8, args.steps)), args.strict,
+                                            "configs[3]'s per-GPU share (4 096 reads per batch), the workload of every rank at N > 1, without the exchange")
     al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
+    if exch is not None:
+        exch.close()
     if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
         try:
             strict = {"start": "ties"}.get(args.strict, args.strict)

@@ -483,6 +483,13 @@ class Aligner:
         if rc != N.DYN_OK:
             raise ValueError(self.last_error() or "strict mode must be 0 (off), 1 (ties) or 2 (all)")
 
+    def set_session_mode(self, enabled: bool, reserved_cus: int = 0) -> None:
+        """dyn_aligner_set_session_mode: the resident read queue on / off, and compute units kept free of it (for RCCL's
+        kernels, which do not fit beside a resident session)."""
+        rc = self._L.dyn_aligner_set_session_mode(self._h, 1 if enabled else 0, int(reserved_cus))
+        if rc != N.DYN_OK:
+            _raise(rc, self.last_error())
+
     def session_stats(self) -> dict:
         """dyn_aligner_session_stats: totals over the closed sessions of the resident read queue (closes an open one and
         waits for its waves first). ``wave_occupancy`` = busy / lifetime wave-cycles."""
@@ -761,16 +768,20 @@ class RcclComm:
 
     __del__ = close
 
-    def gather_rows(self, batch, root: int = 0):
+    def gather_rows(self, batch, root: int = 0, out=None):
         """(rows, counts): on ``root`` a structured array of every rank's segment rows in rank order; elsewhere rows is
         None. ``batch``: an aligned Batch or an AsyncBatch ticket. Two collectives: the counts (dyn_comm_gather_counts),
         then -- root's buffer allocated for exactly their sum -- the rows. A rank whose batch failed still takes part in
-        both (with 0 rows) before its error is raised here, so its peers never block on it."""
+        both (with 0 rows) before its error is raised here, so its peers never block on it. ``out`` (root): a ROW array to
+        receive into (e.g. ``pinned_empty(n, RcclComm.ROW)``: the copy off the device is then a plain DMA); one that is too
+        small is replaced by a fresh array."""
         counts = np.zeros(self.n_ranks, dtype=np.uint64)
         rc1 = self._L.dyn_comm_gather_counts(self._h, batch._h, _ptr(counts, N.c_u64_p))
         err1 = (self._L.dyn_comm_last_error(self._h) or b"").decode()
         total = int(counts.sum())
-        rows = np.empty(max(1, total), dtype=self.ROW) if self.rank == root else None
+        rows = None
+        if self.rank == root:
+            rows = out if (out is not None and out.dtype == self.ROW and out.size >= max(1, total)) else np.empty(max(1, total), dtype=self.ROW)
         rc = self._L.dyn_comm_gather_rows(self._h, batch._h, int(root), rows.ctypes.data if rows is not None else None,
                                           total if rows is not None else 0, None)
         if rc1 != N.DYN_OK:

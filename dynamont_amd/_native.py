@@ -89,6 +89,7 @@ SIGNATURES = {
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_session_stats": (C.c_int, [C.c_void_p, C.POINTER(DynSessionStats)]),
+    "dyn_aligner_set_session_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
     "dyn_aligner_set_train_zcheck": (C.c_int, [C.c_void_p, C.c_int]),

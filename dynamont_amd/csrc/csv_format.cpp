@@ -71,7 +71,15 @@ inline char* put_prob6(char* p, double x) {
       return p;
     }
   }
-  return p + std::snprintf(p, 48, "%.6f", x);
+  // Ties of the scaled product, and values no posterior can take (negative, non-finite, >= 4e9: the caller's arrays, not the
+  // device's). "%.6f" of a double can be 317 characters long; a row's slot holds 48 (kRowBound), and snprintf RETURNS the
+  // untruncated length -- found by tools/sanitize/fuzz_host.cpp (round 5). What does not fit is written as "%.17g" instead
+  // (<= 24 characters, the value still exact): outside the reference's range of values there is no reference text to match.
+  char buf[352];
+  int n = std::snprintf(buf, sizeof buf, "%.6f", x);
+  if (n < 0 || n > 47) n = std::snprintf(buf, sizeof buf, "%.17g", x);
+  std::memcpy(p, buf, (size_t)n);
+  return p + n;
 }
 
 struct Args {

@@ -481,6 +481,52 @@ static bool model_allows_strict(const dynhost::PoreModel& m) {
   return true;
 }
 
+// The session stream: CU-masked, hence a hardware queue of its own. reserved_cus CUs are left OUT of the mask: a resident
+// session occupies every CU it may use (one workgroup each, 150 KB of LDS), and a kernel of another stream that needs more
+// than the 13 KB of LDS and 152 registers per lane they leave free -- RCCL's (37 KB, 248-256 registers) -- would otherwise
+// not start before the session ends.
+static int make_session_stream(dyn_aligner* a, int reserved_cus) {
+  if (a->s_session) {
+    (void)hipStreamDestroy(a->s_session);
+    a->s_session = nullptr;
+  }
+  a->sess_cus = std::max(1, a->n_cus - std::max(0, reserved_cus));
+  std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0u);
+  for (int c = 0; c < a->sess_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+  if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    a->s_session = nullptr;
+    return DYN_ERR_DEVICE;
+  }
+  if (!a->sess_flags && hipHostMalloc(reinterpret_cast<void**>(&a->sess_flags), SESSION_FLAGS * 4, hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(a->s_session);
+    a->s_session = nullptr;
+    a->sess_flags = nullptr;
+    return DYN_ERR_DEVICE;
+  }
+  return DYN_OK;
+}
+
+int dyn_aligner_set_session_mode(dyn_aligner* a, int enabled, int reserved_cus) {
+  if (!a || reserved_cus < 0) return DYN_ERR_INVALID_ARGUMENT;
+  if (a->host_only) return DYN_OK;
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (int rc = need_device(a)) return rc;
+  if (int rc = session_quiesce(a)) return rc;
+  if (!enabled) {
+    if (a->s_session) (void)hipStreamDestroy(a->s_session);
+    a->s_session = nullptr;
+    return DYN_OK;
+  }
+  if (reserved_cus >= a->n_cus) return DYN_ERR_INVALID_ARGUMENT;
+  if (make_session_stream(a, reserved_cus) != DYN_OK) {
+    a->last_error = "hipExtStreamCreateWithCUMask failed: the handle runs one launch per batch";
+    return DYN_ERR_DEVICE;
+  }
+  return DYN_OK;
+}
+
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap) {
   *out = nullptr;
@@ -539,18 +585,8 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   // (tools/ubench/resident_probe.hip). A CU-masked stream (all CUs enabled) always gets its own. No such stream, or
   // DYN_NO_SESSION=1: the handle runs one launch per batch, as before round 5.
   if (!std::getenv("DYN_NO_SESSION")) {
-    std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0xffffffffu);
-    if (a->n_cus % 32) mask.back() = (1u << (a->n_cus % 32)) - 1u;
-    if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      a->s_session = nullptr;
-    }
-    if (a->s_session && hipHostMalloc(reinterpret_cast<void**>(&a->sess_flags), SESSION_FLAGS * 4, hipHostMallocCoherent) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipStreamDestroy(a->s_session);
-      a->s_session = nullptr;
-      a->sess_flags = nullptr;
-    }
+    const char* rsv = std::getenv("DYN_SESSION_RESERVE_CUS");
+    (void)make_session_stream(a, rsv ? std::atoi(rsv) : 0);  // failure: the handle simply has no resident read queue
     if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.05, std::atof(f));
   }
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
@@ -1545,7 +1581,7 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   sa.e2 = a->model.log_e2;
   sa.idle_limit_ticks = (uint64_t)(a->sess_idle_s * 1e8);
   HIP_TRY(a, hipEventRecord(ss.ev_begin[blk], a->s_session));
-  dynk::launch_session(mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), a->n_cus, a->s_session);
+  dynk::launch_session(mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), a->sess_cus, a->s_session);
   HIP_TRY(a, hipGetLastError());
   HIP_TRY(a, hipEventRecord(ss.ev_end[blk], a->s_session));
   ss.open = true;
@@ -1556,7 +1592,7 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   ss.next_base = 0;
   ss.log_r = log_r;
   ss.arena_pages = arena_pages;
-  ss.n_waves = (uint32_t)a->n_cus * dynk::WAVES_PER_CU;
+  ss.n_waves = (uint32_t)a->sess_cus * dynk::WAVES_PER_CU;
   ss.cells = ss.reads = ss.tickets = 0;
   (void)need;
   return DYN_OK;
@@ -1631,7 +1667,7 @@ int session_plan(dyn_batch* b, bool* use) {
   int log_r = 8;
   uint32_t arena = 0;
   session_geometry(need.max_S, &log_r, &arena);
-  const uint64_t n_waves = (uint64_t)a->n_cus * dynk::WAVES_PER_CU;
+  const uint64_t n_waves = (uint64_t)a->sess_cus * dynk::WAVES_PER_CU;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
   const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + parked_bytes(a->device);
@@ -1673,7 +1709,7 @@ int session_publish(dyn_batch* b) {
     int log_r = 8;
     uint32_t arena = 0;
     session_geometry(max_S, &log_r, &arena);
-    const uint64_t n_waves = (uint64_t)a->n_cus * dynk::WAVES_PER_CU;
+    const uint64_t n_waves = (uint64_t)a->sess_cus * dynk::WAVES_PER_CU;
     SessionNeed need;
     need.n_ok = n_ok;
     need.max_S = max_S;

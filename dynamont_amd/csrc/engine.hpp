@@ -148,6 +148,7 @@ struct dyn_aligner {
   std::unique_ptr<dyneng::Pipeline> pipe;  // started by the first asynchronous submit
   // the resident read queue (guarded by mu)
   hipStream_t s_session = nullptr;   // CU-masked: a hardware queue of its own; nullptr = no sessions on this handle
+  int sess_cus = 0;                  // CUs in its mask = workgroups of a session (n_cus minus what dyn_aligner_set_session_mode reserves)
   dyneng::DevBuf sess_ctl[2], sess_ring[2];
   dyneng::DevBuf sess_anchor;        // out_base of k_session: the address the ticket records' output offsets count from
   std::atomic<bool> sess_open_hint{false};  // mirrors sess.open for readers that do not hold mu

@@ -91,6 +91,8 @@ struct dyn_comm {
   uint64_t* d_counts = nullptr;  // [n_ranks] rows per rank (all-gather target)
   void* d_recv = nullptr;        // root: gathered rows
   size_t recv_bytes = 0;
+  std::vector<void*> retired;    // receive buffers that were outgrown: freed with the communicator (hipFree waits for the whole
+                                 // device, i.e. for the END of a resident read queue -- never in the middle of a run)
   std::string last_error;
   // rows every rank announced in the last dyn_comm_gather_counts (the exchange dyn_comm_gather_rows then performs)
   std::vector<uint64_t> counts;
@@ -167,7 +169,21 @@ int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn
     delete c;
     return DYN_ERR_DEVICE;
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+  // A stream with a hardware queue of its own where the runtime provides one (a CU-masked stream, every CU enabled): an RCCL
+  // kernel waits for its peers while it runs, and whatever shares its hardware queue waits with it -- the copies and small
+  // kernels that feed a resident read queue must not (tools/ubench/resident_probe.hip).
+  {
+    int n_cus = 0;
+    if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cus > 0) {
+      std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
+      for (int k = 0; k < n_cus; ++k) mask[(size_t)k / 32] |= 1u << (k % 32);
+      if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        c->stream = nullptr;
+      }
+    }
+  }
+  if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
       hipMalloc(reinterpret_cast<void**>(&c->d_counts), sizeof(uint64_t) * (size_t)n_ranks) != hipSuccess) {
     put_err(err, errcap, "HIP error while setting up the communicator's stream");
     dyn_comm_destroy(c);
@@ -184,6 +200,7 @@ void dyn_comm_destroy(dyn_comm* c) {
   if (c->comm && !c->aborted) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_recv) (void)hipFree(c->d_recv);
+  for (void* p : c->retired) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -272,11 +289,12 @@ int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* r
   constexpr size_t ROW = sizeof(dyn_segment_row);
   const bool too_small = c->rank == root && rows_out && rows_cap < total;
   if (c->rank == root && c->recv_bytes < total * ROW) {
-    if (c->d_recv) C_TRY_X(c, hipFree(c->d_recv));
+    if (c->d_recv) c->retired.push_back(c->d_recv);  // (growth is geometric: what is retired adds up to less than what is live)
     c->d_recv = nullptr;
     c->recv_bytes = 0;
-    C_TRY_X(c, hipMalloc(&c->d_recv, std::max<size_t>(total * ROW + total * ROW / 8, ROW)));
-    c->recv_bytes = total * ROW + total * ROW / 8;
+    const size_t want = std::max<size_t>(total * ROW + total * ROW / 2, ROW);
+    C_TRY_X(c, hipMalloc(&c->d_recv, want));
+    c->recv_bytes = want;
   }
   // the rows: each peer's link to the root carries its rows once
   N_TRY_X(c, g_rccl.GroupStart());

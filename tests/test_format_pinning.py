@@ -218,6 +218,231 @@ def test_write_bam_output_is_read_by_the_specification_decoder(tmp_path):
     assert all(g[4] == t and g[2] == 4 and g[3] == 0 for g, (_, _, t) in zip(got, recs))
 
 
+# ---- a POD5 file assembled from the specification ------------------------------------------------------------------------
+# The same idea as the BAM above: nothing of dynamont_amd writes this file. Arrow IPC tables come from pyarrow called
+# directly with the specification's schemas (extension types as their storage type + the ARROW:extension:* field metadata an
+# IPC writer emits for them), the flatbuffers footer from a small generic builder written here from the flatbuffers encoding
+# rules -- with a DIFFERENT physical layout than pod5_native.build_footer (vtables behind their tables, hence negative
+# soffsets; the `format` field left at its default and therefore absent from the vtable; strings after the vector) -- and the
+# VBZ chunks from a second StreamVByte-16 encoder (a plain loop over samples) around libzstd called through ctypes.
+def _spec_svb16_zigzag_delta(samples) -> bytes:
+    """pod5 SPECIFICATION.md, "VBZ": deltas of consecutive int16 samples (the first against 0), zigzag coded, then
+    StreamVByte with 16-bit values: one KEY BIT per value (bit i % 8 of key byte i // 8; 0 = one data byte, 1 = two,
+    little-endian), all key bytes first."""
+    keys = bytearray((len(samples) + 7) // 8)
+    data = bytearray()
+    prev = 0
+    for i, x in enumerate(int(v) for v in samples):
+        d = (x - prev + 32768) % 65536 - 32768            # int16 wrap-around of the difference
+        prev = x
+        z = ((d << 1) ^ (d >> 15)) & 0xFFFF                # zigzag
+        if z < 256:
+            data.append(z)
+        else:
+            keys[i // 8] |= 1 << (i % 8)
+            data += bytes((z & 255, z >> 8))
+    return bytes(keys) + bytes(data)
+
+
+def _spec_zstd(raw: bytes) -> bytes:
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    out = C.create_string_buffer(z.ZSTD_compressBound(len(raw)))
+    n = z.ZSTD_compress(out, len(out), raw, len(raw), 1)
+    assert not z.ZSTD_isError(n)
+    return out.raw[:n]
+
+
+class _SpecFlatbuffer:
+    """Just enough of the flatbuffers wire format (flatbuffers "Internals": little-endian; a uoffset32 points FORWARD from
+    its own position; a table starts with an soffset32 = table position - vtable position; a vtable = u16 vtable bytes, u16
+    table bytes, then one u16 per field = offset inside the table or 0 for a field left at its default)."""
+
+    def __init__(self):
+        self.b = bytearray(4)   # root uoffset
+        self.fix = []           # (position of a uoffset, key of its target)
+        self.at = {}            # key -> position
+
+    def align(self, n):
+        while len(self.b) % n:
+            self.b.append(0)
+
+    def table(self, key, fields):
+        """fields: list of None (default: absent) | ('ref', target key) | (struct format, value). vtable BEHIND the table."""
+        self.align(8)
+        start = len(self.b)
+        self.at[key] = start
+        self.b += b"\0\0\0\0"           # soffset, patched once the vtable's place is known
+        offs = []
+        for f in fields:
+            if f is None:
+                offs.append(0)
+                continue
+            size = 4 if f[0] == "ref" else struct.calcsize(f[0])
+            while (len(self.b) - start) % size:
+                self.b.append(0)
+            offs.append(len(self.b) - start)
+            if f[0] == "ref":
+                self.fix.append((len(self.b), f[1]))
+                self.b += b"\0\0\0\0"
+            else:
+                self.b += struct.pack(f[0], f[1])
+        size = len(self.b) - start
+        self.align(2)
+        vt = len(self.b)
+        self.b += struct.pack("<HH", 4 + 2 * len(offs), size) + b"".join(struct.pack("<H", o) for o in offs)
+        struct.pack_into("<i", self.b, start, start - vt)   # negative: the vtable lies behind
+
+    def vector_of_refs(self, key, targets):
+        self.align(4)
+        self.at[key] = len(self.b)
+        self.b += struct.pack("<I", len(targets))
+        for t in targets:
+            self.fix.append((len(self.b), t))
+            self.b += b"\0\0\0\0"
+
+    def string(self, key, text):
+        self.align(4)
+        self.at[key] = len(self.b)
+        raw = text.encode()
+        self.b += struct.pack("<I", len(raw)) + raw + b"\0"
+
+    def finish(self, root) -> bytes:
+        struct.pack_into("<I", self.b, 0, self.at[root])
+        for pos, key in self.fix:
+            assert self.at[key] > pos, "uoffsets point forward"
+            struct.pack_into("<I", self.b, pos, self.at[key] - pos)
+        return bytes(self.b)
+
+
+def _spec_pod5(path, reads, chunk):
+    """reads: (uuid, int16 samples, calibration offset, calibration scale). Table version 3 of pod5's SPECIFICATION.md."""
+    import pyarrow as pa
+    ext = lambda name: {b"ARROW:extension:name": name, b"ARROW:extension:metadata": b""}  # noqa: E731
+    meta = {b"MINKNOW:pod5_version": b"0.3.2", b"MINKNOW:software": b"assembled from the specification",
+            b"MINKNOW:file_identifier": b"cbf91180-0684-4a39-bf56-41eaf437de9e"}
+
+    def ipc(schema, columns):
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_file(sink, schema.with_metadata(meta)) as w:
+            w.write_batch(pa.record_batch(columns, schema=schema.with_metadata(meta)))
+        return sink.getvalue().to_pybytes()
+
+    # signal table: one row per chunk of at most `chunk` samples
+    sig_ids, blobs, counts, rows_of = [], [], [], []
+    for rid, adc, _, _ in reads:
+        mine = []
+        for a in range(0, max(1, len(adc)), chunk):
+            part = adc[a:a + chunk]
+            mine.append(len(blobs))
+            sig_ids.append(rid.bytes)
+            blobs.append(_spec_zstd(_spec_svb16_zigzag_delta(part)))
+            counts.append(len(part))
+        rows_of.append(mine)
+    uuid_t = pa.binary(16)
+    signal_schema = pa.schema([pa.field("read_id", uuid_t, metadata=ext(b"minknow.uuid")),
+                               pa.field("signal", pa.large_binary(), metadata=ext(b"minknow.vbz")), pa.field("samples", pa.uint32())])
+    signal_tab = ipc(signal_schema, [pa.array(sig_ids, uuid_t), pa.array(blobs, pa.large_binary()), pa.array(counts, pa.uint32())])
+    dict_t = pa.dictionary(pa.int16(), pa.utf8())
+    run_schema = pa.schema([pa.field("acquisition_id", pa.utf8()), pa.field("acquisition_start_time", pa.timestamp("ms", "UTC")),
+                            pa.field("adc_max", pa.int16()), pa.field("adc_min", pa.int16()),
+                            pa.field("context_tags", pa.map_(pa.utf8(), pa.utf8())), pa.field("device_type", pa.utf8()),
+                            pa.field("flow_cell_id", pa.utf8()), pa.field("flow_cell_product_code", pa.utf8()), pa.field("protocol_name", pa.utf8()),
+                            pa.field("protocol_run_id", pa.utf8()), pa.field("protocol_start_time", pa.timestamp("ms", "UTC")),
+                            pa.field("sample_id", pa.utf8()), pa.field("sample_rate", pa.uint16()), pa.field("sequencing_kit", pa.utf8()),
+                            pa.field("sequencer_position", pa.utf8()), pa.field("sequencer_position_type", pa.utf8()), pa.field("software", pa.utf8()),
+                            pa.field("system_name", pa.utf8()), pa.field("system_type", pa.utf8()), pa.field("tracking_id", pa.map_(pa.utf8(), pa.utf8()))])
+    one = lambda v, t: pa.array([v], t)  # noqa: E731
+    run_tab = ipc(run_schema, [one("acq-1", pa.utf8()), one(1700000000000, pa.timestamp("ms", "UTC")), one(4095, pa.int16()), one(-4096, pa.int16()),
+                               one([("k", "v")], pa.map_(pa.utf8(), pa.utf8())), one("promethion", pa.utf8()), one("FC1", pa.utf8()), one("FLO", pa.utf8()),
+                               one("proto", pa.utf8()), one("run-1", pa.utf8()), one(1700000000000, pa.timestamp("ms", "UTC")), one("s", pa.utf8()),
+                               one(4000, pa.uint16()), one("kit", pa.utf8()), one("1A", pa.utf8()), one("p2", pa.utf8()), one("sw", pa.utf8()),
+                               one("sys", pa.utf8()), one("st", pa.utf8()), one([], pa.map_(pa.utf8(), pa.utf8()))])
+    n = len(reads)
+    reads_schema = pa.schema([pa.field("read_id", uuid_t, metadata=ext(b"minknow.uuid")), pa.field("signal", pa.list_(pa.uint64())),
+                              pa.field("read_number", pa.uint32()), pa.field("start", pa.uint64()), pa.field("median_before", pa.float32()),
+                              pa.field("num_minknow_events", pa.uint64()), pa.field("tracked_scaling_scale", pa.float32()),
+                              pa.field("tracked_scaling_shift", pa.float32()), pa.field("predicted_scaling_scale", pa.float32()),
+                              pa.field("predicted_scaling_shift", pa.float32()), pa.field("num_reads_since_mux_change", pa.uint32()),
+                              pa.field("time_since_mux_change", pa.float32()), pa.field("num_samples", pa.uint64()), pa.field("channel", pa.uint16()),
+                              pa.field("well", pa.uint8()), pa.field("pore_type", dict_t), pa.field("calibration_offset", pa.float32()),
+                              pa.field("calibration_scale", pa.float32()), pa.field("end_reason", dict_t), pa.field("end_reason_forced", pa.bool_()),
+                              pa.field("run_info", dict_t)])
+    f32 = lambda vals: pa.array(np.asarray(vals, dtype=np.float32), pa.float32())  # noqa: E731
+    dic = lambda word: pa.DictionaryArray.from_arrays(pa.array([0] * n, pa.int16()), pa.array([word], pa.utf8()))  # noqa: E731
+    reads_tab = ipc(reads_schema, [pa.array([r[0].bytes for r in reads], uuid_t), pa.array(rows_of, pa.list_(pa.uint64())),
+                                   pa.array(range(n), pa.uint32()), pa.array([0] * n, pa.uint64()), f32([200.0] * n), pa.array([0] * n, pa.uint64()),
+                                   f32([1.0] * n), f32([0.0] * n), f32([1.0] * n), f32([0.0] * n), pa.array([0] * n, pa.uint32()), f32([0.0] * n),
+                                   pa.array([len(r[1]) for r in reads], pa.uint64()), pa.array(range(1, n + 1), pa.uint16()), pa.array([1] * n, pa.uint8()),
+                                   dic("not_set"), f32([r[2] for r in reads]), f32([r[3] for r in reads]), dic("signal_positive"),
+                                   pa.array([False] * n, pa.bool_()), dic("acq-1")])
+    marker = uuid.UUID("5b6e9c2a-2b0c-4d8c-9d4e-0123456789ab").bytes
+    sig8 = b"\x8bPOD\r\n\x1a\n"
+    body = bytearray(sig8 + marker)
+    where = {}
+    for kind, blob in ((1, signal_tab), (4, run_tab), (0, reads_tab)):   # content_type: 1 signal, 4 run info, 0 reads
+        where[kind] = (len(body), len(blob))
+        body += blob
+        body += b"\0" * (-len(body) % 8)
+        body += marker
+    fb = _SpecFlatbuffer()
+    fb.table("footer", [("ref", "id"), ("ref", "sw"), ("ref", "ver"), ("ref", "contents")])
+    fb.vector_of_refs("contents", ["e1", "e4", "e0"])
+    for kind in (1, 4, 0):   # EmbeddedFile { offset:int64; length:int64; format:short = FeatherV2 (default, absent); content_type:short }
+        fb.table(f"e{kind}", [("<q", where[kind][0]), ("<q", where[kind][1]), None, ("<h", kind)])
+    fb.string("ver", "0.3.2")
+    fb.string("id", "cbf91180-0684-4a39-bf56-41eaf437de9e")
+    fb.string("sw", "assembled from the specification")
+    footer = fb.finish("footer")
+    body += b"FOOTER\0\0" + footer + b"\0" * (-len(footer) % 8)
+    body += struct.pack("<q", len(footer) + (-len(footer) % 8)) + marker + sig8
+    open(path, "wb").write(bytes(body))
+
+
+def test_pod5_from_the_specification_is_read_by_the_reader_and_the_native_decoder(tmp_path, native_lib):
+    """N1: the container framing, the footer and the VBZ stage are ours alone (Arrow IPC is read by Apache Arrow, zstd frames by
+    libzstd) -- pinned here against a file no code of dynamont_amd wrote. Samples cover every svb16 case: deltas of one and
+    of two bytes, the int16 extremes (wrap-around differences), a chunk whose sample count is not a multiple of 8, a
+    one-sample read, a read of several chunks."""
+    import ctypes as C
+    from dynamont_amd import pod5_native as P
+    rng = np.random.default_rng(123)
+    walk = np.clip(np.cumsum(rng.integers(-300, 301, size=25013)) + 500, -32768, 32767).astype(np.int16)
+    edge = np.array([0, 32767, -32768, -1, 1, 127, 128, -128, -129, 255, 256, 32767, 32767, -32768], dtype=np.int16)
+    reads = [(uuid.UUID(int=int(rng.integers(1, 2 ** 62))), adc, np.float32(o), np.float32(sc))
+             for adc, o, sc in ((walk, -243.0, 0.1462), (edge, 3.0, 0.25), (np.array([-7], dtype=np.int16), 0.0, 1.0),
+                                (rng.integers(-32768, 32768, size=4099).astype(np.int16), -10.5, 0.2))]
+    path = str(tmp_path / "spec.pod5")
+    _spec_pod5(path, reads, chunk=10240)
+    f = P.Pod5File(path)
+    assert f.footer["software"] == "assembled from the specification" and f.footer["pod5_version"] == "0.3.2"
+    assert sorted(c["content_type"] for c in f.footer["contents"]) == [0, 1, 4] and all(c["format"] == 0 for c in f.footer["contents"])
+    assert sorted(f.read_ids) == sorted(str(r[0]) for r in reads)
+    for rid, adc, o, sc in reads:
+        got, go, gs = f.signal_adc(str(rid))
+        assert got.dtype == np.int16 and np.array_equal(got, adc) and np.float32(go) == o and np.float32(gs) == sc
+        assert np.array_equal(f.signal(str(rid), True), (adc.astype(np.float32) + o) * sc)   # pod5_io.py:6-16: signal_pa
+    # the library's own decoder (vbz_decode.cpp, what dyn_batch_align_vbz_async runs) on the chunks as they lie in the file
+    ids16 = np.frombuffer(b"".join(r[0].bytes for r in reads), dtype=np.uint8).reshape(-1, 16)
+    found, ptrs, nbytes, samples, read_off, cal_o, cal_s = f.signal_chunks_batch(ids16)
+    assert found.all() and [int(x) for x in np.diff(read_off.astype(np.int64))] == [3, 1, 1, 1]
+    err = C.create_string_buffer(256)
+    for i, (rid, adc, o, sc) in enumerate(reads):
+        parts = []
+        for c in range(int(read_off[i]), int(read_off[i + 1])):
+            out = np.full(int(samples[c]) + 1, 21845, dtype=np.int16)
+            rc = native_lib.dyn_vbz_decode(C.c_void_p(int(ptrs[c])), int(nbytes[c]), int(samples[c]), out.ctypes.data_as(C.c_void_p), err, 256)
+            assert rc == 0, err.value
+            assert out[-1] == 21845
+            parts.append(out[:-1])
+        assert np.array_equal(np.concatenate(parts), adc) and cal_o[i] == o and cal_s[i] == sc
+    f.close()
+
+
 # ---- official tools, when the box has them -------------------------------------------------------------------------------
 def _reads_for_official_tools():
     rng = np.random.default_rng(77)

@@ -18,15 +18,16 @@ from dynamont_amd.segmentation import utils as U
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib")]
 
 
-def _torchrun(module, args, port):
+def _torchrun(module, args, port, ranks=2):
     env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(port), "-m", module] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-def test_resquiggle_two_ranks_gather_rows(models, tmp_path):
+@pytest.mark.parametrize("ranks", [2, 4])   # (a GPU box lets one job put 6 processes on its card: pytest itself + 4 ranks stay inside)
+def test_resquiggle_ranks_gather_rows(models, tmp_path, ranks):
     pore = "rna004"
     model = model_for(models, pore)
     _, mean, sd = synth.read_model_file(model)
@@ -37,7 +38,7 @@ def test_resquiggle_two_ranks_gather_rows(models, tmp_path):
     open(bam, "w").write("\n".join(lines) + "\n")
     base = ["-r", str(tmp_path / "in"), "-b", bam, "--mode", "basic", "-p", pore, "--model_path", model, "--batch-reads", "3"]
     seg.main(base + ["-o", str(tmp_path / "single.csv")])
-    _torchrun("dynamont_amd.segmentation.segment", base + ["-o", str(tmp_path / "multi.csv")], 29621)
+    _torchrun("dynamont_amd.segmentation.segment", base + ["-o", str(tmp_path / "multi.csv")], 29621 + ranks, ranks)
     one = zstd_io.decompress(open(tmp_path / "single.csv.zst", "rb").read()).decode().splitlines()
     two = zstd_io.decompress(open(tmp_path / "multi.csv.zst", "rb").read()).decode().splitlines()
     assert one[0] == two[0] and sorted(one[1:]) == sorted(two[1:]) and len(one) > 500
@@ -78,23 +79,29 @@ def test_train_two_ranks_allreduce(models, tmp_path):
     assert open(tmp_path / "single" / "trained_0_1.model", "rb").read() == open(tmp_path / "single2" / "trained_0_1.model", "rb").read()
 
 
-def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` WITHOUT a launcher (what a driver may type): bench.py starts its two ranks itself as a
-    child torch.distributed.run and prints ONE line that says n_gpus 2. Rehearsal hooks: both ranks on cuda:0, gloo
-    (a 1-GPU box cannot host two RCCL ranks). Without the hooks the same command must refuse a box with one device
-    instead of measuring one GPU and calling it two."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path, ranks):
+    """`python bench.py --gpus N` WITHOUT a launcher (what a driver may type): bench.py starts its N ranks itself as a
+    child torch.distributed.run and prints ONE line that says n_gpus N. Rehearsal hooks: every rank on cuda:0, gloo, and a
+    torch.distributed stand-in for the exchange (a 1-GPU box cannot host two RCCL ranks; the real exchange is dyn_comm_*,
+    tests/test_gpu_rccl_comm.py) -- the line must SAY that it is a rehearsal. Without the hooks the same command must refuse
+    a box with one device instead of measuring one GPU and calling it N. (4 ranks: a GPU box lets one job put 6 processes on its
+    card, this test runner included; gloo at world 8 runs on the CPU, tests/test_parallel_gloo.py.)"""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(DYN_BENCH_ONE_DEVICE="1", DYN_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg2_small",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "cfg2_small",
            "--no-plain"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["strict_mode"] == "ties" and len(d["per_rank_ms"]) == 2
+    assert d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["strict_mode"] == "ties" and len(d["per_rank_ms"]) == ranks
+    assert "REHEARSAL" in d["exchange"]["implementation"] and d["exchange"]["rows_gathered_rank0"] > 0
+    if ranks != 2:
+        return
     env.pop("DYN_BENCH_ONE_DEVICE")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "refusing to measure fewer GPUs" in r.stderr, r.stderr[-2000:]

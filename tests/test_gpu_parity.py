@@ -843,3 +843,49 @@ def test_band_above_447_short_reads_equal_the_oracle_long_reads_get_their_status
     tr = al.train_batch(sigs, seqs)
     assert tr.status[-1] == 11 and (tr.status[:-1] == 0).all()
     al.close()
+
+
+def _g13_clustered9(mean5, sd5):
+    """tests/golden/make_golden_g13.py, clustered9(): every 9-mer takes its central 5-mer's entry, moved by +-10^-(4 + code % 4)"""
+    code = np.arange(4 ** 9, dtype=np.int64)
+    central = (code // 16) % 1024
+    sign = np.where((code * 2654435761 >> 7) & 1, 1.0, -1.0)
+    return mean5[central] + sign * 10.0 ** -(4 + code % 4), sd5[central].copy()
+
+
+@pytest.mark.parametrize("family", ["rna002_real", "rna002_trained", "clustered9", "dna_cfg3"])
+def test_g13_decision_margin_families_in_the_default_mode(models, tmp_path, family):
+    """G13 (tests/golden/make_golden_g13.py): the tables where distinct k-mers lie closest together -- the reference's real RNA002
+    models (one with a stdev per k-mer), a 9-mer table with real-like clustering (256 nine-mers 1e-4 .. 1e-7 around each
+    real 5-mer level), and configs[2]'s long DNA reads. The strict mode "ties" certifies a read only on IDENTICAL neighbouring
+    parameters; everything else rests on the traceback's on-path margin (NT_aligner_api.cpp:445-448), which the fixture
+    records per read from the compiled reference: its floor over all four families is 6e-7, seven orders above what the table
+    softplus can move. Every read runs here in the DEFAULT mode and must come out on the reference's borders."""
+    import json
+    g = golden("g13_margin_families.npz")
+    spec = json.loads(str(g["families"]))[family]
+    pore = spec["pore"]
+    k = synth.PORES[pore][2]
+    if spec["table"] == "syn9":
+        model = models["syn9"]
+    else:
+        if spec["table"] == "clustered9":
+            mean, sd = _g13_clustered9(g["rna004_5_mean"], g["rna004_5_sd"])
+        else:
+            mean, sd = g[spec["table"] + "_mean"], g[spec["table"] + "_sd"]
+        model = synth.write_model_values(str(tmp_path / f"{family}.model"), k, mean, sd)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(spec["seed"], spec["reads"], pore, np.asarray(mean), np.asarray(sd), tuple(spec["bases"]))
+    assert g[f"{family}_margin_distinct"].min() >= 1e-7   # what "far above 1e-13" means here; below 1e-9 the tie rule would need a net
+    al = Aligner(model, pore, device=0)
+    res = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    offs, want_sp, want_z = g[f"{family}_offsets"], g[f"{family}_signal_positions"], g[f"{family}_Z"]
+    assert (res.status == 0).all()
+    bad = []
+    for i in range(len(reads)):
+        got = res.read(i)
+        if not np.array_equal(np.asarray(got["signal_positions"], dtype=np.int64), want_sp[offs[i]:offs[i + 1]].astype(np.int64)):
+            bad.append(i)
+        assert abs(got["Z"] - want_z[i]) <= 1e-12 * max(1.0, abs(want_z[i]))
+    assert not bad, f"{family}: reads off the reference's borders: {bad[:10]}"
+    al.close()

@@ -105,3 +105,28 @@ def test_one_rank_rccl_gather_and_allreduce(models):
     assert out["pooled_weight"] > 100.0
     assert out["pooled_bits_equal_host"] and out["pooled_identical_over_10_runs"]
     assert out["failed_reads"] == [3, 7] and out["pooled_bits_equal_host_with_failed_reads"]
+
+
+def test_bench_exchange_through_dyn_comm_beside_the_resident_queue():
+    """`bench.py` with its exchange forced on for ONE rank (DYN_BENCH_FORCE_DIST=1): the timed steps of BASELINE's cfg2 run in
+    the resident read queue with 8 compute units reserved (dyn_aligner_set_session_mode) while every step's segment rows go
+    through dyn_comm_gather_counts / dyn_comm_gather_rows -- the code path of `bench.py --gpus N`, on the one rank a 1-GPU box
+    can host. The line must name the exchange implementation and count the rows it gathered."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DYN_BENCH_FORCE_DIST="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batches", "2", "--no-plain", "--no-cpu-baseline",
+           "--no-e2e", "--no-resident"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rccl_ranks"] == 1 and d["value"] > 0
+    ex = d["exchange"]
+    assert ex["implementation"].startswith("dyn_comm_") and ex["resident_queue"] and ex["reserved_cus"] == 8
+    assert ex["rows_gathered_rank0"] > 4 * 1024 * 1500   # ~2 000 segments per read, 1 024 reads, 4 timed steps (+ the warm-up's)
+    rq = d["roofline"]["resident_queue"]
+    assert rq and rq["aborted"] == 0 and rq["waves"] == (256 - 8) * 4 * rq["sessions"]

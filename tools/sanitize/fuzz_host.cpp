@@ -21,6 +21,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <unistd.h>
@@ -398,6 +399,39 @@ int main(int argc, char** argv) {
     std::printf("csv rows            : %llu rows formatted inside their bounds (NaN, inf-like, denormal and boundary probabilities included)\n",
                 (unsigned long long)rows);
     std::remove((tmp + ".model").c_str());
+  }
+  // ---- 5. the sink's threads (csv_sink.cpp) without a GPU: header frame, error lines from several producers, close -------
+  {
+    uint64_t lines = 0;
+    for (int round = 0; round < 8; ++round) {
+      dyn_csv_sink* sink = nullptr;
+      char err[512];
+      const std::string out = tmp + ".csv.zst", errs = tmp + ".errors";
+      if (dyn_csv_sink_open(out.c_str(), errs.c_str(), 3, 1 + round % 4, &sink, err, sizeof err) != DYN_OK) {
+        std::fprintf(stderr, "fuzz_host: dyn_csv_sink_open: %s\n", err);
+        return 1;
+      }
+      std::vector<std::thread> producers;
+      for (int t = 0; t < 4; ++t)
+        producers.emplace_back([&, t] {
+          for (int k = 0; k < 200; ++k) {
+            const std::string line = "error: worker, boom\tN: " + std::to_string(k) + "\tRid: r" + std::to_string(t) + "\tSid: s";
+            if (dyn_csv_sink_error_line(sink, line.c_str()) != DYN_OK) std::abort();
+            (void)dyn_csv_sink_completed(sink);
+            (void)dyn_csv_sink_failed(sink);
+          }
+        });
+      for (auto& th : producers) th.join();
+      uint64_t csv = 0, zst = 0, nerr = 0;
+      if (dyn_csv_sink_close(sink, &csv, &zst, &nerr, err, sizeof err) != DYN_OK || nerr != 800) {
+        std::fprintf(stderr, "fuzz_host: dyn_csv_sink_close: %s (%llu error lines)\n", err, (unsigned long long)nerr);
+        return 1;
+      }
+      lines += nerr;
+      std::remove(out.c_str());
+      std::remove(errs.c_str());
+    }
+    std::printf("csv sink            : 8 sinks opened, fed by four threads each and closed; %llu error lines written\n", (unsigned long long)lines);
   }
   std::printf("TOTAL %llu mutated inputs, no crash, no sanitizer report\n", (unsigned long long)total);
   return 0;

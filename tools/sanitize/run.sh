@@ -16,20 +16,17 @@ fail=0
 make -s -C tools/sanitize -j"$(nproc)" all || exit 2
 {
   echo "# host-side sanitizer runs ($(date -u +%Y-%m-%dT%H:%MZ), $(g++ --version | head -1))"
-  for kind in asan tsan; do
-    if [ $kind = asan ]; then
-      rt=$(g++ -print-file-name=libasan.so)
-      export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-    else
-      rt=$(g++ -print-file-name=libtsan.so)
-      export TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"
-    fi
-    echo "## $kind: pytest -m 'not gpu' $TESTS"
-    LD_PRELOAD="$rt" DYN_LIB_PATH="$PWD/build/sanitize/libdynamont_mi_$kind.so" timeout 1500 python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4
-    rc=${PIPESTATUS[0]}
-    echo "exit code $rc"
-    [ "$rc" = 0 ] || fail=1
-  done
+  # The Python tests run on the ASan + UBSan build only: CPython under a preloaded TSan runtime deadlocks in its own start-up
+  # on this image (tried, round 5); the thread sanitizer sees the library through fuzz_host_tsan -- the BAM reader's inflate
+  # threads on every mutated file, the VBZ decoder, and the sink's sink / compress / writer threads fed by four producers.
+  # (libstdc++ is preloaded too: python does not link it, and ASan resolves its __cxa_throw interceptor when it starts.)
+  rt="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so)"
+  echo "## asan+ubsan: pytest -m 'not gpu' $TESTS"
+  ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD="$rt" \
+    DYN_LIB_PATH="$PWD/build/sanitize/libdynamont_mi_asan.so" timeout 1500 python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4
+  rc=${PIPESTATUS[0]}
+  echo "exit code $rc"
+  [ "$rc" = 0 ] || fail=1
   echo "## asan+ubsan: fuzz_host tests/fuzz_corpus $N_ASAN (seed 5)"
   ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 timeout 3000 build/sanitize/fuzz_host_asan tests/fuzz_corpus "$N_ASAN" 5 > "$OUT/fuzz_asan_ubsan.txt" 2>&1
   rc=$?
