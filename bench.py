@@ -12,25 +12,32 @@ to `--depth` of them are in flight, so neighbouring batches overlap host work an
 kernels exactly as a stream of batches does in production; the timed region starts with an idle
 pipeline and ends when the last batch's results are in host memory (and, for N > 1, the RCCL
 collective of the last step is complete). `value` = signal samples of all ranks / max-over-ranks
-wall time. The kernel-only rate with inputs resident in HBM is reported as the secondary
-`kernel_resident_Msamp_s` -- of ONE batch in one launch: the engine merges tickets that wait while the GPU is busy into one
-launch (include/dynamont_mi.h), and a launch of two or three 1 024-read batches balances better than one of a single batch,
-so `pipeline_efficiency` can exceed 1. `roofline` prices the launches as they ran: `cells_per_launch`, `avg_launch_ms` and
-`batches_per_launch` describe the merged launches (HIP events per launch, each counted once through the tickets'
-`launch_share`), which is what a rocprofv3 kernel trace of the same command shows.
+wall time. `roofline` prices the dominant kernel as it ran: since round 5 the batches of the timed region are published into
+ONE launch of resident waves (k_session: the resident read queue, include/dynamont_mi.h), so `roofline.launches` counts
+SESSIONS, `kernel_ms_total` is the sum of their durations (HIP events on the session stream = what a rocprofv3 kernel trace of
+the same command shows) and `wave_occupancy` is busy / lifetime wave-cycles; with `--no-sessions` the engine merges waiting
+tickets into launches of two or three batches as in round 4 and the same fields describe those (each counted once through the
+tickets' `launch_share`). `kernel_resident_Msamp_s` is ONE batch alone in one launch with inputs resident in HBM (the round-1
+headline), kept as a reference point only.
 
 N = 1 workload: BASELINE.json configs[1] -- 1 024 synthetic RNA004 reads x ~20 k samples per batch,
 synthetic 9-mer model, --mode basic, band 400. N > 1: configs[3]'s per-GPU share, 4 096 reads per
 rank and batch, RCCL gather of the segment rows to rank 0 (weak scaling). --mode train: configs[4]'s
 per-GPU share (1 024 reads per rank and batch), RCCL all-reduce of the pooled statistics.
 
-N > 1, what the timed region contains per step and rank: the batch through the drop-in boundary as above, then
-the rank's segment rows (still resident in HBM) into a send buffer, an ASYNCHRONOUS gather to rank 0 over RCCL that
-overlaps the next batch, and on rank 0 the copy of all ranks' rows into pinned host memory -- the line says
-"gather_lands_in": "rank0_pinned_host". The clock stops after the last gather and its host copy have completed.
+N > 1, what the timed region contains per step and rank: the batch through the drop-in boundary as above, then the
+library's OWN exchange on the waited ticket -- dyn_comm_gather_counts + dyn_comm_gather_rows (rccl_comm.cpp: an 8-byte count
+all-gather, then one ncclSend per peer / ncclRecv per peer on rank 0 in one group, straight from the batch's device rows;
+rank 0 copies them to page-locked host memory: "gather_lands_in": "rank0_pinned_host"), or dyn_comm_allreduce_pooled for
+--mode train. torch.distributed only hands the 128-byte communicator id round, brackets the clock with barriers and
+reduces the ranks' clocks. RCCL's kernels do not fit beside resident waves: --reserve-cus (8) compute units stay free of
+the resident read queue (`exchange` in the line reports what was observed).
 
-N = 1 also carries `e2e_cli`: the dynamont-resquiggle counterpart itself on a synthetic .pod5 + BAM dataset of 32 768 reads
-(configs[3]'s read count), and `e2e_cli.large` on 131 072 -- file in, compressed CSV out, in this process (run_e2e_cli).
+N = 1 also carries: `plain_arithmetic` (strict mode off), `cfg2_polya` (cfg2 with a polyA tail behind the pad: EVERY read runs
+the certified sweeps, as on real direct-RNA data), `scale_ref` (configs[3]'s per-GPU share on this one GPU: the N = 1 point of
+the scaling curve, the workload every rank runs at N > 1) -- each with its own warm-up, timed region and roofline fraction --
+and `e2e_cli`: the dynamont-resquiggle counterpart itself on a synthetic .pod5 + BAM dataset of 32 768 reads (configs[3]'s
+read count), and `e2e_cli.large` on 131 072 -- file in, compressed CSV out, in this process (run_e2e_cli).
 
 Import order (asserted below): `torch` is imported BEFORE the first dynamont_amd.Aligner is created. PyTorch's wheel
 bundles its own libamdhip64 and refuses to initialise once another copy is mapped; libdynamont_mi.so links the

@@ -572,7 +572,19 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
     }
     const uint64_t n = b->n;
     if (n) P_TRY(b, hipMemcpyAsync(b->h_state.p, b->d_state.p, n * sizeof(ReadState), hipMemcpyDeviceToHost, a->s_out));
-    if (b->capacity) {
+    if (b->job == DynJob::Train) {  // as front_stage does for a launch of its own
+      const dyn_train_out* ot = b->out_train;
+      const bool need_cols = (ot->em_code && ot->em_mean && ot->em_stdev) || b->out_pooled;
+      const uint64_t c = need_cols ? b->total_cols : 0;
+      P_TRY(b, b->h_rows.ensure(std::max<uint64_t>(8, (3 * c + 2 * n) * 8)));
+      double* h = b->h_rows.as<double>();
+      if (c) {
+        P_TRY(b, hipMemcpyAsync(h, b->d_colw.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+        P_TRY(b, hipMemcpyAsync(h + c, b->d_cols1.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+        P_TRY(b, hipMemcpyAsync(h + 2 * c, b->d_cols2.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
+      }
+      if (n) P_TRY(b, hipMemcpyAsync(h + 3 * c, b->d_trans.p, n * 16, hipMemcpyDeviceToHost, a->s_out));
+    } else if (b->capacity) {
       P_TRY(b, b->h_rows.ensure(b->capacity * sizeof(SegRow)));
       P_TRY(b, hipMemcpyAsync(b->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost, a->s_out));
     }

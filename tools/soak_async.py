@@ -5,7 +5,11 @@ them, a random number of tickets in flight (so that some merge into one launch a
 result compared, bit for bit, with the synchronous call of a second handle on the same input. What `pytest -m gpu` checks
 once per feature meets here in random order on recycled buffers.
 
-    python tools/soak_async.py [tickets] [seed]
+    python tools/soak_async.py [tickets] [seed] [resident]
+
+`resident` (round 5): batches of up to 1 100 reads as well, so that tickets open, join, outgrow and close sessions of the
+RESIDENT read queue (align and train sessions alternate with one-launch-per-batch jobs on the same lattice pool) -- the
+results must still be the synchronous calls' bit for bit.
 """
 import os, sys, tempfile, time
 sys.path.insert(0, "/root/repo")
@@ -14,14 +18,15 @@ from dynamont_amd import Aligner, synth
 
 n_tickets = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+RESIDENT = len(sys.argv) > 3 and sys.argv[3] == "resident"
 d = tempfile.mkdtemp(prefix="dyn_soak_async_")
 model = synth.write_model(os.path.join(d, "m9.model"), 9, seed=7, stdev=0.15)
 _, mean, sd = synth.read_model_file(model)
 
 pool = []
 for k in range(24):
-    n = int(rng.choice([1, 3, 17, 64, 200, 400]))
-    hi = int(rng.choice([120, 600, 2500]))
+    n = int(rng.choice([3, 64, 400, 530, 700, 1100] if RESIDENT else [1, 3, 17, 64, 200, 400]))
+    hi = int(rng.choice([120, 400, 900] if RESIDENT else [120, 600, 2500]))
     reads = synth.make_reads(5000 + k, n, "rna004", mean, sd, (30, hi), polya=(20, 100) if k % 3 == 0 else None)
     sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
     for i in rng.choice(n, size=max(1, n // 12), replace=False):   # damage some reads
@@ -61,7 +66,7 @@ def same(got, exp, kind):
     return None
 
 t0 = time.time()
-inflight, done, merged = [], 0, 0
+inflight, done, merged, resident = [], 0, 0, 0
 depth = int(rng.integers(1, 13))
 for t in range(n_tickets):
     if t % 25 == 0:
@@ -74,10 +79,15 @@ for t in range(n_tickets):
     while len(inflight) > depth or (t == n_tickets - 1 and inflight):
         tk, k, kind = inflight.pop(0)
         got = tk.wait()
-        merged += tk.timing()["launch_share"] < 1.0
+        tm = tk.timing()
+        resident += tm["launches"] == 0 and tm["reads_ok"] > 0
+        merged += 0.0 < tm["launch_share"] < 1.0
         bad = same(got, reference(k, kind), kind)
         assert bad is None, f"ticket {done}: batch {k} ({len(pool[k][1])} reads), {kind}: field {bad} differs from the synchronous call"
         tk.close()
         done += 1
-print(f"soak done: {done} tickets ({merged} of them shared a launch) in {time.time() - t0:.0f} s, every result bit-identical to the synchronous call")
+ss = al.session_stats()
+assert ss["aborted"] == 0, ss
+print(f"soak done: {done} tickets ({merged} of them shared a launch, {resident} ran in the resident read queue: {ss['sessions']} sessions, "
+      f"{ss['tickets']} tickets, wave occupancy {ss['wave_occupancy']:.3f}) in {time.time() - t0:.0f} s, every result bit-identical to the synchronous call")
 al.close(); ref.close()
