@@ -540,16 +540,26 @@ int Pipeline::wait_resident(dyn_batch* b) {
   for (uint64_t spin = 0;; ++spin) {
     if (*b->sess_flag == b->sess_reads) return DYN_OK;
     if ((spin & 63) == 63) {
+      const double c0 = now_ms();
       P_TRY(b, hipMemcpyAsync(h, b->d_tctl.p, 4, hipMemcpyDeviceToHost, a->s_out));
       P_TRY(b, hipMemcpyAsync(h + 1, a->sess_ctl[b->sess_blk].as<uint32_t>() + dynk::S_ABORT, 4, hipMemcpyDeviceToHost, a->s_out));
+      const double c1 = now_ms();
       P_TRY(b, hipStreamSynchronize(a->s_out));
+      if (g_trace && now_ms() - c0 > 20.0)
+        std::fprintf(stderr, "[dyn] back  %p: second opinion took %.1f ms to enqueue, %.1f ms to complete (flag %u, counter %u of %u)\n", (void*)b, c1 - c0,
+                     now_ms() - c1, *b->sess_flag, h[0], b->sess_reads);
       if (h[0] == b->sess_reads) return DYN_OK;  // the counter is there; the word is on its way
-      if (h[1] != 0) {
-        b->error = "the resident read queue aborted: its waves found no work for DYN_SESSION_IDLE_S seconds while this ticket was pending";
-        return DYN_ERR_DEVICE;
-      }
-      if (now_ms() - t0 > limit_ms) {
-        b->error = "the resident read queue did not finish a ticket within DYN_SESSION_WAIT_S seconds";
+      const bool aborted = h[1] != 0, late = now_ms() - t0 > limit_ms;
+      if (aborted || late) {
+        // what the queue looked like: reads claimed, tickets published, closed, abort -- and this ticket's own counter
+        uint32_t* cw = h + 2;
+        P_TRY(b, hipMemcpyAsync(cw, a->sess_ctl[b->sess_blk].p, 16, hipMemcpyDeviceToHost, a->s_out));
+        P_TRY(b, hipStreamSynchronize(a->s_out));
+        char what[256];
+        std::snprintf(what, sizeof what, " (reads claimed %u, tickets published %u, closed %u, abort %u; this ticket: %u of %u reads done)", cw[0], cw[1],
+                      cw[2], cw[3], h[0], b->sess_reads);
+        b->error = std::string(aborted ? "the resident read queue aborted: its waves found no work for DYN_SESSION_IDLE_S seconds while this ticket was pending"
+                                       : "the resident read queue did not finish a ticket within DYN_SESSION_WAIT_S seconds") + what;
         return DYN_ERR_DEVICE;
       }
     }
@@ -565,26 +575,16 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
     rc = wait_resident(b);
     if (rc != DYN_OK) return rc;
     // the per-segment kernels and the copies out, beside the resident waves
+    const double f0 = now_ms();
     rc = session_finish_enqueue(b, a->s_out);
+    if (g_trace) std::fprintf(stderr, "[dyn] back  %p: resident ticket complete after %.2f ms, finish enqueued in %.2f ms\n", (void*)b, f0 - t0, now_ms() - f0);
     if (rc != DYN_OK) {
       b->error = a->last_error;
       return rc;
     }
     const uint64_t n = b->n;
     if (n) P_TRY(b, hipMemcpyAsync(b->h_state.p, b->d_state.p, n * sizeof(ReadState), hipMemcpyDeviceToHost, a->s_out));
-    if (b->job == DynJob::Train) {  // as front_stage does for a launch of its own
-      const dyn_train_out* ot = b->out_train;
-      const bool need_cols = (ot->em_code && ot->em_mean && ot->em_stdev) || b->out_pooled;
-      const uint64_t c = need_cols ? b->total_cols : 0;
-      P_TRY(b, b->h_rows.ensure(std::max<uint64_t>(8, (3 * c + 2 * n) * 8)));
-      double* h = b->h_rows.as<double>();
-      if (c) {
-        P_TRY(b, hipMemcpyAsync(h, b->d_colw.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
-        P_TRY(b, hipMemcpyAsync(h + c, b->d_cols1.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
-        P_TRY(b, hipMemcpyAsync(h + 2 * c, b->d_cols2.p, c * 8, hipMemcpyDeviceToHost, a->s_out));
-      }
-      if (n) P_TRY(b, hipMemcpyAsync(h + 3 * c, b->d_trans.p, n * 16, hipMemcpyDeviceToHost, a->s_out));
-    } else if (b->capacity) {
+    if (b->capacity) {
       P_TRY(b, b->h_rows.ensure(b->capacity * sizeof(SegRow)));
       P_TRY(b, hipMemcpyAsync(b->h_rows.p, b->d_rows.p, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost, a->s_out));
     }

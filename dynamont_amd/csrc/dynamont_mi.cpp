@@ -612,10 +612,19 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
 
 void dyn_aligner_destroy(dyn_aligner* a) {
   if (!a) return;
+  const bool trace = std::getenv("DYN_TRACE_HOST") != nullptr;
+  if (trace) std::fprintf(stderr, "[dyn] destroy %p: joining the pipeline\n", (void*)a);
   a->pipe.reset();  // drains and joins the pipeline threads
   if (!a->host_only) {
     (void)hipSetDevice(a->device);
+    if (trace) std::fprintf(stderr, "[dyn] destroy %p: session open %d, pending %d %d; device synchronise\n", (void*)a, (int)a->sess.open, (int)a->sess.pending[0],
+                            (int)a->sess.pending[1]);
+    {
+      std::lock_guard<std::mutex> lk(a->mu);
+      (void)session_quiesce(a);  // (an open session would make the device-wide wait below wait for its idle watchdog)
+    }
     (void)hipDeviceSynchronize();
+    if (trace) std::fprintf(stderr, "[dyn] destroy %p: device idle; releasing buffers\n", (void*)a);
     a->d_model.release();
     a->d_sptab.release();
     park_pool_buffer(a->device, 0, a->ws);
@@ -634,8 +643,10 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->sess_hctl.release();
     if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->cache.park(a->device);
+    if (trace) std::fprintf(stderr, "[dyn] destroy %p: buffers parked; destroying streams\n", (void*)a);
     for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_session})
       if (s) (void)hipStreamDestroy(s);
+    if (trace) std::fprintf(stderr, "[dyn] destroy %p: done\n", (void*)a);
   }
   delete a;
 }
@@ -1492,17 +1503,10 @@ int collect_timing(dyn_batch* b) {
 // ==== the resident read queue (engine.hpp: Session; nt_kernels.hpp: k_session) ============================================
 namespace {
 
-// Workgroups of a session = CUs it occupies. A TRAINING session leaves 8 more CUs free: every training ticket is followed by
-// rocPRIM's radix sort (pool_stats.hip), whose kernels need more LDS than the 13 KB a resident workgroup leaves on its CU --
-// with no CU free they would wait for the session to end, in a hardware queue they may share with the copy-in stream that
-// feeds the session (first build of training sessions: the waves starved until their watchdog ended the run).
-constexpr int SESSION_TRAIN_FREE_CUS = 8;
-int session_wgs(const dyn_aligner* a, bool train) { return std::max(1, a->sess_cus - (train ? SESSION_TRAIN_FREE_CUS : 0)); }
-// bytes of one lattice row in the pool: align = bE 8 B + float LPE 4 B per slot + the decision ballots; train = 8 B per slot
-uint64_t session_row_bytes(bool train) { return train ? (uint64_t)dynk::P * 8 : (uint64_t)dynk::P * 12 + dynk::CPL * 8; }
-int session_job_of(const dyn_aligner* a, DynJob job) {
-  return job == DynJob::Train ? (a->train_zcheck ? dynk::JOB_TRAIN_ZCHECK : dynk::JOB_TRAIN) : dynk::JOB_ALIGN;
-}
+// workgroups of a session = CUs it occupies (dyn_aligner_set_session_mode leaves the others free)
+int session_wgs(const dyn_aligner* a) { return std::max(1, a->sess_cus); }
+// bytes of one lattice row in the pool (separate LPE layout): bE 8 B + float LPE 4 B per slot + the decision ballots
+constexpr uint64_t SESSION_ROW_BYTES = (uint64_t)dynk::P * 12 + dynk::CPL * 8;
 
 uint32_t session_pages_of(uint64_t S, int log_r) { return (uint32_t)((S + 2 + (1ull << log_r) - 1) >> log_r); }
 
@@ -1545,9 +1549,8 @@ int session_collect(dyn_aligner* a, int blk) {
   return DYN_OK;
 }
 
-int session_open(dyn_aligner* a, const SessionNeed& need, int qjob, bool mixed, int log_r, uint32_t arena_pages, uint32_t n_pages_total) {
+int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r, uint32_t arena_pages, uint32_t n_pages_total) {
   Session& ss = a->sess;
-  const bool train = qjob != dynk::JOB_ALIGN;
   const int blk = ss.blk ^ 1;
   // the session before the last one used this block: it has long ended, but its statistics may still be waiting
   if (ss.pending[blk]) {
@@ -1567,13 +1570,11 @@ int session_open(dyn_aligner* a, const SessionNeed& need, int qjob, bool mixed, 
   const uint64_t page_rows = 1ull << log_r;
   const uint64_t ws_pp = page_rows * dynk::P * 8, lpe_pp = page_rows * dynk::P * 4, bits_pp = page_rows * dynk::CPL * 8;
   HIP_TRY(a, hipStreamSynchronize(a->stream));
-  if (a->ws.bytes < n_pages_total * ws_pp || (!train && (a->lpe.bytes < n_pages_total * lpe_pp || a->bits.bytes < n_pages_total * bits_pp))) {
+  if (a->ws.bytes < n_pages_total * ws_pp || a->lpe.bytes < n_pages_total * lpe_pp || a->bits.bytes < n_pages_total * bits_pp) {
     if (ss.pending[ss.blk]) HIP_TRY(a, hipEventSynchronize(ss.ev_end[ss.blk]));
     HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, n_pages_total * ws_pp, 1.0));
-    if (!train) {
-      HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
-      HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, n_pages_total * bits_pp, 1.0));
-    }
+    HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
+    HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, n_pages_total * bits_pp, 1.0));
   }
   // control words cleared IN the session stream, and waited for: the first publish (copy-in stream) must not be wiped
   HIP_TRY(a, hipMemsetAsync(a->sess_ctl[blk].p, 0, dynk::SESSION_CTL_WORDS * 4, a->s_session));
@@ -1587,8 +1588,8 @@ int session_open(dyn_aligner* a, const SessionNeed& need, int qjob, bool mixed, 
   sa.arena_pages = arena_pages;
   sa.ctl = a->sess_ctl[blk].as<uint32_t>();
   sa.pool.ws = a->ws.as<double>();
-  sa.pool.lpe = train ? nullptr : a->lpe.as<float>();
-  sa.pool.bits = train ? nullptr : a->bits.as<uint64_t>();
+  sa.pool.lpe = a->lpe.as<float>();
+  sa.pool.bits = a->bits.as<uint64_t>();
   sa.pool.free_list = nullptr;
   sa.pool.ctl = nullptr;
   sa.pool.log_rows = log_r;
@@ -1597,20 +1598,18 @@ int session_open(dyn_aligner* a, const SessionNeed& need, int qjob, bool mixed, 
   sa.e2 = a->model.log_e2;
   sa.idle_limit_ticks = (uint64_t)(a->sess_idle_s * 1e8);
   HIP_TRY(a, hipEventRecord(ss.ev_begin[blk], a->s_session));
-  dynk::launch_session((dynk::QueueJob)qjob, mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), session_wgs(a, train),
-                       a->s_session);
+  dynk::launch_session(mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), session_wgs(a), a->s_session);
   HIP_TRY(a, hipGetLastError());
   HIP_TRY(a, hipEventRecord(ss.ev_end[blk], a->s_session));
   ss.open = true;
   a->sess_open_hint.store(true);
   ss.mixed = mixed;
-  ss.job = qjob;
   ss.blk = blk;
   ss.published = 0;
   ss.next_base = 0;
   ss.log_r = log_r;
   ss.arena_pages = arena_pages;
-  ss.n_waves = (uint32_t)session_wgs(a, train) * dynk::WAVES_PER_CU;
+  ss.n_waves = (uint32_t)session_wgs(a) * dynk::WAVES_PER_CU;
   ss.cells = ss.reads = ss.tickets = 0;
   (void)need;
   return DYN_OK;
@@ -1622,7 +1621,11 @@ bool session_candidate(const dyn_batch* b) {
   const dyn_aligner* a = b->a;
   // (b->async: a caller's ticket. The batch of a MERGED launch is the engine's own and stays one launch: its members report
   //  that launch and their share of it.)
-  return a->s_session && !a->host_only && !a->ntk && b->async && (b->job == DynJob::AlignFull || b->job == DynJob::Train) &&
+  // align(calc_probabilities=1) only. Training tickets were tried (round 5, k_session<JOB_TRAIN>): the kernels that follow each
+  // of them on the copy-out stream -- rocPRIM's radix sort for the fixed-order pooled statistics -- did not progress beside a
+  // resident session (8 CUs left free for them, their queue's scratch allocated beforehand): every ticket's results arrived
+  // when the session ENDED. Training stays one launch per batch.
+  return a->s_session && !a->host_only && !a->ntk && b->async && b->job == DynJob::AlignFull &&
          (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
 }
 
@@ -1670,11 +1673,9 @@ int session_plan(dyn_batch* b, bool* use) {
   const SessionNeed need = session_need(b);
   if (!need.n_ok) return DYN_OK;  // nothing to launch
   Session& ss = a->sess;
-  const int qjob = session_job_of(a, b->job);
-  const bool train = qjob != dynk::JOB_ALIGN;
-  const bool strict_reads = !train && a->strict_mode != 0;
+  const bool strict_reads = a->strict_mode != 0;
   if (ss.open) {
-    const bool fits = ss.job == qjob && session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
+    const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
                       (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull && (ss.mixed || !strict_reads);
     if (fits) {
       *use = true;
@@ -1687,13 +1688,13 @@ int session_plan(dyn_batch* b, bool* use) {
   int log_r = 8;
   uint32_t arena = 0;
   session_geometry(need.max_S, &log_r, &arena);
-  const uint64_t n_waves = (uint64_t)session_wgs(a, train) * dynk::WAVES_PER_CU;
+  const uint64_t n_waves = (uint64_t)session_wgs(a) * dynk::WAVES_PER_CU;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
   const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + parked_bytes(a->device);
   uint64_t budget = (uint64_t)((double)(free_b + pool) * 0.90);
   if (a->mem_budget && a->mem_budget < budget) budget = a->mem_budget;
-  const uint64_t want = n_waves * arena * ((1ull << log_r) * session_row_bytes(train));
+  const uint64_t want = n_waves * arena * ((1ull << log_r) * SESSION_ROW_BYTES);
   if (want > budget || n_waves * arena > (0xfffffff0ull >> log_r)) return DYN_OK;  // page-starved: the planned classic launch
   *use = true;
   return DYN_OK;
@@ -1703,8 +1704,6 @@ int session_publish(dyn_batch* b) {
   dyn_aligner* a = b->a;
   const PoreModel& m = a->model;
   Session& ss = a->sess;
-  const int qjob = session_job_of(a, b->job);
-  const bool train = qjob != dynk::JOB_ALIGN;
   // strict reads and the queue order: as enqueue_job
   const int32_t* km = b->kmers();
   std::vector<uint32_t> strict_rows(b->n, 0), order;
@@ -1712,8 +1711,8 @@ int session_publish(dyn_batch* b) {
   for (uint64_t i = 0; i < b->n; ++i) {
     const HostRead& r = b->reads[i];
     if (r.status != DYN_READ_OK) continue;
-    if (!train && a->strict_mode == 2) strict_rows[i] = 0xffffffffu;
-    else if (!train && a->strict_mode == 1) strict_rows[i] = tie_rows(a->model, km + r.flat_off, r.kc, r.S);
+    if (a->strict_mode == 2) strict_rows[i] = 0xffffffffu;
+    else if (a->strict_mode == 1) strict_rows[i] = tie_rows(a->model, km + r.flat_off, r.kc, r.S);
     n_strict += strict_rows[i] != 0;
     max_S = std::max(max_S, r.S);
     order.push_back((uint32_t)i);
@@ -1731,27 +1730,16 @@ int session_publish(dyn_batch* b) {
     int log_r = 8;
     uint32_t arena = 0;
     session_geometry(max_S, &log_r, &arena);
-    const uint64_t n_waves = (uint64_t)session_wgs(a, train) * dynk::WAVES_PER_CU;
+    const uint64_t n_waves = (uint64_t)session_wgs(a) * dynk::WAVES_PER_CU;
     SessionNeed need;
     need.n_ok = n_ok;
     need.max_S = max_S;
-    if (int rc = session_open(a, need, qjob, !train && a->strict_mode != 0, log_r, arena, (uint32_t)(n_waves * arena))) return rc;
+    if (int rc = session_open(a, need, a->strict_mode != 0, log_r, arena, (uint32_t)(n_waves * arena))) return rc;
   }
 
-  if (!train) {
-    HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
-    HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));
-    HIP_TRY(a, b->d_medlo.ensure(std::max<uint64_t>(8, b->capacity * 8)));
-  } else {  // as enqueue_job
-    HIP_TRY(a, b->d_colw.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
-    HIP_TRY(a, b->d_cols1.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
-    HIP_TRY(a, b->d_cols2.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
-    HIP_TRY(a, b->d_trans.ensure(std::max<uint64_t>(16, b->n * 16)));
-    HIP_TRY(a, b->d_pooled.ensure(3 * m.num_kmers * 8));
-    HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->s_in));
-    HIP_TRY(a, b->d_poolwork.ensure(std::max<size_t>(8, dynk::pool_stats_work_bytes(b->total_cols))));
-    HIP_TRY(a, b->d_pooltemp.ensure(std::max<size_t>(8, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers))));
-  }
+  HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
+  HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));
+  HIP_TRY(a, b->d_medlo.ensure(std::max<uint64_t>(8, b->capacity * 8)));
   ReadState* st = b->h_state.as<ReadState>();
   for (uint64_t i = 0; i < b->n; ++i) {
     st[i].Zb = 0.0;
@@ -1788,10 +1776,8 @@ int session_publish(dyn_batch* b) {
     tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
     tm.samples += r.S;
   }
-  if (!train) {
-    HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
-    HIP_TRY(a, b->d_pathn.ensure(std::max<uint64_t>(4, rows_total * 4)));
-  }
+  HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
+  HIP_TRY(a, b->d_pathn.ensure(std::max<uint64_t>(4, rows_total * 4)));
   HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
   HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, n_ok * sizeof(ReadDesc), hipMemcpyHostToDevice, a->s_in));
   b->d_tctl.cache = &a->cache;
@@ -1812,24 +1798,16 @@ int session_publish(dyn_batch* b) {
   tk.sig_off = off_in(b->d_sig.p);
   tk.par_off = off_in(b->d_par.p);
   tk.st_off = off_out(b->d_state.p);
-  if (!train) {
-    tk.pp_off = off_out(b->d_pp.p);
-    tk.pathn_off = off_out(b->d_pathn.p);
-    tk.segrow_off = off_out(b->d_segrow.p);
-    tk.medhi_off = off_out(b->d_medhi.p);
-    tk.medlo_off = off_out(b->d_medlo.p);
-  } else {  // (SessionTicket: a training ticket's per-column sums and transition counts travel in the same slots)
-    tk.pp_off = off_out(b->d_colw.p);
-    tk.pathn_off = off_out(b->d_cols1.p);
-    tk.segrow_off = off_out(b->d_cols2.p);
-    tk.medhi_off = off_out(b->d_trans.p);
-    tk.medlo_off = 0;
-  }
+  tk.pp_off = off_out(b->d_pp.p);
+  tk.pathn_off = off_out(b->d_pathn.p);
+  tk.segrow_off = off_out(b->d_segrow.p);
+  tk.medhi_off = off_out(b->d_medhi.p);
+  tk.medlo_off = off_out(b->d_medlo.p);
   tk.tctl_off = off_out(b->d_tctl.p);
   tk.flag_off = off_out(flag);
   tk.n_reads = (uint32_t)n_ok;
   tk.base = ss.next_base;
-  tk.z_fail_status = train ? DYN_READ_TRAIN_Z_MISMATCH : DYN_READ_Z_MISMATCH;
+  tk.z_fail_status = DYN_READ_Z_MISMATCH;
   dynk::launch_session_publish(a->sess_ring[ss.blk].as<dynk::SessionTicket>(), a->sess_ctl[ss.blk].as<uint32_t>(), tk, ss.published, SESSION_RING,
                                a->s_in);
   HIP_TRY(a, hipGetLastError());
@@ -1857,9 +1835,9 @@ int session_publish(dyn_batch* b) {
   for (uint64_t i = 0; i < b->n; ++i) b->strict_flag[i] = strict_rows[i] != 0;
   b->timing = tm;
   b->n_chunks = 1;
-  b->aligned = !train;
-  b->trained = train;
-  b->last_calc = train ? 0 : 1;
+  b->aligned = true;
+  b->trained = false;
+  b->last_calc = 1;
   b->in_session = true;
   b->sess_reads = (uint32_t)n_ok;
   b->sess_waves = ss.n_waves;
@@ -1875,17 +1853,10 @@ int session_finish_enqueue(dyn_batch* b, hipStream_t s) {
   dyn_aligner* a = b->a;
   hipEvent_t* ev = b->events.data();
   HIP_TRY(a, hipEventRecord(ev[1], s));
-  if (b->trained) {
-    dynk::TrainBuffers tr{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
-    HIP_TRY(a, dynk::launch_pool_stats(b->d_descs.as<ReadDesc>(), (int)b->sess_reads, b->sess_max_N, b->d_state.as<ReadState>(), b->d_kmers.as<int32_t>(),
-                                       tr, b->d_pooled.as<double>(), a->model.num_kmers, b->total_cols, b->d_poolwork.p, b->d_pooltemp.p,
-                                       dynk::pool_stats_temp_bytes(b->total_cols, a->model.num_kmers), s));
-  } else {
-    dynk::TraceBuffers tb{b->d_pp.as<double>(), b->d_pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(), b->d_medhi.as<double>(),
-                          b->d_medlo.as<double>()};
-    dynk::launch_segments(b->d_descs.as<ReadDesc>(), (int)b->sess_reads, b->sess_rows_total, b->sess_max_N, b->d_state.as<ReadState>(), tb,
-                          b->d_rows.as<SegRow>(), a->model.k, s);
-  }
+  dynk::TraceBuffers tb{b->d_pp.as<double>(), b->d_pathn.as<uint32_t>(), b->d_segrow.as<uint32_t>(), b->d_medhi.as<double>(),
+                        b->d_medlo.as<double>()};
+  dynk::launch_segments(b->d_descs.as<ReadDesc>(), (int)b->sess_reads, b->sess_rows_total, b->sess_max_N, b->d_state.as<ReadState>(), tb,
+                        b->d_rows.as<SegRow>(), a->model.k, s);
   HIP_TRY(a, hipGetLastError());
   HIP_TRY(a, hipEventRecord(ev[2], s));
   HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, b->d_tctl.p, dynk::SESSION_TCTL_WORDS * 4, hipMemcpyDeviceToHost, s));

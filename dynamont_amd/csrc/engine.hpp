@@ -105,7 +105,6 @@ constexpr uint32_t SESSION_FLAGS = 4096;       // completion words in pinned hos
 struct Session {
   bool open = false;
   bool mixed = false;           // the kernel variant that carries the certified sweeps
-  int job = 1;                  // dynk::QueueJob of its tickets: JOB_ALIGN, JOB_TRAIN or JOB_TRAIN_ZCHECK (one kind per session)
   int blk = 0;                  // control block / ticket ring in use
   uint32_t published = 0;       // tickets of the open session
   uint32_t next_base = 0;       // global read index of the next ticket's first read

@@ -1515,11 +1515,9 @@ __device__ __forceinline__ SessionTicket load_ticket(const SessionTicket* ring, 
 
 }  // namespace
 
-// JOB: JOB_ALIGN (separate LPE layout), or JOB_TRAIN / JOB_TRAIN_ZCHECK -- a session holds tickets of ONE kind
-template <int JOB, bool MIXED>
+template <bool MIXED>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char* __restrict__ in_base, char* out_base,
                                                 const SoftplusNode* __restrict__ sp_tab) {
-  static_assert(JOB == JOB_ALIGN || ((JOB == JOB_TRAIN || JOB == JOB_TRAIN_ZCHECK) && !MIXED), "jobs of the resident read queue");
   constexpr int TAB_NODES = SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2;
   __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[TAB_NODES];
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
@@ -1594,18 +1592,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     WaveStats ws;
     ReadIO io{};
     io.st = reinterpret_cast<ReadState*>(out_base + tk.st_off);
-    if constexpr (JOB == JOB_ALIGN) {
-      io.tb = TraceBuffers{reinterpret_cast<double*>(out_base + tk.pp_off), reinterpret_cast<uint32_t*>(out_base + tk.pathn_off),
-                           reinterpret_cast<uint32_t*>(out_base + tk.segrow_off), reinterpret_cast<double*>(out_base + tk.medhi_off),
-                           reinterpret_cast<double*>(out_base + tk.medlo_off)};
-    } else {  // a training ticket: the same four slots of the record hold its per-column sums and transition counts
-      io.tr = TrainBuffers{reinterpret_cast<double*>(out_base + tk.pp_off), reinterpret_cast<double*>(out_base + tk.pathn_off),
-                           reinterpret_cast<double*>(out_base + tk.segrow_off), reinterpret_cast<double*>(out_base + tk.medhi_off)};
-    }
+    io.tb = TraceBuffers{reinterpret_cast<double*>(out_base + tk.pp_off), reinterpret_cast<uint32_t*>(out_base + tk.pathn_off),
+                         reinterpret_cast<uint32_t*>(out_base + tk.segrow_off), reinterpret_cast<double*>(out_base + tk.medhi_off),
+                         reinterpret_cast<double*>(out_base + tk.medlo_off)};
     io.m1 = sa.m1;
     io.e2 = sa.e2;
     io.z_fail_status = tk.z_fail_status;
-    run_read<JOB, MIXED>(rd, w, sa.pool, io, sig, par, s_tab, ring_base, sb, ws, t1);
+    run_read<JOB_ALIGN, MIXED>(rd, w, sa.pool, io, sig, par, s_tab, ring_base, sb, ws, t1);
     // everything this wave wrote for the read (state, path arrays, segment rows) must have left this XCD's L2 before the
     // ticket's counter says so: the per-segment kernels and the copies that follow run elsewhere
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1957,15 +1950,13 @@ void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n
   }
 }
 
-void launch_session(QueueJob job, bool with_strict, const SessionArgs& a, const void* in_base, void* out_base,
-                    const dynmath::SoftplusNode* sp_tab, int n_cus, hipStream_t s) {
+void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+                    int n_cus, hipStream_t s) {
   const dim3 grid(std::max(1, n_cus)), block(64 * DYN_WAVES_PER_GROUP);
-  const char* ib = static_cast<const char*>(in_base);
-  char* ob = static_cast<char*>(out_base);
-  if (job == JOB_TRAIN) hipLaunchKernelGGL((k_session<JOB_TRAIN, false>), grid, block, 0, s, a, ib, ob, sp_tab);
-  else if (job == JOB_TRAIN_ZCHECK) hipLaunchKernelGGL((k_session<JOB_TRAIN_ZCHECK, false>), grid, block, 0, s, a, ib, ob, sp_tab);
-  else if (with_strict) hipLaunchKernelGGL((k_session<JOB_ALIGN, true>), grid, block, 0, s, a, ib, ob, sp_tab);
-  else hipLaunchKernelGGL((k_session<JOB_ALIGN, false>), grid, block, 0, s, a, ib, ob, sp_tab);
+  if (with_strict)
+    hipLaunchKernelGGL((k_session<true>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
+  else
+    hipLaunchKernelGGL((k_session<false>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
 }
 
 void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s) {

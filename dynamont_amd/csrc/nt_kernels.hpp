@@ -142,7 +142,7 @@ struct SessionTicket {      // 128 bytes in device memory, written once per tick
   int64_t sig_off;          //   the ticket's signal pool (ReadDesc::sig_off counts doubles from here),
   int64_t par_off;          //   its per-column emission table (ReadDesc::par_off counts entries from here)
   int64_t st_off;           // from out_base: ReadState[], then the five TraceBuffers arrays
-  int64_t pp_off, pathn_off, segrow_off, medhi_off, medlo_off;   // a TRAINING ticket: col_w, col_s1, col_s2, trans in the first four
+  int64_t pp_off, pathn_off, segrow_off, medhi_off, medlo_off;
   int64_t tctl_off;         // the ticket's control block: [0] reads finished; 64-bit statistics from word SESSION_TSTATS on:
                             //   wave-cycles (shader clock) in backward / forward / traceback, [3] the reads' durations in 10 ns
                             //   ticks (s_memrealtime), [6..9] the certified sweeps apart (as QUEUE_STATS)
@@ -170,9 +170,9 @@ struct SessionArgs {
 };
 
 // n_cus workgroups of four waves on `s` -- which must own its hardware queue (hipExtStreamCreateWithCUMask)
-// job: JOB_ALIGN (with_strict: the variant that carries the certified sweeps), JOB_TRAIN or JOB_TRAIN_ZCHECK
-void launch_session(QueueJob job, bool with_strict, const SessionArgs& a, const void* in_base, void* out_base,
-                    const dynmath::SoftplusNode* sp_tab, int n_cus, hipStream_t s);
+// with_strict: the variant that carries the certified sweeps
+void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+                    int n_cus, hipStream_t s);
 // record `tk` as ticket `index` and make it visible (tail = index + 1); closed: no ticket will follow
 void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s);
 void launch_session_close(uint32_t* ctl, hipStream_t s);

@@ -238,8 +238,7 @@ int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
  * waves have left -- call it when the tickets of interest have been waited for. */
 int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out);
 /* enabled = 0: no resident read queue on this handle (one launch per batch, as DYN_NO_SESSION=1 does for a process).
- * enabled = 1: sessions of n_cus - reserved_cus workgroups, one per compute unit (a training session leaves 8 more free for
- * the radix sort of its pooled statistics). A resident session leaves 13 KB of LDS and 152 registers
+ * enabled = 1: sessions of n_cus - reserved_cus workgroups, one per compute unit. A resident session leaves 13 KB of LDS and 152 registers
  * per lane free on every CU it occupies: the library's own small kernels run beside it, RCCL's kernels (37 KB of LDS, 248-256
  * registers) do not -- a process that calls dyn_comm_* (or any other kernel of that size) WHILE tickets are in flight
  * reserves a few CUs for them (bench.py --gpus N: 8). Closes an open session first. Default: enabled, nothing reserved

@@ -722,7 +722,7 @@ def test_cfg5_share_full_size_train(models, al9):
     res = t.wait()
     tm = t.timing()
     t.close()
-    assert (res.status == 0).all() and tm["reads_ok"] == 1024 and tm["launches"] == 0   # (a ticket of the resident read queue)
+    assert (res.status == 0).all() and tm["reads_ok"] == 1024 and tm["launches"] == 1
     K = al9.num_kmers
     k = al9.kmer_size
     for i, r in enumerate(reads):

@@ -110,33 +110,3 @@ def test_no_session_environment_switch(models, monkeypatch):
         t.close()
     assert al.session_stats()["sessions"] == 0
     al.close()
-
-
-def test_training_tickets_in_the_resident_queue(models):
-    """train() tickets of >= 512 reads share a session of their own kind (k_session<JOB_TRAIN>): per-read Z, transitions and
-    emission updates and the pooled statistics are those of one launch per batch, bit for bit (per-read results do not depend
-    on the queue; the pooled sums are taken in a fixed order, pool_stats.hip)."""
-    al = Aligner(models["syn9"], "rna004", device=0)
-    data = _data(models, 3, 560, 4700, bases=(150, 300))
-    want = [al.train_batch([r.signal for r in reads], [r.sequence for r in reads], pooled=True) for reads, _ in data]
-    tickets = [al.train_async(*packed, pooled=True) for _, packed in data]
-    mixed = al.align_async(*data[0][1], True)   # another kind: closes the training session, opens an align session
-    for t, w in zip(tickets, want):
-        r = t.wait()
-        assert np.array_equal(r.status, w.status)
-        assert np.array_equal(r.Z.view(np.uint64), w.Z.view(np.uint64))
-        assert np.array_equal(r.transitions.view(np.uint64), w.transitions.view(np.uint64))
-        assert np.array_equal(r.em_count, w.em_count)
-        n = int(r.em_offsets[-1]) if hasattr(r, "em_offsets") and r.em_offsets is not None else 0
-        for name in ("em_code", "em_mean", "em_stdev"):
-            a_, b_ = getattr(r, name), getattr(w, name)
-            if a_ is not None and b_ is not None and n:
-                assert np.array_equal(np.asarray(a_[:n]).view(np.uint8), np.asarray(b_[:n]).view(np.uint8)), name
-        assert np.array_equal(r.pooled.view(np.uint64), w.pooled.view(np.uint64))
-        assert t.timing()["launches"] == 0
-    _same(mixed.wait(), al.align_batch([r.signal for r in data[0][0]], [r.sequence for r in data[0][0]], True))
-    for t in tickets + [mixed]:
-        t.close()
-    s = al.session_stats()
-    assert s["aborted"] == 0 and s["sessions"] >= 2 and s["tickets"] == 4
-    al.close()

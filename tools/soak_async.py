@@ -8,7 +8,7 @@ once per feature meets here in random order on recycled buffers.
     python tools/soak_async.py [tickets] [seed] [resident]
 
 `resident` (round 5): batches of up to 1 100 reads as well, so that tickets open, join, outgrow and close sessions of the
-RESIDENT read queue (align and train sessions alternate with one-launch-per-batch jobs on the same lattice pool) -- the
+RESIDENT read queue (sessions alternate with one-launch-per-batch jobs -- Z-only, training -- on the same lattice pool) -- the
 results must still be the synchronous calls' bit for bit.
 """
 import os, sys, tempfile, time
