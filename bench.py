@@ -108,6 +108,9 @@ def parse():
     ap.add_argument("--no-polya", action="store_true", help="skip the `cfg2_polya` record (N = 1: cfg2 with every read flagged)")
     ap.add_argument("--no-scale-ref", action="store_true", help="skip the `scale_ref` record (N = 1: configs[3]'s per-GPU share on one GPU)")
     ap.add_argument("--no-sessions", action="store_true", help="experiment: one launch per batch (no resident read queue)")
+    ap.add_argument("--exchange-stall-ms", type=float, default=60.0,
+                    help="N > 1: an exchange of the two untimed probe steps slower than this = RCCL's kernels are not served beside "
+                         "the resident read queue on this node; the ranks then run one launch per batch")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="N > 1: compute units kept free of the resident read queue for RCCL's kernels (dyn_aligner_set_session_mode)")
     ap.add_argument("--mode", default="align", choices=["align", "train"],
@@ -532,14 +535,26 @@ def main():
     elif args.no_sessions:
         al.set_session_mode(False)
 
-    m = measure(al, wl, args, args.steps, args.warmup, 0, args.mode, exch, sync)
     sessions_with_exchange = None
-    if use_dist and not args.no_sessions:
-        # were the exchanges of the WARM-UP steps served beside the resident waves? One that had to wait for a session to end
-        # takes tens of milliseconds (a session only ends when the pipeline has run dry): then the timed steps ran like that too,
-        # and the line says so
-        we = sorted(m["warmup_exchange_ms"] + m["exchange_ms"])
-        sessions_with_exchange = {"median_exchange_ms": round(we[len(we) // 2], 3) if we else None, "max_exchange_ms": round(we[-1], 3) if we else None}
+    resident_with_exchange = use_dist and not args.no_sessions
+    if resident_with_exchange:
+        # Are RCCL's kernels served beside the resident waves on this node? They need whole free CUs (37 KB of LDS, 248-256
+        # registers per lane); the reserved CUs are meant for them, but no multi-GPU node was available to see it happen. Two
+        # UNTIMED probe steps decide: an exchange that has to wait for a session to END takes as long as the pipeline needs to
+        # run dry (hundreds of milliseconds) instead of a few -- then every rank falls back to one launch per batch, together,
+        # and the line says so.
+        probe = measure(al, wl, args, 2, 0, 0, args.mode, exch, sync)
+        worst = max(probe["exchange_ms"]) if probe["exchange_ms"] else 0.0
+        t = torch.tensor([worst], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst = float(t.item())
+        served = worst < args.exchange_stall_ms
+        sessions_with_exchange = {"probe_worst_exchange_ms": round(worst, 3), "threshold_ms": args.exchange_stall_ms,
+                                  "exchanges_served_beside_sessions": served}
+        if not served:
+            al.set_session_mode(False)
+            resident_with_exchange = False
+    m = measure(al, wl, args, args.steps, args.warmup, 0, args.mode, exch, sync)
     elapsed = m["elapsed"]
     per_rank_ms = [elapsed * 1e3]
     if use_dist:
@@ -638,7 +653,7 @@ def main():
                 "bracket_collectives": f"torch.distributed ({backend}): communicator id broadcast, barriers, the reduction of the ranks' clocks",
                 "per_step_ms_rank0": {"median": round(sorted(m["exchange_ms"])[len(m["exchange_ms"]) // 2], 3), "max": round(max(m["exchange_ms"]), 3)} if m["exchange_ms"] else None,
                 "rows_gathered_rank0": exch.rows_gathered if args.mode == "align" else None,
-                "resident_queue": (not args.no_sessions), "reserved_cus": reserved_cus, "observed": sessions_with_exchange,
+                "resident_queue": resident_with_exchange, "reserved_cus": reserved_cus if resident_with_exchange else 0, "observed": sessions_with_exchange,
             }
             line["collective_backend"] = "rehearsal" if isinstance(exch, RehearsalExchange) else "rccl (dyn_comm_*)"
             if args.mode == "align":

@@ -485,26 +485,42 @@ static bool model_allows_strict(const dynhost::PoreModel& m) {
 // session occupies every CU it may use (one workgroup each, 150 KB of LDS), and a kernel of another stream that needs more
 // than the 13 KB of LDS and 152 registers per lane they leave free -- RCCL's (37 KB, 248-256 registers) -- would otherwise
 // not start before the session ends.
+// CU-masked streams are PARKED per device, never destroyed: the second hipStreamDestroy of such a stream in a process did
+// not return on this runtime (ROCm 7.2; tools/sess_mode_probe.py and a CLI run in a loop both stopped there), and a parked
+// stream costs one idle hardware queue.
+static std::mutex g_sess_stream_m;
+static std::vector<hipStream_t> g_sess_streams[32];
+static void park_session_stream(dyn_aligner* a) {
+  if (!a->s_session) return;
+  std::lock_guard<std::mutex> lk(g_sess_stream_m);
+  if (a->device >= 0 && a->device < 32) g_sess_streams[a->device].push_back(a->s_session);
+  a->s_session = nullptr;
+}
+
 static int make_session_stream(dyn_aligner* a, int reserved_cus) {
-  if (a->s_session) {
-    (void)hipStreamDestroy(a->s_session);
-    a->s_session = nullptr;
+  if (!a->s_session && a->device >= 0 && a->device < 32) {
+    std::lock_guard<std::mutex> lk(g_sess_stream_m);
+    if (!g_sess_streams[a->device].empty()) {
+      a->s_session = g_sess_streams[a->device].back();
+      g_sess_streams[a->device].pop_back();
+    }
   }
   // Reserved CUs are not masked out: a session is ONE workgroup per CU it uses (150 KB of LDS each), so a grid of
-  // n_cus - reserved workgroups leaves `reserved` CUs empty wherever the dispatcher puts it. The mask enables every CU; what
-  // it buys is the hardware queue.
+  // n_cus - reserved workgroups leaves `reserved` CUs empty wherever the dispatcher puts it. The mask enables every CU (the
+  // stream serves any mode); what it buys is the hardware queue.
   a->sess_cus = std::max(1, a->n_cus - std::max(0, reserved_cus));
-  std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0u);
-  for (int c = 0; c < a->n_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-  if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-    (void)hipGetLastError();
-    a->s_session = nullptr;
-    return DYN_ERR_DEVICE;
+  if (!a->s_session) {
+    std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0u);
+    for (int c = 0; c < a->n_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+    if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      a->s_session = nullptr;
+      return DYN_ERR_DEVICE;
+    }
   }
   if (!a->sess_flags && hipHostMalloc(reinterpret_cast<void**>(&a->sess_flags), SESSION_FLAGS * 4, hipHostMallocCoherent) != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipStreamDestroy(a->s_session);
-    a->s_session = nullptr;
+    park_session_stream(a);
     a->sess_flags = nullptr;
     return DYN_ERR_DEVICE;
   }
@@ -518,8 +534,7 @@ int dyn_aligner_set_session_mode(dyn_aligner* a, int enabled, int reserved_cus) 
   if (int rc = need_device(a)) return rc;
   if (int rc = session_quiesce(a)) return rc;
   if (!enabled) {
-    if (a->s_session) (void)hipStreamDestroy(a->s_session);
-    a->s_session = nullptr;
+    park_session_stream(a);
     return DYN_OK;
   }
   if (reserved_cus >= a->n_cus) return DYN_ERR_INVALID_ARGUMENT;
@@ -562,7 +577,8 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   auto fail = [&](hipError_t e, const char* what) {
     copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
                               " (the MI355X build has no CPU compute path)");
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_session})
+    park_session_stream(a);
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
       if (s) (void)hipStreamDestroy(s);
     if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->d_model.release();
@@ -644,7 +660,8 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->cache.park(a->device);
     if (trace) std::fprintf(stderr, "[dyn] destroy %p: buffers parked; destroying streams\n", (void*)a);
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_session})
+    park_session_stream(a);
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
       if (s) (void)hipStreamDestroy(s);
     if (trace) std::fprintf(stderr, "[dyn] destroy %p: done\n", (void*)a);
   }
@@ -1786,8 +1803,7 @@ int session_publish(dyn_batch* b) {
   HIP_TRY(a, b->h_stats.ensure(dynk::SESSION_TCTL_WORDS * 4));
   std::memset(b->h_stats.p, 0, dynk::SESSION_TCTL_WORDS * 4);
   volatile uint32_t* flag = a->sess_flags + (ss.flag_seq++ % SESSION_FLAGS);
-  *flag = 0;
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  __atomic_store_n(const_cast<uint32_t*>(flag), 0u, __ATOMIC_SEQ_CST);  // (before the record that names it is published)
 
   const char* in_base = static_cast<const char*>(a->d_model.p);
   const char* out_base = static_cast<const char*>(a->sess_anchor.p);

@@ -88,6 +88,7 @@ struct dyn_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1, device = 0;
   hipStream_t stream = nullptr;
+  bool stream_masked = false;    // created with hipExtStreamCreateWithCUMask (a hardware queue of its own)
   uint64_t* d_counts = nullptr;  // [n_ranks] rows per rank (all-gather target)
   void* d_recv = nullptr;        // root: gathered rows
   size_t recv_bytes = 0;
@@ -180,6 +181,8 @@ int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn
       if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();
         c->stream = nullptr;
+      } else {
+        c->stream_masked = true;
       }
     }
   }
@@ -201,7 +204,8 @@ void dyn_comm_destroy(dyn_comm* c) {
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_recv) (void)hipFree(c->d_recv);
   for (void* p : c->retired) (void)hipFree(p);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  // (a CU-masked stream is left to the runtime: destroying a second one in a process did not return on ROCm 7.2, dynamont_mi.cpp)
+  if (c->stream && !c->stream_masked) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 

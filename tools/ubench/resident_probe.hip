@@ -90,6 +90,26 @@ __global__ void k_fill(double* __restrict__ p, int n, double v) {
   if (i < n) p[i] = s / 48.0;
 }
 
+// an auxiliary kernel of RCCL's footprint: 40 KB of LDS, 248 VGPRs -- fits no CU a resident workgroup occupies
+__global__ __launch_bounds__(256) void k_big(double* __restrict__ p, int n) {
+  __shared__ double lds[40 * 1024 / 8];
+  asm volatile("v_mov_b32 v247, 0" ::: "v247");
+  lds[threadIdx.x] = (double)threadIdx.x;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = lds[(threadIdx.x + 1) & 255];
+}
+
+// the same with SCRATCH (a dynamically indexed private array), as RCCL's and rocPRIM's kernels have
+__global__ __launch_bounds__(256) void k_scratch(double* __restrict__ p, int n, int rot) {
+  double a[96];
+  for (int k = 0; k < 96; ++k) a[k] = (double)(k * rot);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sacc = 0.0;
+  for (int k = 0; k < 8; ++k) sacc += a[(i * 7 + k * rot) % 96];   // dynamic index: the array lives in scratch
+  if (i < n) p[i] = sacc;
+}
+
 // waits (bounded) until every resident wave has seen ticket `tail`: the k_wait_ticket of the design
 __global__ void k_wait_seen(uint32_t* ctl, uint32_t want, unsigned long long limit_ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -180,8 +200,67 @@ static int run(const char* name, int stream_kind, int extra_streams, bool payloa
   return ok;
 }
 
-int main() {
+// Kernels that need a WHOLE free CU (and scratch) beside a resident kernel that occupies n_cus - free_cus CUs: are they served,
+// and how fast? (RCCL's exchange kernels at N > 1; rocPRIM's radix sort behind a training ticket.)
+static void run_big(const char* name, int free_cus, int kind) {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int n_cus = prop.multiProcessorCount;
+  hipStream_t s_res = nullptr, s_aux = nullptr;
+  std::vector<uint32_t> mask((n_cus + 31) / 32, 0xffffffffu);
+  CK(hipExtStreamCreateWithCUMask(&s_res, (uint32_t)mask.size(), mask.data()));
+  CK(hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking));
+  uint32_t* ctl = nullptr;
+  double *payload = nullptr, *sink = nullptr, *buf = nullptr;
+  CK(hipMalloc(&ctl, 256));
+  CK(hipMalloc(&payload, PAYLOAD * 8));
+  CK(hipMalloc(&sink, 8));
+  CK(hipMalloc(&buf, 1 << 22));
+  CK(hipMemset(ctl, 0, 256));
+  CK(hipDeviceSynchronize());
+  const double limit_s = 3.0;
+  const double t0 = now();
+  hipLaunchKernelGGL(k_resident, dim3(n_cus - free_cus), dim3(256), 0, s_res, ctl, payload, sink, (unsigned long long)(limit_s * 1e8));
+  CK(hipGetLastError());
+  double worst = 0, sum = 0, first = 0;
+  int done = 0;
+  for (int it = 0; it < 20; ++it) {
+    const double a = now();
+    if (kind == 0) hipLaunchKernelGGL(k_big, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
+    else hipLaunchKernelGGL(k_scratch, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256, it + 1);
+    CK(hipStreamSynchronize(s_aux));
+    const double dt = now() - a;
+    if (!it) first = dt;
+    else {
+      worst = std::max(worst, dt);
+      sum += dt;
+    }
+    ++done;
+    if (now() - t0 > limit_s - 0.5) break;
+  }
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_aux, ctl, 0u, 1u);
+  CK(hipStreamSynchronize(s_aux));
+  CK(hipStreamSynchronize(s_res));
+  printf("%-44s %2d/20 launches beside a resident kernel on %d of %d CUs: first %9.1f us, then mean %8.1f us worst %9.1f us%s\n", name, done, n_cus - free_cus, n_cus,
+         1e6 * first, done > 1 ? 1e6 * sum / (done - 1) : 0.0, 1e6 * worst, done < 20 ? "   <-- WAITED for the resident kernel to leave" : "");
+  fflush(stdout);
+  CK(hipFree(ctl));
+  CK(hipFree(payload));
+  CK(hipFree(sink));
+  CK(hipFree(buf));
+  CK(hipStreamDestroy(s_res));
+  CK(hipStreamDestroy(s_aux));
+}
+
+int main(int argc, char** argv) {
   CK(hipSetDevice(0));
+  if (argc > 1 && !strcmp(argv[1], "big")) {
+    run_big("40 KB LDS + 248 VGPRs, no CU free", 0, 0);
+    run_big("40 KB LDS + 248 VGPRs, 8 CUs free", 8, 0);
+    run_big("scratch kernel, no CU free", 0, 1);
+    run_big("scratch kernel, 8 CUs free", 8, 1);
+    return 0;
+  }
   int ok = 1;
   ok &= run("plain streams, payload by kernel", 0, 0, false);
   ok &= run("plain streams, payload by H2D copy", 0, 0, true);
