@@ -292,10 +292,12 @@ void Pipeline::back_loop() {
     }
     int rc = w.rc;
     if (rc == DYN_OK) rc = back_stage(w.b, w.grp);
-    if (rc != DYN_OK && w.b->in_session && !a->host_only) {  // a session that lost a ticket takes no more of them
+    if (rc != DYN_OK && w.b->in_session && !a->host_only) {
+      // A session that lost a ticket takes no more of them -- and has LEFT before the ticket's buffers go back to the cache:
+      // its waves may still be writing results of that ticket (they leave at the close mark, or when the idle watchdog fires)
       std::lock_guard<std::mutex> lk(a->mu);
       (void)hipSetDevice(a->device);
-      (void)session_close(a);
+      (void)session_quiesce(a);
     }
     {
       std::lock_guard<std::mutex> lk(m);
@@ -537,9 +539,22 @@ int Pipeline::wait_resident(dyn_batch* b) {
   const double t0 = now_ms();
   const double limit_ms = 1e3 * (std::getenv("DYN_SESSION_WAIT_S") ? std::atof(std::getenv("DYN_SESSION_WAIT_S")) : 300.0);
   uint32_t* h = b->h_stats.as<uint32_t>();  // pinned; the statistics copy overwrites it afterwards
+  bool published = false;  // events[0]: the counter has been cleared on the device (session_publish)
   for (uint64_t spin = 0;; ++spin) {
     if (*b->sess_flag == b->sess_reads) return DYN_OK;
-    if ((spin & 63) == 63) {
+    if ((spin & 63) == 63 && !published) {
+      const hipError_t q = hipEventQuery(b->events[0]);
+      if (q == hipSuccess) published = true;
+      else {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error of this thread's next launch
+        if (q != hipErrorNotReady) P_TRY(b, q);
+        if (now_ms() - t0 > limit_ms) {
+          b->error = "the copy-in stream did not reach the ticket's record within DYN_SESSION_WAIT_S seconds";
+          return DYN_ERR_DEVICE;
+        }
+      }
+    }
+    if ((spin & 63) == 63 && published) {
       const double c0 = now_ms();
       P_TRY(b, hipMemcpyAsync(h, b->d_tctl.p, 4, hipMemcpyDeviceToHost, a->s_out));
       P_TRY(b, hipMemcpyAsync(h + 1, a->sess_ctl[b->sess_blk].as<uint32_t>() + dynk::S_ABORT, 4, hipMemcpyDeviceToHost, a->s_out));

@@ -1838,6 +1838,9 @@ int session_publish(dyn_batch* b) {
     HIP_TRY(a, hipEventCreate(&e));
     b->events.push_back(e);
   }
+  // events[0]: the ticket's counter has been cleared and its record published. Until then d_tctl holds what the buffer's last
+  // ticket left there (its full count, often the same number of reads): wait_resident must not read it earlier.
+  HIP_TRY(a, hipEventRecord(b->events[0], a->s_in));
   tm.reads_ok = n_ok;
   tm.reads_strict = (uint32_t)n_strict;
   tm.launch_share = 0.0;

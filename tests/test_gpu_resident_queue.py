@@ -110,3 +110,25 @@ def test_no_session_environment_switch(models, monkeypatch):
         t.close()
     assert al.session_stats()["sessions"] == 0
     al.close()
+
+
+def test_recycled_tickets_of_equal_size_with_long_copies(models):
+    """Round 5 regression: a ticket's completion counter lives in a recycled device buffer and is cleared on the copy-in
+    stream BEHIND the ticket's copies; the host's second opinion read it before that -- and found the full count of the
+    buffer's last ticket (the same number of reads), so the per-segment kernels ran on a ticket whose reads had not started
+    (a GPU memory fault with 4 096-read batches in the plain arithmetic, where the host is quickest). Every ticket must
+    be the one-launch-per-batch result, however long its copies take."""
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    reads = synth.make_reads(4700, 4096, "rna004", mean, sd, 2000)
+    packed = synth.pack_reads(reads)
+    al = Aligner(models["syn9"], "rna004", device=0)
+    al.set_strict("off")  # no tie search on the host: the publish follows the copies at once
+    want = al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True)
+    for rnd in range(3):  # from the second round on every buffer is a recycled one
+        tickets = [al.align_async(*packed, True) for _ in range(4)]
+        for t in tickets:
+            _same(t.wait(), want)
+            assert t.timing()["launches"] == 0
+            t.close()
+    assert al.session_stats()["aborted"] == 0
+    al.close()

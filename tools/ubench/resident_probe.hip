@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   lds[threadIdx.x] = 1.0;
   asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a103, 0" ::: "v255", "a103");
   const int lane = threadIdx.x & 63;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(&ctl[CTL_ARRIVED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t seen = 0;
   double acc = 0.0;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       continue;
     }
     if (__builtin_amdgcn_readfirstlane((int)ld_agent(&ctl[CTL_CLOSED]))) break;
-    if (__builtin_amdgcn_s_memtime() - t0 > limit_ticks) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) {
       if (lane == 0) __hip_atomic_store(&ctl[CTL_TIMEOUT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
@@ -110,11 +110,22 @@ __global__ __launch_bounds__(256) void k_scratch(double* __restrict__ p, int n, 
   if (i < n) p[i] = sacc;
 }
 
+// rocPRIM's radix sort shape: 1 024-thread workgroups, 20 KB of LDS, scratch
+__global__ __launch_bounds__(1024) void k_wide(double* __restrict__ p, int n, int rot) {
+  __shared__ double lds[20 * 1024 / 8];
+  double a[40];
+  for (int k = 0; k < 40; ++k) a[k] = (double)(k * rot);
+  lds[threadIdx.x] = a[(threadIdx.x * rot) % 40];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = lds[(threadIdx.x + 1) & 1023];
+}
+
 // waits (bounded) until every resident wave has seen ticket `tail`: the k_wait_ticket of the design
 __global__ void k_wait_seen(uint32_t* ctl, uint32_t want, unsigned long long limit_ticks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (ld_agent(&ctl[CTL_SEEN]) < want) {
-    if (__builtin_amdgcn_s_memtime() - t0 > limit_ticks) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) {
       __hip_atomic_store(&ctl[CTL_TIMEOUT], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
@@ -147,7 +158,7 @@ static int run(const char* name, int stream_kind, int extra_streams, bool payloa
   CK(hipMemset(payload, 0, PAYLOAD * 8));
   CK(hipDeviceSynchronize());
   const double limit_s = 4.0;
-  const unsigned long long limit_ticks = (unsigned long long)(limit_s * 1e8);  // s_memtime: 100 MHz
+  const unsigned long long limit_ticks = (unsigned long long)(limit_s * 1e8);  // s_memrealtime: 100 MHz (s_memtime is the shader clock, ~2.2 GHz)
   const double t0 = now();
   hipLaunchKernelGGL(k_resident, dim3(n_cus), dim3(256), 0, s_res, ctl, payload, sink, limit_ticks);
   CK(hipGetLastError());
@@ -227,7 +238,8 @@ static void run_big(const char* name, int free_cus, int kind) {
   for (int it = 0; it < 20; ++it) {
     const double a = now();
     if (kind == 0) hipLaunchKernelGGL(k_big, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
-    else hipLaunchKernelGGL(k_scratch, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256, it + 1);
+    else if (kind == 1) hipLaunchKernelGGL(k_scratch, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256, it + 1);
+    else hipLaunchKernelGGL(k_wide, dim3(64), dim3(1024), 0, s_aux, buf, 64 * 1024, it + 1);
     CK(hipStreamSynchronize(s_aux));
     const double dt = now() - a;
     if (!it) first = dt;
@@ -259,6 +271,8 @@ int main(int argc, char** argv) {
     run_big("40 KB LDS + 248 VGPRs, 8 CUs free", 8, 0);
     run_big("scratch kernel, no CU free", 0, 1);
     run_big("scratch kernel, 8 CUs free", 8, 1);
+    run_big("1024-thread workgroups + scratch, no CU free", 0, 2);
+    run_big("1024-thread workgroups + scratch, 8 CUs free", 8, 2);
     return 0;
   }
   int ok = 1;
