@@ -74,7 +74,7 @@ class DynTiming(C.Structure):
 class DynSessionStats(C.Structure):
     _fields_ = [("sessions", C.c_uint64), ("tickets", C.c_uint64), ("reads", C.c_uint64), ("cells", C.c_uint64), ("ms", C.c_double),
                 ("wave_cycles_busy", C.c_uint64), ("wave_cycles_idle", C.c_uint64), ("wave_cycles_life", C.c_uint64),
-                ("waves", C.c_uint64), ("aborted", C.c_uint64)]
+                ("waves", C.c_uint64), ("aborted", C.c_uint64), ("republished", C.c_uint64)]
 
 
 # every symbol include/dynamont_mi.h declares: name -> (restype, argtypes)

@@ -535,6 +535,8 @@ int Pipeline::front_stage(dyn_batch* b) {
 // A ticket of the resident read queue is complete when the wave that finished its last read has raised the ticket's word
 // in pinned host memory. Polled with short sleeps; every few milliseconds the ticket's own counter and the session's abort
 // word are copied out as a second opinion (a word that never arrives must not hang the pipeline), and the wait is bounded.
+constexpr int SESSION_LOST = -1000;  // wait_resident -> back_stage only
+
 int Pipeline::wait_resident(dyn_batch* b) {
   const double t0 = now_ms();
   const double limit_ms = 1e3 * (std::getenv("DYN_SESSION_WAIT_S") ? std::atof(std::getenv("DYN_SESSION_WAIT_S")) : 300.0);
@@ -564,6 +566,11 @@ int Pipeline::wait_resident(dyn_batch* b) {
         std::fprintf(stderr, "[dyn] back  %p: second opinion took %.1f ms to enqueue, %.1f ms to complete (flag %u, counter %u of %u)\n", (void*)b, c1 - c0,
                      now_ms() - c1, *b->sess_flag, h[0], b->sess_reads);
       if (h[0] == b->sess_reads) return DYN_OK;  // the counter is there; the word is on its way
+      // The session aborted (its waves found nothing to do for DYN_SESSION_IDLE_S seconds -- a slow front stage, a stopped
+      // host -- and left), or its control block already serves a later session: the ticket was published to waves that are
+      // gone. It is published again, at most twice (back_stage).
+      const bool lost = h[1] != 0 || a->sess.blk_gen[b->sess_blk].load() != b->sess_gen;
+      if (lost && b->sess_retries < 2) return SESSION_LOST;
       const bool aborted = h[1] != 0, late = now_ms() - t0 > limit_ms;
       if (aborted || late) {
         // what the queue looked like: reads claimed, tickets published, closed, abort -- and this ticket's own counter
@@ -587,7 +594,18 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
   const double t0 = now_ms();
   int rc = DYN_OK;
   if (b->in_session) {
-    rc = wait_resident(b);
+    while ((rc = wait_resident(b)) == SESSION_LOST) {
+      std::lock_guard<std::mutex> lk(a->mu);
+      P_TRY(b, hipSetDevice(a->device));
+      if (g_trace) std::fprintf(stderr, "[dyn] back  %p: the ticket's session aborted before it took all of its reads; publishing it again\n", (void*)b);
+      bool again = false;
+      rc = session_recover(b, &again);
+      if (rc != DYN_OK) {
+        b->error = a->last_error;
+        return rc;
+      }
+      if (!again) break;  // complete after all
+    }
     if (rc != DYN_OK) return rc;
     // the per-segment kernels and the copies out, beside the resident waves
     const double f0 = now_ms();

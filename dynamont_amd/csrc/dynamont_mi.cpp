@@ -1548,7 +1548,9 @@ int session_collect(dyn_aligner* a, int blk) {
   float ms = 0.f;
   HIP_TRY(a, hipEventElapsedTime(&ms, ss.ev_begin[blk], ss.ev_end[blk]));
   HIP_TRY(a, a->sess_hctl.ensure(dynk::SESSION_CTL_WORDS * 4));
-  HIP_TRY(a, hipMemcpy(a->sess_hctl.p, a->sess_ctl[blk].p, dynk::SESSION_CTL_WORDS * 4, hipMemcpyDeviceToHost));
+  // (not a null-stream copy: that one would also wait for a later session that is still open)
+  HIP_TRY(a, hipMemcpyAsync(a->sess_hctl.p, a->sess_ctl[blk].p, dynk::SESSION_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->s_out));
+  HIP_TRY(a, hipStreamSynchronize(a->s_out));
   const uint32_t* cw = a->sess_hctl.as<uint32_t>();
   const uint64_t* st = reinterpret_cast<const uint64_t*>(cw + dynk::SESSION_STATS);
   dyn_session_stats& t = a->sess_total;
@@ -1622,6 +1624,7 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   a->sess_open_hint.store(true);
   ss.mixed = mixed;
   ss.blk = blk;
+  ss.blk_gen[blk].store(++ss.gen);
   ss.published = 0;
   ss.next_base = 0;
   ss.log_r = log_r;
@@ -1861,10 +1864,44 @@ int session_publish(dyn_batch* b) {
   b->sess_reads = (uint32_t)n_ok;
   b->sess_waves = ss.n_waves;
   b->sess_blk = ss.blk;
+  b->sess_gen = ss.gen;
   b->sess_flag = flag;
   b->sess_max_N = max_N;
   b->sess_rows_total = rows_total;
   return DYN_OK;
+}
+
+int session_recover(dyn_batch* b, bool* republished) {
+  dyn_aligner* a = b->a;
+  Session& ss = a->sess;
+  *republished = false;
+  const bool mine_open = ss.open && ss.gen == b->sess_gen;
+  if (mine_open) {
+    // the host still believes in the session that aborted: close it and wait until its kernel has left
+    if (int rc = session_quiesce(a)) return rc;
+  } else if (ss.pending[b->sess_blk] && ss.blk_gen[b->sess_blk].load() == b->sess_gen) {
+    HIP_TRY(a, hipEventSynchronize(ss.ev_end[b->sess_blk]));
+    if (int rc = session_collect(a, b->sess_blk)) return rc;
+  }
+  // (otherwise the block has been cleared for a later session: the lost one ended long ago)
+  // The abort word may have been raised by a wave that idled while OTHERS were still busy with this ticket's last reads: now
+  // that the kernel has ended, the counter says whether anything is missing.
+  // (on the copy-out stream: a null-stream copy would wait for a LATER session that is open, and that one waits for us)
+  uint32_t* count = b->h_stats.as<uint32_t>();
+  HIP_TRY(a, hipMemcpyAsync(count, b->d_tctl.p, 4, hipMemcpyDeviceToHost, a->s_out));
+  HIP_TRY(a, hipStreamSynchronize(a->s_out));
+  if (*count == b->sess_reads) return DYN_OK;
+  const SessionNeed need = session_need(b);
+  if (ss.open) {
+    const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
+                      (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull && (ss.mixed || a->strict_mode == 0);
+    if (!fits)
+      if (int rc = session_quiesce(a)) return rc;  // (the pool may have to grow: nothing may be using it)
+  }
+  b->sess_retries += 1;
+  a->sess_total.republished += 1;
+  *republished = true;
+  return session_publish(b);
 }
 
 // the ticket's reads are done (its completion word has been seen): per-segment kernels, statistics

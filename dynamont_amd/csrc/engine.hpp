@@ -117,6 +117,10 @@ struct Session {
   uint32_t pend_waves[2] = {0, 0};
   hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
   uint64_t flag_seq = 0;        // next completion word
+  // which session runs (or ran last) on a control block: a ticket remembers its session's number, and a block that has moved on
+  // to a later session while the ticket is incomplete has LOST it (wait_resident -> session_recover)
+  std::atomic<uint64_t> blk_gen[2] = {{0}, {0}};
+  uint64_t gen = 0;
 };
 
 }  // namespace dyneng
@@ -246,6 +250,8 @@ struct dyn_batch {
   uint32_t sess_reads = 0;             // reads published (the value its completion word reaches)
   uint32_t sess_waves = 0;
   int sess_blk = 0;                    // the session's control block
+  uint64_t sess_gen = 0;               // ... and the session's number (Session::blk_gen)
+  int sess_retries = 0;                // times the ticket was published again after its session had aborted
   volatile uint32_t* sess_flag = nullptr;
   dyneng::DevBuf d_tctl;               // the ticket's control block (reads done, wave-cycle statistics)
   uint32_t sess_max_N = 0;
@@ -293,6 +299,11 @@ int session_plan(dyn_batch* b, bool* use);
 // descriptors, per-read state, control block -> copy-in stream; the ticket's record published behind them (opens the
 // session first if none is open). The ticket's inputs must already be enqueued on the copy-in stream.
 int session_publish(dyn_batch* b);
+// The ticket's session is gone (its waves left at the idle watchdog) and the ticket is incomplete: wait until that session's
+// kernel has ended, then publish the ticket again -- into the session that is open now if it fits, else into a new one.
+// All of its reads are redone (the results of those that had finished are the same). *republished = false: nothing was
+// missing after all (the waves that were still busy finished the ticket before they left). Caller holds a->mu.
+int session_recover(dyn_batch* b, bool* republished);
 // the per-segment kernels and the statistics copy of a COMPLETED session ticket, on `s`
 int session_finish_enqueue(dyn_batch* b, hipStream_t s);
 int session_collect_timing(dyn_batch* b);

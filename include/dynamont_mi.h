@@ -201,7 +201,10 @@ typedef struct dyn_timing {
  * 0, launch_share = 0; the sessions themselves are accounted for here -- ms is the sum of the session kernels' durations
  * (HIP events on the session stream), which is what the roofline of a run must be taken over. Everything else (training,
  * Z-only jobs, small or page-starved batches, the synchronous calls) runs as one launch per batch as before; a handle
- * whose session stream cannot be created, or with DYN_NO_SESSION=1 in the environment, never opens a session. */
+ * whose session stream cannot be created, or with DYN_NO_SESSION=1 in the environment, never opens a session.
+ * Resident waves that find no work for DYN_SESSION_IDLE_S seconds (default 20) while the session is held open leave on
+ * their own (`aborted`); a ticket that was published after that is published again into the next session, its results
+ * unchanged (`republished`). */
 typedef struct dyn_session_stats {
   uint64_t sessions;       /* closed sessions */
   uint64_t tickets, reads, cells;
@@ -209,6 +212,7 @@ typedef struct dyn_session_stats {
   uint64_t wave_cycles_busy, wave_cycles_idle, wave_cycles_life;   /* shader-clock cycles, summed over waves and sessions */
   uint64_t waves;          /* sum over sessions of waves launched */
   uint64_t aborted;        /* sessions whose waves raised the abort word (idle watchdog) */
+  uint64_t republished;    /* tickets published again because their session had aborted before it took them */
 } dyn_session_stats;
 
 /* aligner_bindings.cpp:18-32 poreTypeFromString. Unknown -> DYN_ERR_INVALID_ARGUMENT,

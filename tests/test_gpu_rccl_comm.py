@@ -117,6 +117,10 @@ def test_bench_exchange_through_dyn_comm_beside_the_resident_queue():
     import subprocess
     import sys
     from conftest import ROOT
+    import dynamont_amd
+    # the pools this process' earlier tests parked would leave the child too little memory for an arena per resident wave
+    # (it would then run one launch per batch: session_plan's page-starved exit)
+    dynamont_amd.release_cached_memory()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(DYN_BENCH_FORCE_DIST="1", PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batches", "2", "--no-plain", "--no-cpu-baseline",

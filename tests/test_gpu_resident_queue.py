@@ -132,3 +132,29 @@ def test_recycled_tickets_of_equal_size_with_long_copies(models):
             t.close()
     assert al.session_stats()["aborted"] == 0
     al.close()
+
+
+def test_a_ticket_published_to_waves_that_have_left_is_published_again(models, monkeypatch):
+    """The idle watchdog (DYN_SESSION_IDLE_S, 20 s by default; 5 ms here): resident waves that find nothing to do while the
+    host still holds the session open raise the abort word and leave -- a front stage that takes longer than that (here:
+    staging 4 096 reads behind a ticket of 600 tiny ones) then publishes its ticket to waves that are gone. The back thread
+    sees the abort word, waits for the kernel's end and publishes the ticket again; the results are the synchronous call's."""
+    monkeypatch.setenv("DYN_SESSION_IDLE_S", "0.005")
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    tiny = synth.make_reads(4800, 600, "rna004", mean, sd, (30, 40))
+    big = synth.make_reads(4801, 4096, "rna004", mean, sd, 2000)
+    al = Aligner(models["syn9"], "rna004", device=0)
+    want_tiny = al.align_batch([r.signal for r in tiny], [r.sequence for r in tiny], True)
+    want_big = al.align_batch([r.signal for r in big], [r.sequence for r in big], True)
+    p_tiny, p_big = synth.pack_reads(tiny), synth.pack_reads(big)
+    for rnd in range(2):
+        t0 = al.align_async(*p_tiny, True)   # opens a session; its reads are done within a millisecond
+        t1 = al.align_async(*p_big, True)    # in flight (the session stays open) but tens of ms away from its publish
+        _same(t0.wait(), want_tiny)
+        _same(t1.wait(), want_big)
+        assert t1.timing()["launches"] == 0
+        t0.close(), t1.close()
+    s = al.session_stats()
+    assert s["aborted"] >= 1 and s["republished"] >= 1, s
+    assert s["reads"] >= 2 * (600 + 4096)
+    al.close()
