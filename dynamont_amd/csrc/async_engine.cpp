@@ -568,11 +568,11 @@ int Pipeline::wait_resident(dyn_batch* b) {
       if (h[0] == b->sess_reads) return DYN_OK;  // the counter is there; the word is on its way
       // The session aborted (its waves found nothing to do for DYN_SESSION_IDLE_S seconds -- a slow front stage, a stopped
       // host -- and left), or its control block already serves a later session: the ticket was published to waves that are
-      // gone. It is published again, at most twice (back_stage).
+      // gone, or to waves that stop taking reads. back_stage waits for that kernel's end and publishes again what is incomplete
+      // then (session_recover: at most twice).
       const bool lost = h[1] != 0 || a->sess.blk_gen[b->sess_blk].load() != b->sess_gen;
-      if (lost && b->sess_retries < 2) return SESSION_LOST;
-      const bool aborted = h[1] != 0, late = now_ms() - t0 > limit_ms;
-      if (aborted || late) {
+      if (lost) return SESSION_LOST;
+      if (now_ms() - t0 > limit_ms) {
         // what the queue looked like: reads claimed, tickets published, closed, abort -- and this ticket's own counter
         uint32_t* cw = h + 2;
         P_TRY(b, hipMemcpyAsync(cw, a->sess_ctl[b->sess_blk].p, 16, hipMemcpyDeviceToHost, a->s_out));
@@ -580,8 +580,7 @@ int Pipeline::wait_resident(dyn_batch* b) {
         char what[256];
         std::snprintf(what, sizeof what, " (reads claimed %u, tickets published %u, closed %u, abort %u; this ticket: %u of %u reads done)", cw[0], cw[1],
                       cw[2], cw[3], h[0], b->sess_reads);
-        b->error = std::string(aborted ? "the resident read queue aborted: its waves found no work for DYN_SESSION_IDLE_S seconds while this ticket was pending"
-                                       : "the resident read queue did not finish a ticket within DYN_SESSION_WAIT_S seconds") + what;
+        b->error = std::string("the resident read queue did not finish a ticket within DYN_SESSION_WAIT_S seconds") + what;
         return DYN_ERR_DEVICE;
       }
     }

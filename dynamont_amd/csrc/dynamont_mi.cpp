@@ -606,7 +606,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   if (!std::getenv("DYN_NO_SESSION")) {
     const char* rsv = std::getenv("DYN_SESSION_RESERVE_CUS");
     (void)make_session_stream(a, rsv ? std::atoi(rsv) : 0);  // failure: the handle simply has no resident read queue
-    if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.05, std::atof(f));
+    if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.001, std::atof(f));
   }
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
   if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
@@ -1891,6 +1891,13 @@ int session_recover(dyn_batch* b, bool* republished) {
   HIP_TRY(a, hipMemcpyAsync(count, b->d_tctl.p, 4, hipMemcpyDeviceToHost, a->s_out));
   HIP_TRY(a, hipStreamSynchronize(a->s_out));
   if (*count == b->sess_reads) return DYN_OK;
+  if (b->sess_retries >= 2) {
+    char msg[200];
+    std::snprintf(msg, sizeof msg, "the resident read queue aborted under this ticket three times (its waves found no work for DYN_SESSION_IDLE_S "
+                  "seconds while it was pending): %u of %u reads done", *count, b->sess_reads);
+    a->last_error = msg;
+    return DYN_ERR_DEVICE;
+  }
   const SessionNeed need = session_need(b);
   if (ss.open) {
     const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&

@@ -1545,6 +1545,9 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   for (;;) {
     const uint64_t t0 = __builtin_amdgcn_s_memtime();      // shader clock: phase shares
     const uint64_t r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: durations
+    // An aborted session takes no more reads: the waves that idled into the watchdog have left, the host publishes what is
+    // incomplete again elsewhere (session_recover) -- a few busy waves must not work the queue off on their own meanwhile.
+    if (sctl_load(&ctl[S_ABORT])) break;
     uint32_t h = 0;
     if (w.lane == 0) h = __hip_atomic_fetch_add(&ctl[S_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);

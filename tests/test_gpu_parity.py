@@ -388,6 +388,23 @@ def _full_size_properties(reads, res, k):
     assert np.all(np.isfinite(res.Z))
 
 
+def _resident_queue_gives_the_same(al, packed, res):
+    """The same batch as an asynchronous ticket -- the RESIDENT read queue (no launch of its own) -- must be the one-launch
+    result bit for bit: Z bits, integer columns, probabilities. (What bench.py times is this path.)"""
+    t = al.align_async(*packed, True)
+    got = t.wait()
+    tm = t.timing()
+    assert tm["launches"] == 0 and tm["reads_ok"] == int((res.status == 0).sum())
+    assert np.array_equal(got.status, res.status) and np.array_equal(got.Z.view(np.uint64), res.Z.view(np.uint64))
+    assert np.array_equal(got.n_segments, res.n_segments) and np.array_equal(got.seg_offsets, res.seg_offsets)
+    m = int(res.seg_offsets[-1])
+    assert np.array_equal(got.signal_positions[:m], res.signal_positions[:m])
+    assert np.array_equal(got.sequence_positions[:m], res.sequence_positions[:m])
+    assert np.array_equal(got.probabilities[:m].view(np.uint64), res.probabilities[:m].view(np.uint64))
+    t.close()
+    assert al.session_stats()["aborted"] == 0
+
+
 def test_cfg2_full_size_properties_and_parity_on_64_reads(models, al9):
     """BASELINE configs[1]: 1 024 RNA004 reads x ~20 k samples. Size-independent properties on
     all reads, full parity against the oracle on every 33rd read and on every read with a structural-tie decision (63 reads)."""
@@ -402,6 +419,7 @@ def test_cfg2_full_size_properties_and_parity_on_64_reads(models, al9):
     assert tm["samples"] == int(so[-1]) and tm["reads_ok"] == len(reads)
     assert tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == len(reads)
     _full_size_properties(reads, res, al9.kmer_size)
+    _resident_queue_gives_the_same(al9, (sig, so, sq, qo), res)
     # every 33rd read, and EVERY read of this workload in which the reference's traceback takes a decision on a
     # structural tie (neighbouring columns with the same k-mer: margin 0 in exact arithmetic, 0 .. 1e-8 in the
     # reference's floating point; tests/decision_margin.py -> tests/golden/g9_cfg2_decision_margin.json). Decisions
@@ -425,6 +443,7 @@ def test_cfg4_share_full_size(models, al9):
         tm = b.timing()
     assert tm["reads_ok"] == 4096 and tm["launches"] == 1 and tm["lp_inplace"] == 0 and tm["n_static"] == 1024
     _full_size_properties(reads, res, al9.kmer_size)
+    _resident_queue_gives_the_same(al9, (sig, so, sq, qo), res)
     # 64 reads against the oracle: 48 spread evenly over the queue (longest first: the first round, the rounds taken
     # off the queue on the device, the tail) + 16 of the reads that START with a structural tie (pad + A: the first
     # two 9-mers are equal), spread the same way

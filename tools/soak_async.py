@@ -5,11 +5,13 @@ them, a random number of tickets in flight (so that some merge into one launch a
 result compared, bit for bit, with the synchronous call of a second handle on the same input. What `pytest -m gpu` checks
 once per feature meets here in random order on recycled buffers.
 
-    python tools/soak_async.py [tickets] [seed] [resident]
+    python tools/soak_async.py [tickets] [seed] [resident|watchdog]
 
 `resident` (round 5): batches of up to 1 100 reads as well, so that tickets open, join, outgrow and close sessions of the
 RESIDENT read queue (sessions alternate with one-launch-per-batch jobs -- Z-only, training -- on the same lattice pool) -- the
 results must still be the synchronous calls' bit for bit.
+`watchdog`: the same with the idle watchdog at 3 ms (DYN_SESSION_IDLE_S): sessions abort under the tickets all the time, tickets
+are published to waves that have left and published again (dyn_session_stats.republished) -- and nothing may change.
 """
 import os, sys, tempfile, time
 sys.path.insert(0, "/root/repo")
@@ -18,7 +20,10 @@ from dynamont_amd import Aligner, synth
 
 n_tickets = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-RESIDENT = len(sys.argv) > 3 and sys.argv[3] == "resident"
+WATCHDOG = len(sys.argv) > 3 and sys.argv[3] == "watchdog"
+RESIDENT = len(sys.argv) > 3 and sys.argv[3] in ("resident", "watchdog")
+if WATCHDOG:
+    os.environ["DYN_SESSION_IDLE_S"] = "0.003"
 d = tempfile.mkdtemp(prefix="dyn_soak_async_")
 model = synth.write_model(os.path.join(d, "m9.model"), 9, seed=7, stdev=0.15)
 _, mean, sd = synth.read_model_file(model)
@@ -87,7 +92,9 @@ for t in range(n_tickets):
         tk.close()
         done += 1
 ss = al.session_stats()
-assert ss["aborted"] == 0, ss
+assert WATCHDOG or ss["aborted"] == 0, ss
+if WATCHDOG:
+    print(f"watchdog at 3 ms: {ss['aborted']} sessions aborted, {ss['republished']} tickets published again")
 print(f"soak done: {done} tickets ({merged} of them shared a launch, {resident} ran in the resident read queue: {ss['sessions']} sessions, "
       f"{ss['tickets']} tickets, wave occupancy {ss['wave_occupancy']:.3f}) in {time.time() - t0:.0f} s, every result bit-identical to the synchronous call")
 al.close(); ref.close()

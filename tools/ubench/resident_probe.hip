@@ -110,6 +110,17 @@ __global__ __launch_bounds__(256) void k_scratch(double* __restrict__ p, int n, 
   if (i < n) p[i] = sacc;
 }
 
+// small register footprint, KB kilobytes of LDS: where is the line between 'fits beside a resident workgroup' (9.5 KB are
+// free on its CU) and 'needs a CU of its own'?
+template <int KB>
+__global__ __launch_bounds__(256) void k_lds(double* __restrict__ p, int n) {
+  __shared__ double lds[KB * 1024 / 8];
+  lds[threadIdx.x] = (double)threadIdx.x;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = lds[(threadIdx.x + 1) & 255];
+}
+
 // rocPRIM's radix sort shape: 1 024-thread workgroups, 20 KB of LDS, scratch
 __global__ __launch_bounds__(1024) void k_wide(double* __restrict__ p, int n, int rot) {
   __shared__ double lds[20 * 1024 / 8];
@@ -213,14 +224,25 @@ static int run(const char* name, int stream_kind, int extra_streams, bool payloa
 
 // Kernels that need a WHOLE free CU (and scratch) beside a resident kernel that occupies n_cus - free_cus CUs: are they served,
 // and how fast? (RCCL's exchange kernels at N > 1; rocPRIM's radix sort behind a training ticket.)
-static void run_big(const char* name, int free_cus, int kind) {
+// partition: 0 = the resident grid merely leaves `free_cus` CUs unused (any of them); 1 = the CUs are PARTITIONED by CU masks:
+// the resident stream may use the first n - free_cus CUs only, the auxiliary stream the last free_cus only; 2 = the same with
+// the free CUs spread (every (n / free_cus)-th CU)
+static void run_big(const char* name, int free_cus, int kind, int partition = 0) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int n_cus = prop.multiProcessorCount;
   hipStream_t s_res = nullptr, s_aux = nullptr;
-  std::vector<uint32_t> mask((n_cus + 31) / 32, 0xffffffffu);
+  std::vector<uint32_t> mask((n_cus + 31) / 32, 0xffffffffu), aux_mask((n_cus + 31) / 32, 0u);
+  if (partition) {
+    for (int k = 0; k < free_cus; ++k) {
+      const int cu = partition == 1 ? n_cus - 1 - k : k * (n_cus / free_cus);
+      mask[cu / 32] &= ~(1u << (cu % 32));
+      aux_mask[cu / 32] |= 1u << (cu % 32);
+    }
+  }
   CK(hipExtStreamCreateWithCUMask(&s_res, (uint32_t)mask.size(), mask.data()));
-  CK(hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking));
+  if (partition) CK(hipExtStreamCreateWithCUMask(&s_aux, (uint32_t)aux_mask.size(), aux_mask.data()));
+  else CK(hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking));
   uint32_t* ctl = nullptr;
   double *payload = nullptr, *sink = nullptr, *buf = nullptr;
   CK(hipMalloc(&ctl, 256));
@@ -229,7 +251,7 @@ static void run_big(const char* name, int free_cus, int kind) {
   CK(hipMalloc(&buf, 1 << 22));
   CK(hipMemset(ctl, 0, 256));
   CK(hipDeviceSynchronize());
-  const double limit_s = 3.0;
+  const double limit_s = 2.0;
   const double t0 = now();
   hipLaunchKernelGGL(k_resident, dim3(n_cus - free_cus), dim3(256), 0, s_res, ctl, payload, sink, (unsigned long long)(limit_s * 1e8));
   CK(hipGetLastError());
@@ -239,7 +261,10 @@ static void run_big(const char* name, int free_cus, int kind) {
     const double a = now();
     if (kind == 0) hipLaunchKernelGGL(k_big, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
     else if (kind == 1) hipLaunchKernelGGL(k_scratch, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256, it + 1);
-    else hipLaunchKernelGGL(k_wide, dim3(64), dim3(1024), 0, s_aux, buf, 64 * 1024, it + 1);
+    else if (kind == 2) hipLaunchKernelGGL(k_wide, dim3(64), dim3(1024), 0, s_aux, buf, 64 * 1024, it + 1);
+    else if (kind == 3) hipLaunchKernelGGL(k_lds<8>, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
+    else if (kind == 4) hipLaunchKernelGGL(k_lds<16>, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
+    else hipLaunchKernelGGL(k_lds<16>, dim3(1), dim3(256), 0, s_aux, buf, 256);
     CK(hipStreamSynchronize(s_aux));
     const double dt = now() - a;
     if (!it) first = dt;
@@ -250,9 +275,12 @@ static void run_big(const char* name, int free_cus, int kind) {
     ++done;
     if (now() - t0 > limit_s - 0.5) break;
   }
+  uint32_t arrived = 0;
+  CK(hipMemcpyAsync(&arrived, ctl + CTL_ARRIVED, 4, hipMemcpyDeviceToHost, s_aux));
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_aux, ctl, 0u, 1u);
   CK(hipStreamSynchronize(s_aux));
   CK(hipStreamSynchronize(s_res));
+  printf("[%3u resident workgroups running] ", arrived);
   printf("%-44s %2d/20 launches beside a resident kernel on %d of %d CUs: first %9.1f us, then mean %8.1f us worst %9.1f us%s\n", name, done, n_cus - free_cus, n_cus,
          1e6 * first, done > 1 ? 1e6 * sum / (done - 1) : 0.0, 1e6 * worst, done < 20 ? "   <-- WAITED for the resident kernel to leave" : "");
   fflush(stdout);
@@ -264,8 +292,42 @@ static void run_big(const char* name, int free_cus, int kind) {
   CK(hipStreamDestroy(s_aux));
 }
 
+// where does bit i of a CU mask point? One workgroup on a stream whose mask has only that bit reports its XCC and HW_ID
+__global__ void k_where(uint32_t* out) {
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    out[1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+  }
+}
+
+static void run_map() {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int n_cus = prop.multiProcessorCount;
+  uint32_t* out = nullptr;
+  CK(hipHostMalloc(&out, 64, hipHostMallocDefault));
+  const int bits[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 24, 31, 32, 33, 40, 63, 64, 96, 128, 160, 192, 224, 247, 248, 249, 250, 251, 252, 253, 254, 255};
+  for (int bit : bits) {
+    if (bit >= n_cus) continue;
+    std::vector<uint32_t> mask((n_cus + 31) / 32, 0u);
+    mask[bit / 32] = 1u << (bit % 32);
+    hipStream_t s = nullptr;
+    CK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    out[0] = out[1] = 0xffffffffu;
+    hipLaunchKernelGGL(k_where, dim3(1), dim3(64), 0, s, out);
+    CK(hipStreamSynchronize(s));
+    const uint32_t hw = out[1];
+    printf("mask bit %3d -> XCC %u, SE %u, SH %u, CU %2u   (XCC_ID %08x HW_ID %08x)\n", bit, out[0] & 0xf, (hw >> 13) & 0x7, (hw >> 12) & 1, (hw >> 8) & 0xf, out[0], hw);
+  }
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   CK(hipSetDevice(0));
+  if (argc > 1 && !strcmp(argv[1], "map")) {
+    run_map();
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "big")) {
     run_big("40 KB LDS + 248 VGPRs, no CU free", 0, 0);
     run_big("40 KB LDS + 248 VGPRs, 8 CUs free", 8, 0);
@@ -273,6 +335,19 @@ int main(int argc, char** argv) {
     run_big("scratch kernel, 8 CUs free", 8, 1);
     run_big("1024-thread workgroups + scratch, no CU free", 0, 2);
     run_big("1024-thread workgroups + scratch, 8 CUs free", 8, 2);
+    run_big("8 KB LDS, 64 workgroups, no CU free", 0, 3);
+    run_big("16 KB LDS, 64 workgroups, no CU free", 0, 4);
+    run_big("16 KB LDS, 64 workgroups, 8 CUs free", 8, 4);
+    run_big("16 KB LDS, 64 workgroups, 64 CUs free", 64, 4);
+    run_big("16 KB LDS, 64 workgroups, 128 CUs free", 128, 4);
+    run_big("16 KB LDS, ONE workgroup, 8 CUs free", 8, 5);
+    run_big("16 KB LDS, ONE workgroup, 128 CUs free", 128, 5);
+    run_big("40 KB LDS + 248 VGPRs, 128 CUs free", 128, 0);
+    run_big("40 KB+248 VGPRs x64, 8 CUs by CU MASK (last 8)", 8, 0, 1);
+    run_big("40 KB+248 VGPRs x64, 8 CUs by CU MASK (spread)", 8, 0, 2);
+    run_big("1024-thread x64, 8 CUs by CU MASK (last 8)", 8, 2, 1);
+    run_big("1024-thread x64, 8 CUs by CU MASK (spread)", 8, 2, 2);
+    run_big("16 KB LDS x64, 4 CUs by CU MASK (spread)", 4, 4, 2);
     return 0;
   }
   int ok = 1;
