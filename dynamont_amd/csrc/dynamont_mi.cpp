@@ -481,13 +481,13 @@ static bool model_allows_strict(const dynhost::PoreModel& m) {
   return true;
 }
 
-// The session stream: CU-masked, hence a hardware queue of its own. reserved_cus CUs are left OUT of the mask: a resident
-// session occupies every CU it may use (one workgroup each, 150 KB of LDS), and a kernel of another stream that needs more
-// than the 13 KB of LDS and 152 registers per lane they leave free -- RCCL's (37 KB, 248-256 registers) -- would otherwise
-// not start before the session ends.
+// The session stream: CU-masked (every CU enabled), hence a hardware queue of its own. `reserved_cus` CUs are left free by the
+// session's GRID (one workgroup of 150 KB of LDS per CU, n_cus - reserved of them), not by the mask: partitioning by masks
+// leaves resident workgroups unplaced (tools/ubench/resident_probe.hip). What starts beside a session
+// is what fits beside a resident workgroup (<= 9.5 KB of LDS, <= 152 registers per lane) or a single workgroup on a free CU.
 // CU-masked streams are PARKED per device, never destroyed: the second hipStreamDestroy of such a stream in a process did
-// not return on this runtime (ROCm 7.2; tools/sess_mode_probe.py and a CLI run in a loop both stopped there), and a parked
-// stream costs one idle hardware queue.
+// not return on this runtime (ROCm 7.2: set_session_mode(0) after a destroyed handle, and a CLI run in a loop, both
+// stopped there), and a parked stream costs one idle hardware queue.
 static std::mutex g_sess_stream_m;
 static std::vector<hipStream_t> g_sess_streams[32];
 static void park_session_stream(dyn_aligner* a) {
