@@ -1568,7 +1568,18 @@ int session_collect(dyn_aligner* a, int blk) {
   return DYN_OK;
 }
 
-int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r, uint32_t arena_pages, uint32_t n_pages_total) {
+// what a session is launched with (session_choose)
+struct SessionGeom {
+  bool ok = false;
+  int layout = 0, log_r = 8;
+  uint32_t arena_pages = 0;   // layout 0: per wave; paged: the most one read may need
+  uint32_t n_pages = 0;       // of the pool
+};
+
+int session_open(dyn_aligner* a, bool mixed, const SessionGeom& g) {
+  const int log_r = g.log_r;
+  const uint32_t arena_pages = g.arena_pages, n_pages_total = g.n_pages;
+  const bool paged = g.layout != 0, separate = g.layout != 2;
   Session& ss = a->sess;
   const int blk = ss.blk ^ 1;
   // the session before the last one used this block: it has long ended, but its statistics may still be waiting
@@ -1589,12 +1600,15 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   const uint64_t page_rows = 1ull << log_r;
   const uint64_t ws_pp = page_rows * dynk::P * 8, lpe_pp = page_rows * dynk::P * 4, bits_pp = page_rows * dynk::CPL * 8;
   HIP_TRY(a, hipStreamSynchronize(a->stream));
-  if (a->ws.bytes < n_pages_total * ws_pp || a->lpe.bytes < n_pages_total * lpe_pp || a->bits.bytes < n_pages_total * bits_pp) {
+  if (a->ws.bytes < n_pages_total * ws_pp || (separate && a->lpe.bytes < n_pages_total * lpe_pp) || a->bits.bytes < n_pages_total * bits_pp ||
+      (paged && a->free_list.bytes < (size_t)n_pages_total * 4)) {
     if (ss.pending[ss.blk]) HIP_TRY(a, hipEventSynchronize(ss.ev_end[ss.blk]));
     HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, n_pages_total * ws_pp, 1.0));
-    HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
+    if (separate) HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
     HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, n_pages_total * bits_pp, 1.0));
+    if (paged) HIP_TRY(a, a->free_list.ensure((size_t)n_pages_total * 4, 1.0));
   }
+  if (paged) HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));
   // control words cleared IN the session stream, and waited for: the first publish (copy-in stream) must not be wiped
   HIP_TRY(a, hipMemsetAsync(a->sess_ctl[blk].p, 0, dynk::SESSION_CTL_WORDS * 4, a->s_session));
   HIP_TRY(a, hipStreamSynchronize(a->s_session));  // (also: the previous session's kernel has left -- a->s_session is in order)
@@ -1607,17 +1621,18 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   sa.arena_pages = arena_pages;
   sa.ctl = a->sess_ctl[blk].as<uint32_t>();
   sa.pool.ws = a->ws.as<double>();
-  sa.pool.lpe = a->lpe.as<float>();
+  sa.pool.lpe = separate ? a->lpe.as<float>() : nullptr;
   sa.pool.bits = a->bits.as<uint64_t>();
-  sa.pool.free_list = nullptr;
-  sa.pool.ctl = nullptr;
+  sa.pool.free_list = paged ? a->free_list.as<uint32_t>() : nullptr;
+  sa.pool.ctl = paged ? a->ctl.as<uint32_t>() : nullptr;
   sa.pool.log_rows = log_r;
   sa.pool.n_pages = n_pages_total;
   sa.m1 = a->model.log_m1;
   sa.e2 = a->model.log_e2;
   sa.idle_limit_ticks = (uint64_t)(a->sess_idle_s * 1e8);
+  if (paged) dynk::launch_pool_init(sa.pool, 0, 0, a->s_session);  // every page on the free list, control words cleared
   HIP_TRY(a, hipEventRecord(ss.ev_begin[blk], a->s_session));
-  dynk::launch_session(mixed, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), session_wgs(a), a->s_session);
+  dynk::launch_session(mixed, g.layout, sa, a->d_model.p, a->sess_anchor.p, a->d_sptab.as<dynmath::SoftplusNode>(), session_wgs(a), a->s_session);
   HIP_TRY(a, hipGetLastError());
   HIP_TRY(a, hipEventRecord(ss.ev_end[blk], a->s_session));
   ss.open = true;
@@ -1629,9 +1644,10 @@ int session_open(dyn_aligner* a, const SessionNeed& need, bool mixed, int log_r,
   ss.next_base = 0;
   ss.log_r = log_r;
   ss.arena_pages = arena_pages;
+  ss.layout = g.layout;
+  ss.n_pages = n_pages_total;
   ss.n_waves = (uint32_t)session_wgs(a) * dynk::WAVES_PER_CU;
   ss.cells = ss.reads = ss.tickets = 0;
-  (void)need;
   return DYN_OK;
 }
 
@@ -1686,6 +1702,58 @@ static void session_geometry(uint64_t max_S, int* log_r, uint32_t* arena_pages) 
   *arena_pages = session_pages_of(cap_S, lr);
 }
 
+// The geometry of a session that could take the ticket: an arena for every wave if the memory budget allows (layout 0),
+// else the pool's pages shared through the free list, with the posterior layout enqueue_job would choose for such a launch.
+static int session_choose(dyn_aligner* a, const dyn_batch* b, const SessionNeed& need, SessionGeom* g) {
+  *g = SessionGeom{};
+  session_geometry(need.max_S, &g->log_r, &g->arena_pages);
+  const uint64_t n_waves = (uint64_t)session_wgs(a) * dynk::WAVES_PER_CU;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
+  const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + parked_bytes(a->device);
+  uint64_t budget = (uint64_t)((double)(free_b + pool) * 0.90);
+  if (a->mem_budget && a->mem_budget < budget) budget = a->mem_budget;
+  const uint64_t page_rows = 1ull << g->log_r, max_pages = 0xfffffff0ull >> g->log_r;  // pool rows are 32-bit
+  const uint64_t want = n_waves * g->arena_pages * (page_rows * SESSION_ROW_BYTES);
+  if (want <= budget && n_waves * g->arena_pages <= max_pages) {
+    g->layout = 0;
+    g->n_pages = (uint32_t)(n_waves * g->arena_pages);
+    g->ok = true;
+    return DYN_OK;
+  }
+  if (std::getenv("DYN_NO_PAGED_SESSION")) return DYN_OK;  // page-starved batches as one launch each (round 4's path)
+  // page-starved. The pages that would keep every wave busy with this ticket's largest lattices:
+  std::vector<uint32_t> pg;
+  pg.reserve(need.n_ok);
+  for (uint64_t i = 0; i < b->n; ++i)
+    if (b->reads[i].status == DYN_READ_OK) pg.push_back(session_pages_of(b->reads[i].S, g->log_r));
+  const size_t top = std::min<size_t>(n_waves, pg.size());
+  std::partial_sort(pg.begin(), pg.begin() + top, pg.end(), std::greater<uint32_t>());
+  uint64_t wanted = 0;
+  for (size_t k = 0; k < top; ++k) wanted += pg[k];
+  wanted = std::max<uint64_t>(wanted, 1);
+  // separate float LPE: the forward sweep is 17 % faster, 12 instead of 8 bytes per band slot (enqueue_job's rule)
+  const uint64_t row_sep = (uint64_t)dynk::P * 12 + dynk::CPL * 8, row_inp = (uint64_t)dynk::P * 8 + dynk::CPL * 8;
+  const double c_sep = std::min(1.0, (double)budget / ((double)wanted * page_rows * row_sep + 1.0));
+  const double c_inp = std::min(1.0, (double)budget / ((double)wanted * page_rows * row_inp + 1.0));
+  bool separate = !(c_sep < 1.0 && c_inp * 0.92 > c_sep);
+  if (const char* f = std::getenv("DYN_FORCE_LAYOUT")) separate = std::string(f) != "inplace";
+  const uint64_t page_bytes = page_rows * (separate ? row_sep : row_inp);
+  // later tickets of the stream are served from the same pool: everything the budget gives, up to an arena per wave
+  const uint64_t n_pages = std::min<uint64_t>({budget / page_bytes, n_waves * g->arena_pages, max_pages});
+  if (n_pages < g->arena_pages) return DYN_OK;  // the longest read alone does not fit: the classic launch gives it its status
+  g->layout = separate ? 1 : 2;
+  g->n_pages = (uint32_t)n_pages;
+  g->ok = true;
+  return DYN_OK;
+}
+
+static bool session_fits(const dyn_aligner* a, const Session& ss, const SessionNeed& need) {
+  const uint32_t cap = ss.layout == 0 ? ss.arena_pages : std::min<uint32_t>((uint32_t)dynk::PT_MAX, ss.n_pages);
+  return session_pages_of(need.max_S, ss.log_r) <= cap && ss.published < SESSION_RING && (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull &&
+         (ss.mixed || a->strict_mode == 0);
+}
+
 int session_plan(dyn_batch* b, bool* use) {
   dyn_aligner* a = b->a;
   *use = false;
@@ -1693,30 +1761,17 @@ int session_plan(dyn_batch* b, bool* use) {
   const SessionNeed need = session_need(b);
   if (!need.n_ok) return DYN_OK;  // nothing to launch
   Session& ss = a->sess;
-  const bool strict_reads = a->strict_mode != 0;
   if (ss.open) {
-    const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
-                      (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull && (ss.mixed || !strict_reads);
-    if (fits) {
+    if (session_fits(a, ss, need)) {
       *use = true;
       return DYN_OK;
     }
     if (int rc = session_close(a)) return rc;  // a new one is opened below if this ticket deserves it
   }
   if (need.n_ok < SESSION_MIN_READS) return DYN_OK;
-  // an arena for every wave, inside the memory budget?
-  int log_r = 8;
-  uint32_t arena = 0;
-  session_geometry(need.max_S, &log_r, &arena);
-  const uint64_t n_waves = (uint64_t)session_wgs(a) * dynk::WAVES_PER_CU;
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
-  const uint64_t pool = a->ws.bytes + a->lpe.bytes + a->bits.bytes + parked_bytes(a->device);
-  uint64_t budget = (uint64_t)((double)(free_b + pool) * 0.90);
-  if (a->mem_budget && a->mem_budget < budget) budget = a->mem_budget;
-  const uint64_t want = n_waves * arena * ((1ull << log_r) * SESSION_ROW_BYTES);
-  if (want > budget || n_waves * arena > (0xfffffff0ull >> log_r)) return DYN_OK;  // page-starved: the planned classic launch
-  *use = true;
+  SessionGeom g;
+  if (int rc = session_choose(a, b, need, &g)) return rc;
+  *use = g.ok;  // (false: the longest read does not fit the pool at all -- the planned classic launch)
   return DYN_OK;
 }
 
@@ -1747,14 +1802,16 @@ int session_publish(dyn_batch* b) {
   const size_t n_ok = order.size();
 
   if (!ss.open) {
-    int log_r = 8;
-    uint32_t arena = 0;
-    session_geometry(max_S, &log_r, &arena);
-    const uint64_t n_waves = (uint64_t)session_wgs(a) * dynk::WAVES_PER_CU;
     SessionNeed need;
     need.n_ok = n_ok;
     need.max_S = max_S;
-    if (int rc = session_open(a, need, a->strict_mode != 0, log_r, arena, (uint32_t)(n_waves * arena))) return rc;
+    SessionGeom g;
+    if (int rc = session_choose(a, b, need, &g)) return rc;
+    if (!g.ok) {
+      a->last_error = "session_publish: no session geometry for a ticket session_plan had accepted";
+      return DYN_ERR_RUNTIME;
+    }
+    if (int rc = session_open(a, a->strict_mode != 0, g)) return rc;
   }
 
   HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
@@ -1848,8 +1905,8 @@ int session_publish(dyn_batch* b) {
   tm.reads_strict = (uint32_t)n_strict;
   tm.launch_share = 0.0;
   tm.launches = 0;
-  tm.lp_inplace = 0;
-  tm.pool_pages = ss.arena_pages * ss.n_waves;
+  tm.lp_inplace = ss.layout == 2 ? 1 : 0;
+  tm.pool_pages = ss.n_pages;
   tm.page_rows = 1u << ss.log_r;
   tm.n_static = 0;
   tm.n_waves = ss.n_waves;
@@ -1899,12 +1956,8 @@ int session_recover(dyn_batch* b, bool* republished) {
     return DYN_ERR_DEVICE;
   }
   const SessionNeed need = session_need(b);
-  if (ss.open) {
-    const bool fits = session_pages_of(need.max_S, ss.log_r) <= ss.arena_pages && ss.published < SESSION_RING &&
-                      (uint64_t)ss.next_base + need.n_ok < 0x7fffffffull && (ss.mixed || a->strict_mode == 0);
-    if (!fits)
-      if (int rc = session_quiesce(a)) return rc;  // (the pool may have to grow: nothing may be using it)
-  }
+  if (ss.open && !session_fits(a, ss, need))
+    if (int rc = session_quiesce(a)) return rc;  // (the pool may have to grow: nothing may be using it)
   b->sess_retries += 1;
   a->sess_total.republished += 1;
   *republished = true;

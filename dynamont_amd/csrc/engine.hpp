@@ -109,7 +109,9 @@ struct Session {
   uint32_t published = 0;       // tickets of the open session
   uint32_t next_base = 0;       // global read index of the next ticket's first read
   int log_r = 8;
-  uint32_t arena_pages = 0;     // lattice pages per wave
+  uint32_t arena_pages = 0;     // lattice pages per wave (layout 0); paged layouts: the most a read may need
+  int layout = 0;               // 0: an arena per wave; 1: pages shared through the free list; 2: shared pages, posteriors in place
+  uint32_t n_pages = 0;         // pages of the pool
   uint32_t n_waves = 0;
   uint64_t cells = 0, reads = 0, tickets = 0;   // of the open session
   bool pending[2] = {false, false};             // a session ran on this block and its statistics have not been collected

@@ -1214,13 +1214,13 @@ __device__ __forceinline__ void queue_unlock(uint32_t* ctl, int lane) {
 
 // pt[off .. off+count) -> free list. Every store of this wave to those pages must have been written
 // back from this XCD's L2 before a wave on another XCD fills them again (agent-scope release).
-__device__ __forceinline__ void pages_give(const QueueArgs& q, const WaveCtx& w, uint32_t off, uint32_t count) {
-  uint32_t* ctl = q.pool.ctl;
+__device__ __forceinline__ void pages_give(const PagePool& pool, const WaveCtx& w, uint32_t off, uint32_t count) {
+  uint32_t* ctl = pool.ctl;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   queue_lock(ctl, w.lane);
   const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE]));
-  for (uint32_t k = w.lane; k < count; k += 64) ctl_store(&q.pool.free_list[fc + k], w.pt[off + k]);
+  for (uint32_t k = w.lane; k < count; k += 64) ctl_store(&pool.free_list[fc + k], w.pt[off + k]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (w.lane == 0) ctl_store(&ctl[CTL_FREE], fc + count);
   queue_unlock(ctl, w.lane);
@@ -1228,8 +1228,8 @@ __device__ __forceinline__ void pages_give(const QueueArgs& q, const WaveCtx& w,
 
 // `count` pages from the free list -> pt[0 .. count); the wave holds no pages while it waits.
 // Returns false when the launch was aborted.
-__device__ __forceinline__ bool pages_take(const QueueArgs& q, const WaveCtx& w, uint32_t count) {
-  uint32_t* ctl = q.pool.ctl;
+__device__ __forceinline__ bool pages_take(const PagePool& pool, const WaveCtx& w, uint32_t count) {
+  uint32_t* ctl = pool.ctl;
   if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_WAITING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool ok = false;
   for (int waits = 0; !ok; ++waits) {
@@ -1246,7 +1246,7 @@ __device__ __forceinline__ bool pages_take(const QueueArgs& q, const WaveCtx& w,
     queue_lock(ctl, w.lane);
     const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE]));
     if (fc >= count) {
-      for (uint32_t k = w.lane; k < count; k += 64) w.pt[k] = ctl_load(&q.pool.free_list[fc - count + k]);
+      for (uint32_t k = w.lane; k < count; k += 64) w.pt[k] = ctl_load(&pool.free_list[fc - count + k]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (w.lane == 0) ctl_store(&ctl[CTL_FREE], fc - count);
       ok = true;
@@ -1447,13 +1447,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         have = rd.n_pages;
       } else {
         if (have < rd.n_pages) {  // a wave without an arena (or, with another queue order, too small a one)
-          if (have) pages_give(q, w, 0, have);
+          if (have) pages_give(q.pool, w, 0, have);
           have = 0;
-          if (!pages_take(q, w, rd.n_pages)) break;
+          if (!pages_take(q.pool, w, rd.n_pages)) break;
           have = rd.n_pages;
         } else if (have - rd.n_pages >= 8 && 8 * (have - rd.n_pages) >= have &&
                    __builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_WAITING])) != 0) {
-          pages_give(q, w, rd.n_pages, have - rd.n_pages);  // a wave is waiting: hand over what this read leaves unused
+          pages_give(q.pool, w, rd.n_pages, have - rd.n_pages);  // a wave is waiting: hand over what this read leaves unused
           have = rd.n_pages;
         }
         if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_PROVISIONED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1467,7 +1467,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
   }
   // leaving: while a claimed read still lacks its pages, somebody may be waiting for these
   if (LATTICE && have && (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_PROVISIONED])) < (uint32_t)q.n_reads)
-    pages_give(q, w, 0, have);
+    pages_give(q.pool, w, 0, have);
   if (w.lane == 0) {
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(q.pool.ctl + QUEUE_STATS);
     atomicAdd(&stats[0], (unsigned long long)ws.cyc_b);
@@ -1515,9 +1515,15 @@ __device__ __forceinline__ SessionTicket load_ticket(const SessionTicket* ring, 
 
 }  // namespace
 
-template <bool MIXED>
+// LAYOUT 0: an arena of sa.arena_pages pages for every wave, separate float LPE (JOB_ALIGN). LAYOUT 1 / 2: the batches are
+// PAGE-STARVED (an arena per wave does not fit the memory budget: reads of 100 k samples): the pool's pages are shared through
+// the free list exactly as in k_read_queue -- a wave keeps what it holds, takes more only while holding none, gives a large
+// surplus back when somebody waits -- with the separate (1, JOB_ALIGN) or the in-place (2, JOB_ALIGN_INPLACE) posterior layout.
+template <bool MIXED, int LAYOUT>
 __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char* __restrict__ in_base, char* out_base,
                                                 const SoftplusNode* __restrict__ sp_tab) {
+  constexpr int JOB = LAYOUT == 2 ? JOB_ALIGN_INPLACE : JOB_ALIGN;
+  constexpr bool PAGED = LAYOUT != 0;
   constexpr int TAB_NODES = SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2;
   __shared__ __attribute__((aligned(16))) SoftplusNode s_tab[TAB_NODES];
   __shared__ __attribute__((aligned(16))) double s_ring[DYN_WAVES_PER_GROUP][RING_D][P];
@@ -1532,9 +1538,11 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   w.log_r = sa.pool.log_rows;
   const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&s_ring[wave][0][0];
   lds_u64_t* sb = (lds_u64_t*)&s_ring[wave][0][0];
-  // this wave's arena, for the whole session
-  for (uint32_t k = w.lane; k < sa.arena_pages; k += 64) w.pt[k] = slot * sa.arena_pages + k;
+  // this wave's arena, for the whole session (PAGED: pages come and go through the free list)
+  if (!PAGED)
+    for (uint32_t k = w.lane; k < sa.arena_pages; k += 64) w.pt[k] = slot * sa.arena_pages + k;
   wave_lds_sync();
+  uint32_t held = 0;  // PAGED: pages in this wave's table
 
   uint32_t* ctl = sa.ctl;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
@@ -1573,6 +1581,11 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
           leave = true;
           break;
         }
+        // PAGED: an idle wave does not sit on pages somebody is waiting for
+        if (PAGED && held && sctl_load(&sa.pool.ctl[CTL_WAITING]) != 0) {
+          pages_give(sa.pool, w, 0, held);
+          held = 0;
+        }
         for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);  // ~2 us: one lane's poll per wave, agent scope
       }
       if (leave) break;
@@ -1589,6 +1602,22 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const double* __restrict__ sig = reinterpret_cast<const double*>(in_base + tk.sig_off);
     const Emis* __restrict__ par = reinterpret_cast<const Emis*>(in_base + tk.par_off);
     const ReadDesc rd = descs[g - tk.base];
+    if (PAGED) {
+      if (held < rd.n_pages) {
+        if (held) pages_give(sa.pool, w, 0, held);
+        held = 0;
+        if (!pages_take(sa.pool, w, rd.n_pages)) {
+          // waited for pages for seconds: the session is over; what is incomplete is published again (session_recover)
+          if (w.lane == 0) ctl_store(&ctl[S_ABORT], 3u);
+          break;
+        }
+        held = rd.n_pages;
+      } else if (held - rd.n_pages >= 8 && 8 * (held - rd.n_pages) >= held && sctl_load(&sa.pool.ctl[CTL_WAITING]) != 0) {
+        pages_give(sa.pool, w, rd.n_pages, held - rd.n_pages);  // a wave is waiting: hand over what this read leaves unused
+        held = rd.n_pages;
+      }
+      wave_lds_sync();
+    }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     cyc_idle += t1 - t0;
@@ -1601,7 +1630,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     io.m1 = sa.m1;
     io.e2 = sa.e2;
     io.z_fail_status = tk.z_fail_status;
-    run_read<JOB_ALIGN, MIXED>(rd, w, sa.pool, io, sig, par, s_tab, ring_base, sb, ws, t1);
+    run_read<JOB, MIXED>(rd, w, sa.pool, io, sig, par, s_tab, ring_base, sb, ws, t1);
     // everything this wave wrote for the read (state, path arrays, segment rows) must have left this XCD's L2 before the
     // ticket's counter says so: the per-segment kernels and the copies that follow run elsewhere
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1628,6 +1657,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     ++n_done;
     cyc_busy += __builtin_amdgcn_s_memtime() - t1;
   }
+  if (PAGED && held) pages_give(sa.pool, w, 0, held);  // (a wave that claimed a read may still be waiting for these)
   if (w.lane == 0) {
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(ctl + SESSION_STATS);
     const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
@@ -1953,13 +1983,22 @@ void launch_read_queue(QueueJob job, bool with_strict, const QueueArgs& q, int n
   }
 }
 
-void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+void launch_session(bool with_strict, int layout, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
                     int n_cus, hipStream_t s) {
   const dim3 grid(std::max(1, n_cus)), block(64 * DYN_WAVES_PER_GROUP);
-  if (with_strict)
-    hipLaunchKernelGGL((k_session<true>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
-  else
-    hipLaunchKernelGGL((k_session<false>), grid, block, 0, s, a, static_cast<const char*>(in_base), static_cast<char*>(out_base), sp_tab);
+  const char* in = static_cast<const char*>(in_base);
+  char* out = static_cast<char*>(out_base);
+#define DYN_SESSION_LAUNCH(M, L) hipLaunchKernelGGL((k_session<M, L>), grid, block, 0, s, a, in, out, sp_tab)
+  if (with_strict) {
+    if (layout == 0) DYN_SESSION_LAUNCH(true, 0);
+    else if (layout == 1) DYN_SESSION_LAUNCH(true, 1);
+    else DYN_SESSION_LAUNCH(true, 2);
+  } else {
+    if (layout == 0) DYN_SESSION_LAUNCH(false, 0);
+    else if (layout == 1) DYN_SESSION_LAUNCH(false, 1);
+    else DYN_SESSION_LAUNCH(false, 2);
+  }
+#undef DYN_SESSION_LAUNCH
 }
 
 void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s) {

@@ -162,16 +162,17 @@ constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS =
 struct SessionArgs {
   const SessionTicket* ring;   // [ring_size]; slot i holds ticket i of the session (never reused within one)
   uint32_t ring_size;
-  uint32_t arena_pages;        // pages per wave
+  uint32_t arena_pages;        // pages per wave (layout 0)
   uint32_t* ctl;
-  PagePool pool;               // ws, lpe, bits, log_rows (free_list and ctl unused)
+  PagePool pool;               // ws, lpe, bits, log_rows; layouts 1 / 2 (paged): free_list and ctl as well (k_pool_init first)
   double m1, e2;
   uint64_t idle_limit_ticks;   // s_memrealtime ticks (100 MHz)
 };
 
 // n_cus workgroups of four waves on `s` -- which must own its hardware queue (hipExtStreamCreateWithCUMask)
-// with_strict: the variant that carries the certified sweeps
-void launch_session(bool with_strict, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
+// with_strict: the variant that carries the certified sweeps. layout: 0 = an arena per wave (separate LPE), 1 = pages shared
+// through the pool's free list (separate LPE), 2 = shared pages, posteriors in place (page-starved batches)
+void launch_session(bool with_strict, int layout, const SessionArgs& a, const void* in_base, void* out_base, const dynmath::SoftplusNode* sp_tab,
                     int n_cus, hipStream_t s);
 // record `tk` as ticket `index` and make it visible (tail = index + 1); closed: no ticket will follow
 void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s);

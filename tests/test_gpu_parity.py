@@ -472,6 +472,18 @@ def test_cfg3_full_size(models):
     # short reads (host plan) and later reads change arena size on the device
     assert tm["lp_inplace"] == 1 and 0 < tm["n_static"] <= 1024
     _full_size_properties(reads, res, al.kmer_size)
+    # the same batch as a ticket of the resident queue: a PAGED session (the pool's pages shared through the free list,
+    # posteriors in place), bit for bit the launch's results
+    t = al.align_async(sig, so, sq, qo, True)
+    got = t.wait()
+    tmr = t.timing()
+    assert tmr["launches"] == 0 and tmr["lp_inplace"] == 1 and tmr["reads_ok"] == 4096
+    m = int(res.seg_offsets[-1])
+    assert np.array_equal(got.status, res.status) and np.array_equal(got.Z.view(np.uint64), res.Z.view(np.uint64))
+    assert np.array_equal(got.signal_positions[:m], res.signal_positions[:m])
+    assert np.array_equal(got.probabilities[:m].view(np.uint64), res.probabilities[:m].view(np.uint64))
+    t.close()
+    assert al.session_stats()["aborted"] == 0
     order = np.argsort([-len(r.signal) for r in reads], kind="stable")
     # 64 reads against the oracle, spread evenly over the length order (the longest and the shortest included; up to
     # ~12 s and 2.6 GB of oracle per read: 8 processes), plus every read that starts with a homopolymer of k+1 bases

@@ -162,3 +162,27 @@ def test_a_ticket_published_to_waves_that_have_left_is_published_again(models, m
     assert s["aborted"] >= 1 and s["republished"] >= 1, s
     assert s["reads"] >= 2 * (600 + 4096)  # (the reads of a ticket that was published twice count twice)
     al.close()
+
+
+@pytest.mark.parametrize("layout", ["inplace", "separate"])
+def test_page_starved_tickets_share_the_pool_of_a_paged_session(models, monkeypatch, layout):
+    """A memory budget too small for an arena per resident wave (reads of 100 k samples; here: dyn_aligner_set_mem_budget):
+    the session shares the pool's pages through the free list as the one-launch-per-batch kernel does -- waves keep what they
+    hold, take more only while holding none, idle waves hand back what somebody waits for -- with the posteriors in place or
+    separate. Results: the one-launch-per-batch results bit for bit, over tickets of different read lengths."""
+    monkeypatch.setenv("DYN_FORCE_LAYOUT", layout)
+    al = Aligner(models["syn9"], "rna004", device=0)
+    al.set_mem_budget(3 << 30)   # 1 024 waves x ~30 MB of arena do not fit; the longest read needs ~30 MB
+    data = _data(models, 5, 640, 4900, bases=(100, 420)) + _data(models, 1, 700, 4990, bases=(30, 120))
+    want = [al.align_batch([r.signal for r in reads], [r.sequence for r in reads], True) for reads, _ in data]
+    for rnd in range(2):
+        tickets = [al.align_async(*packed, True) for _, packed in data]
+        for t, w in zip(tickets, want):
+            _same(t.wait(), w)
+            tm = t.timing()
+            assert tm["launches"] == 0 and tm["lp_inplace"] == (1 if layout == "inplace" else 0)
+            assert tm["pool_pages"] < tm["n_waves"] * 8   # nowhere near an arena per wave
+            t.close()
+    s = al.session_stats()
+    assert s["aborted"] == 0 and s["sessions"] >= 1 and s["tickets"] == 12
+    al.close()

@@ -12,7 +12,7 @@ namespace dynk {
   std::abort();
 }
 
-void launch_session(bool, const SessionArgs&, const void*, void*, const dynmath::SoftplusNode*, int, hipStream_t) { no_device("launch_session"); }
+void launch_session(bool, int, const SessionArgs&, const void*, void*, const dynmath::SoftplusNode*, int, hipStream_t) { no_device("launch_session"); }
 void launch_session_publish(SessionTicket*, uint32_t*, const SessionTicket&, uint32_t, uint32_t, hipStream_t) { no_device("launch_session_publish"); }
 void launch_session_close(uint32_t*, hipStream_t) { no_device("launch_session_close"); }
 void launch_preprocess(const void*, int, int, const uint64_t*, const double*, const double*, const float*, const float*, void*, double*, int, uint64_t,
