@@ -1813,6 +1813,38 @@ int session_publish(dyn_batch* b) {
     }
     if (int rc = session_open(a, a->strict_mode != 0, g)) return rc;
   }
+  if (ss.layout != 0 && n_ok > ss.n_waves && !std::getenv("DYN_NO_BRIDGE")) {
+    // a PAGED session: the ticket's longest reads one after the other would ask for more pages than the pool has, and the
+    // waves that claim them would wait while the short reads behind them could run -- the planned order of a page-starved
+    // launch (plan_queue: long reads, then BRIDGE reads that fit beside them, then the rest) spreads the demand. The plan is
+    // made for waves that all start empty-handed; here they arrive from the ticket before one by one, which only helps.
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->reads[x].S > b->reads[y].S; });
+    std::vector<uint32_t> need(n_ok);
+    std::vector<uint64_t> rows(n_ok);
+    for (size_t k = 0; k < n_ok; ++k) {
+      need[k] = session_pages_of(b->reads[order[k]].S, ss.log_r);
+      rows[k] = cost_rows(order[k]);
+    }
+    if (std::getenv("DYN_SESSION_PLANNED")) {
+      plan_queue(order, need, rows, ss.n_waves, ss.n_pages);
+    } else {
+      // SPREAD: in a stream of tickets the waves never start together, so what matters is that any ~n_waves consecutive reads
+      // ask for about the AVERAGE number of pages (config 3: 205 GB against a 250 GB pool) instead of the maximum (370 GB for
+      // the 1 024 longest). The longer seven eighths are dealt out in a low-discrepancy order (rank k * phi mod m); the
+      // shortest eighth follows, longest first, so that a ticket nobody follows still ends on short reads. Config 3, same
+      // box: spread with a tail of 1/8 507, of 1/4 499-504, of 1/2 493, none 509; the planned order 465; one launch per
+      // batch (planned) 446-457 Msamp/s.
+      const char* tail_env = std::getenv("DYN_SESSION_TAIL_DIV");  // experiments: 0 = spread every read
+      const int tail_div = tail_env ? std::atoi(tail_env) : 8;
+      const size_t m = tail_div > 0 ? n_ok - n_ok / (size_t)tail_div : n_ok;
+      size_t step = (size_t)((double)m * 0.6180339887498949) | 1;
+      auto gcd = [](size_t x, size_t y) { while (y) { const size_t t = x % y; x = y; y = t; } return x; };
+      while (gcd(step, m) != 1) step += 2;
+      std::vector<uint32_t> spread(order);
+      for (size_t k = 0; k < m; ++k) spread[k] = order[(k * step) % m];
+      order.swap(spread);
+    }
+  }
 
   HIP_TRY(a, b->d_segrow.ensure(std::max<uint64_t>(4, b->capacity * 4)));
   HIP_TRY(a, b->d_medhi.ensure(std::max<uint64_t>(8, b->capacity * 8)));

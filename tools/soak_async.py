@@ -5,11 +5,13 @@ them, a random number of tickets in flight (so that some merge into one launch a
 result compared, bit for bit, with the synchronous call of a second handle on the same input. What `pytest -m gpu` checks
 once per feature meets here in random order on recycled buffers.
 
-    python tools/soak_async.py [tickets] [seed] [resident|watchdog]
+    python tools/soak_async.py [tickets] [seed] [resident|watchdog|paged]
 
 `resident` (round 5): batches of up to 1 100 reads as well, so that tickets open, join, outgrow and close sessions of the
 RESIDENT read queue (sessions alternate with one-launch-per-batch jobs -- Z-only, training -- on the same lattice pool) -- the
 results must still be the synchronous calls' bit for bit.
+`paged`: `resident` with a memory budget of 2 GiB on both handles: no arena per wave fits, the sessions share the pool's pages
+through the free list (posteriors in place), page-starved one-launch-per-batch jobs in between.
 `watchdog`: the same with the idle watchdog at 3 ms (DYN_SESSION_IDLE_S): sessions abort under the tickets all the time, tickets
 are published to waves that have left and published again (dyn_session_stats.republished) -- and nothing may change.
 """
@@ -21,7 +23,8 @@ from dynamont_amd import Aligner, synth
 n_tickets = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 WATCHDOG = len(sys.argv) > 3 and sys.argv[3] == "watchdog"
-RESIDENT = len(sys.argv) > 3 and sys.argv[3] in ("resident", "watchdog")
+PAGED = len(sys.argv) > 3 and sys.argv[3] == "paged"
+RESIDENT = len(sys.argv) > 3 and sys.argv[3] in ("resident", "watchdog", "paged")
 if WATCHDOG:
     os.environ["DYN_SESSION_IDLE_S"] = "0.003"
 d = tempfile.mkdtemp(prefix="dyn_soak_async_")
@@ -49,6 +52,9 @@ for k in range(24):
 
 ref = Aligner(model, "rna004", device=0)
 al = Aligner(model, "rna004", device=0)
+if PAGED:
+    ref.set_mem_budget(2 << 30)
+    al.set_mem_budget(2 << 30)
 want = {}
 def reference(k, kind):
     if (k, kind) not in want:
