@@ -8,6 +8,9 @@ ONLY=${2:-.}
 OUT=/root/repo/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# one handle per process here: its CU-masked session stream is destroyed with it instead of parked (rocprofv3's exit handler
+# faults on a queue that is still alive -- after the output files are written, but the exit code is 139)
+export DYN_DESTROY_SESSION_STREAM=1
 B=/root/repo/bench.py
 run() { name=$1; shift; [[ $name =~ $ONLY ]] || return 0; echo "== $name"; timeout -k 10 280 "$@" > $OUT/$name.log 2>&1 || echo "   rc=$?"; }
 # (round 4) the bench's default is strict mode "ties": launches of the MIXED kernel k_read_queue<JOB_ALIGN, true>. The sub-records
