@@ -1626,6 +1626,7 @@ int session_open(dyn_aligner* a, bool mixed, const SessionGeom& g) {
   sa.ring = a->sess_ring[blk].as<dynk::SessionTicket>();
   sa.ring_size = SESSION_RING;
   sa.arena_pages = arena_pages;
+  sa.give_always = std::getenv("DYN_SESSION_GIVE_ALWAYS") ? 1u : 0u;
   sa.ctl = a->sess_ctl[blk].as<uint32_t>();
   sa.pool.ws = a->ws.as<double>();
   sa.pool.lpe = separate ? a->lpe.as<float>() : nullptr;

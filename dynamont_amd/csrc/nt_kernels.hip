@@ -1612,7 +1612,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
           break;
         }
         held = rd.n_pages;
-      } else if (held - rd.n_pages >= 8 && 8 * (held - rd.n_pages) >= held && sctl_load(&sa.pool.ctl[CTL_WAITING]) != 0) {
+      } else if (held > rd.n_pages && (sa.give_always || (held - rd.n_pages >= 8 && 8 * (held - rd.n_pages) >= held &&
+                                                          sctl_load(&sa.pool.ctl[CTL_WAITING]) != 0))) {
         pages_give(sa.pool, w, rd.n_pages, held - rd.n_pages);  // a wave is waiting: hand over what this read leaves unused
         held = rd.n_pages;
       }

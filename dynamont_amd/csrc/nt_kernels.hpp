@@ -163,6 +163,7 @@ struct SessionArgs {
   const SessionTicket* ring;   // [ring_size]; slot i holds ticket i of the session (never reused within one)
   uint32_t ring_size;
   uint32_t arena_pages;        // pages per wave (layout 0)
+  uint32_t give_always;        // paged layouts, experiments (DYN_SESSION_GIVE_ALWAYS): surplus pages go back at every read
   uint32_t* ctl;
   PagePool pool;               // ws, lpe, bits, log_rows; layouts 1 / 2 (paged): free_list and ctl as well (k_pool_init first)
   double m1, e2;
