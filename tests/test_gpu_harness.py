@@ -234,3 +234,26 @@ def test_resquiggle_cli_column_front_end_equals_the_read_by_read_one(models, tmp
     assert [b for b in ba if b[0] != ra[2].query_name.encode()] == [b for b in bb if b[0] != ra[2].query_name.encode()]   # file order otherwise
     assert got["columns"][1] == got["per_read"][1] and len(got["columns"][1]) == 3
     assert sum("error: worker" in l for l in got["columns"][1]) == 2 and sum("Signal too short" in l for l in got["columns"][1]) == 1
+
+
+def test_resquiggle_cli_page_starved_batches_in_a_paged_session(models, tmp_path, monkeypatch):
+    """`dynamont-resquiggle --mem-budget`: batches whose lattices do not fit an arena per resident wave (long DNA reads; here a
+    small budget) run in a PAGED session of the resident read queue. The output must be the one-launch-per-batch output
+    (DYN_NO_SESSION=1, the same in-place posterior layout) byte for byte."""
+    pore = "dna_r10_400bps"
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(91, 1300, pore, mean, sd, (100, 700))
+    raw, bam, _ = synth.write_dataset(str(tmp_path / "in"), "ds", reads, pore, seed=5, container="pod5", basecalls="bam")
+    monkeypatch.setenv("DYN_FORCE_LAYOUT", "inplace")
+    outs = {}
+    for name, nosess in (("resident", None), ("launches", "1")):
+        if nosess:
+            monkeypatch.setenv("DYN_NO_SESSION", nosess)
+        out = tmp_path / name / "res.csv"
+        seg.main(["-r", str(tmp_path / "in"), "-b", bam, "-o", str(out), "--mode", "basic", "-p", pore, "--model_path", model,
+                  "--batch-reads", "650", "--mem-budget", "2.0"])
+        outs[name] = zstd_io.decompress(open(str(out) + ".zst", "rb").read())
+        seg.close_raw_cache()
+    assert outs["resident"].count(b"\n") > 100000
+    assert outs["resident"] == outs["launches"]
