@@ -497,6 +497,16 @@ def main():
         raise SystemExit(f"bench.py: --gpus {n_gpus} but only {torch.cuda.device_count()} device(s) visible; refusing to measure fewer GPUs than asked for")
     torch.cuda.set_device(local_rank)
     use_dist = n_gpus > 1 or bool(os.environ.get("DYN_BENCH_FORCE_DIST"))
+    rccl_channel_cap = None
+    if use_dist and not args.no_sessions and args.reserve_cus > 0:
+        # Measured (tools/ubench/resident_probe.hip big): beside a resident session a kernel whose
+        # workgroups need CUs of their own starts at once iff it has NO MORE workgroups than there are free CUs -- one more and
+        # it waits for the session's end. RCCL launches one workgroup per channel: cap the channels at the CUs the sessions
+        # leave free, BEFORE the first communicator of the process reads its parameters (torch's included). Whether this RCCL
+        # build honours the caps is what the two untimed probe steps below find out; if not, every rank falls back together.
+        rccl_channel_cap = int(args.reserve_cus)
+        for key in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS"):  # (MIN: an arch default above the cap would lift it)
+            os.environ.setdefault(key, str(rccl_channel_cap))
     if use_dist:
         if n_gpus == 1:  # DYN_BENCH_FORCE_DIST without a launcher: a one-rank group on the loopback
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29561")):
@@ -654,6 +664,7 @@ def main():
                 "per_step_ms_rank0": {"median": round(sorted(m["exchange_ms"])[len(m["exchange_ms"]) // 2], 3), "max": round(max(m["exchange_ms"]), 3)} if m["exchange_ms"] else None,
                 "rows_gathered_rank0": exch.rows_gathered if args.mode == "align" else None,
                 "resident_queue": resident_with_exchange, "reserved_cus": reserved_cus if resident_with_exchange else 0, "observed": sessions_with_exchange,
+                "rccl_channel_cap": rccl_channel_cap and {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS")},
             }
             line["collective_backend"] = "rehearsal" if isinstance(exch, RehearsalExchange) else "rccl (dyn_comm_*)"
             if args.mode == "align":

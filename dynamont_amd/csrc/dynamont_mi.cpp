@@ -484,7 +484,8 @@ static bool model_allows_strict(const dynhost::PoreModel& m) {
 // The session stream: CU-masked (every CU enabled), hence a hardware queue of its own. `reserved_cus` CUs are left free by the
 // session's GRID (one workgroup of 150 KB of LDS per CU, n_cus - reserved of them), not by the mask: partitioning by masks
 // leaves resident workgroups unplaced (tools/ubench/resident_probe.hip). What starts beside a session
-// is what fits beside a resident workgroup (<= 9.5 KB of LDS, <= 152 registers per lane) or a single workgroup on a free CU.
+// is what fits beside a resident workgroup (<= 9.5 KB of LDS, <= 152 registers per lane) or has no more workgroups than
+// there are free CUs.
 // CU-masked streams are PARKED per device, never destroyed: the second hipStreamDestroy of such a stream in a process did
 // not return on this runtime (ROCm 7.2: set_session_mode(0) after a destroyed handle, and a CLI run in a loop, both
 // stopped there), and a parked stream costs one idle hardware queue.

@@ -244,11 +244,13 @@ int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out);
 /* enabled = 0: no resident read queue on this handle (one launch per batch, as DYN_NO_SESSION=1 does for a process).
  * enabled = 1: sessions of n_cus - reserved_cus workgroups, one per compute unit. A resident session leaves 9.5 KB of LDS and 152
  * registers per lane free on every CU it occupies: the library's own small kernels run beside it. A kernel whose workgroups need
- * more (RCCL's: 37 KB of LDS, 248-256 registers) starts beside a session only as a SINGLE workgroup on a reserved CU; with
- * many workgroups it waits until the session has ended, reserved CUs or not (measured: tools/ubench/resident_probe.hip,
- * DESIGN.md section 4) -- a process that runs such kernels WHILE tickets are in flight either accepts that wait (sessions end
- * when the handle's pipeline runs dry) or switches the queue off, as bench.py --gpus N does after probing. Closes an open
- * session first. Default: enabled, nothing reserved (DYN_SESSION_RESERVE_CUS in the environment changes the default). */
+ * more (RCCL's: 37 KB of LDS, 248-256 registers) starts beside a session iff it has NO MORE workgroups than reserved_cus
+ * (reserve multiples of 8: one per XCD); one workgroup more and it waits until the session has ended (measured:
+ * tools/ubench/resident_probe.hip) -- a process that runs such kernels WHILE tickets are in flight
+ * reserves CUs and caps their grid (RCCL: one workgroup per channel, NCCL_MAX_NCHANNELS), accepts the wait (sessions end when
+ * the handle's pipeline runs dry), or switches the queue off; bench.py --gpus N does the first and falls back to the last
+ * after probing. Closes an open session first. Default: enabled, nothing reserved (DYN_SESSION_RESERVE_CUS in the
+ * environment changes the default). */
 int dyn_aligner_set_session_mode(dyn_aligner* a, int enabled, int reserved_cus);
 /* Dense model table in k-mer-code order, (mean, stdev) interleaved, 2*num_kmers doubles. */
 int dyn_aligner_model(const dyn_aligner* a, double* out2n);

@@ -264,7 +264,8 @@ static void run_big(const char* name, int free_cus, int kind, int partition = 0)
     else if (kind == 2) hipLaunchKernelGGL(k_wide, dim3(64), dim3(1024), 0, s_aux, buf, 64 * 1024, it + 1);
     else if (kind == 3) hipLaunchKernelGGL(k_lds<8>, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
     else if (kind == 4) hipLaunchKernelGGL(k_lds<16>, dim3(64), dim3(256), 0, s_aux, buf, 64 * 256);
-    else hipLaunchKernelGGL(k_lds<16>, dim3(1), dim3(256), 0, s_aux, buf, 256);
+    else if (kind == 5) hipLaunchKernelGGL(k_lds<16>, dim3(1), dim3(256), 0, s_aux, buf, 256);
+    else hipLaunchKernelGGL(k_big, dim3(kind - 100), dim3(256), 0, s_aux, buf, (kind - 100) * 256);  // kind 100 + n: n workgroups of RCCL's footprint
     CK(hipStreamSynchronize(s_aux));
     const double dt = now() - a;
     if (!it) first = dt;
@@ -343,6 +344,13 @@ int main(int argc, char** argv) {
     run_big("16 KB LDS, ONE workgroup, 8 CUs free", 8, 5);
     run_big("16 KB LDS, ONE workgroup, 128 CUs free", 128, 5);
     run_big("40 KB LDS + 248 VGPRs, 128 CUs free", 128, 0);
+    run_big("40 KB+248 VGPRs x1, 8 CUs free", 8, 101);
+    run_big("40 KB+248 VGPRs x8, 8 CUs free", 8, 108);
+    run_big("40 KB+248 VGPRs x16, 8 CUs free", 8, 116);
+    run_big("40 KB+248 VGPRs x32, 8 CUs free", 8, 132);
+    run_big("40 KB+248 VGPRs x8, 16 CUs free", 16, 108);
+    run_big("40 KB+248 VGPRs x16, 16 CUs free", 16, 116);
+    run_big("40 KB+248 VGPRs x32, 32 CUs free", 32, 132);
     run_big("40 KB+248 VGPRs x64, 8 CUs by CU MASK (last 8)", 8, 0, 1);
     run_big("40 KB+248 VGPRs x64, 8 CUs by CU MASK (spread)", 8, 0, 2);
     run_big("1024-thread x64, 8 CUs by CU MASK (last 8)", 8, 2, 1);
