@@ -200,7 +200,7 @@ typedef struct dyn_timing {
  * for bit. Such a ticket's dyn_timing reports its own wave time: ms_dp = (wave-cycles its reads took) / waves, launches =
  * 0, launch_share = 0; the sessions themselves are accounted for here -- ms is the sum of the session kernels' durations
  * (HIP events on the session stream), which is what the roofline of a run must be taken over. Everything else (training,
- * Z-only jobs, small or page-starved batches, the synchronous calls) runs as one launch per batch as before; a handle
+ * Z-only jobs, small batches with no session open, the synchronous calls) runs as one launch per batch as before; a handle
  * whose session stream cannot be created, or with DYN_NO_SESSION=1 in the environment, never opens a session.
  * Resident waves that find no work for DYN_SESSION_IDLE_S seconds (default 20) while the session is held open leave on
  * their own (`aborted`); a ticket that was published after that is published again into the next session, its results
