@@ -140,6 +140,7 @@ SIGNATURES = {
     "dyn_batch_timing": (C.c_int, [C.c_void_p, C.POINTER(DynTiming)]),
     "dyn_plan_queue": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), c_u64_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32),
                                  c_u64_p, c_u64_p]),
+    "dyn_session_order": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32)]),
     "dyn_batch_align_async": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p, C.c_int,
                                         C.POINTER(DynAlignOut), C.POINTER(C.c_void_p)]),
     "dyn_batch_train_async": (C.c_int, [C.c_void_p, C.c_uint64, c_double_p, c_u64_p, C.c_char_p, c_u64_p,

@@ -498,6 +498,12 @@ int dyn_batch_timing(const dyn_batch* b, dyn_timing* t);
 int dyn_plan_queue(uint64_t n_reads, const uint32_t* pages, const uint64_t* rows, uint64_t n_slots,
                    uint64_t pool_pages, uint32_t* order_out, uint64_t* makespan_longest_first,
                    uint64_t* makespan_planned);
+/* (ABI 6, additive) Planning diagnostic, needs no GPU: the order in which a PAGED session of the resident read queue takes
+ * the reads of a page-starved ticket. Input: n_reads reads ranked LONGEST FIRST (rank 0 = longest); order_out[k] = rank of
+ * the read at queue position k. The longer 7/8 are dealt out in a low-discrepancy order (any window of consecutive positions
+ * holds ranks spread evenly over the whole range: the demand for lattice pages stays near its average), the shortest eighth
+ * follows, longest first. */
+int dyn_session_order(uint64_t n_reads, uint32_t* order_out);
 
 /* ---- asynchronous form: a stream of batches with H2D, kernels, D2H and host marshalling of
  * neighbouring batches overlapped (the reference keeps its worker pool permanently fed,

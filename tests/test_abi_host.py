@@ -211,3 +211,30 @@ def test_model_file_text_matches_the_python_writer(tmp_path):
         write_kmer_model(str(tmp_path / "py.model"), {names[i]: [mean[i], sd[i]] for i in range(n)})
         write_kmer_model_arrays(str(tmp_path / "native.model"), "".join(names).encode(), k, mean, sd)
         assert (tmp_path / "py.model").read_bytes() == (tmp_path / "native.model").read_bytes(), k
+
+
+def test_session_order_spreads_the_demand_for_pages(native_lib):
+    """dyn_session_order (no GPU): the order in which a paged session of the resident read queue takes a page-starved ticket's
+    reads. A permutation; the shortest eighth last, longest first; and over the rest ANY window of 1 024 consecutive reads --
+    the reads the resident waves hold at one time -- asks for about the average number of lattice pages of a config-3-like
+    batch (10 k - 100 k rows), where the 1 024 longest would ask for 1.6x that."""
+    import ctypes as C
+    n = 4096
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.integers(10_000, 100_000, size=n))[::-1]          # longest first: rank -> rows
+    order = np.zeros(n, dtype=np.uint32)
+    assert native_lib.dyn_session_order(n, order.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    assert sorted(order.tolist()) == list(range(n))
+    m = n - n // 8
+    assert np.array_equal(order[m:], np.arange(m, n, dtype=np.uint32))    # the shortest eighth: in rank order
+    assert set(order[:m].tolist()) == set(range(m))
+    demand = rows[order[:m]].astype(np.float64)
+    mean = demand.mean()
+    win = np.convolve(demand, np.ones(1024), mode="valid") / 1024.0
+    assert win.max() < 1.03 * mean and win.min() > 0.97 * mean, (win.min() / mean, win.max() / mean)
+    assert rows[:1024].mean() > 1.4 * mean                                # what longest-first would ask for at once
+    # degenerate sizes
+    for k in (0, 1, 2, 3, 9):
+        o = np.zeros(max(1, k), dtype=np.uint32)
+        assert native_lib.dyn_session_order(k, o.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+        assert sorted(o[:k].tolist()) == list(range(k))
