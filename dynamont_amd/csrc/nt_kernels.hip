@@ -216,6 +216,7 @@ __device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, cons
 // some lane's certificate failed (a rounding boundary inside the interval: ~1e-4 of the cells of a 20 k-sample read,
 // profiles/r04/cert_ambiguity.json) are recomputed with the restated glibc -- for all 64 lanes of that register: where the
 // certificate held, the restated value IS the certified one.
+
 __device__ __forceinline__ void log_plus_finish_certified(const SoftplusLookup<CPL>& L, double (&out)[CPL], const uint64_t* exp_tab,
                                                           uint32_t& fallbacks) {
   double hi[CPL];
@@ -223,10 +224,18 @@ __device__ __forceinline__ void log_plus_finish_certified(const SoftplusLookup<C
   // One branch per row, not one test per register: the seven comparison masks are OR-ed (7 v_cmp + 6 s_or_b64, where the
   // per-register form took a compare, a select and an OR of SALU each), and which registers hold the ambiguous sums is only
   // worked out on the rare path.
+#ifdef DYN_EXP_NO_CERT_BRANCH  // development (WRONG results): what the ambiguity test and its branch cost the certified rows
+  (void)hi; (void)exp_tab; (void)fallbacks;
+  return;
+#endif
   uint64_t any_amb = 0;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) any_amb |= __ballot(out[j] != hi[j]);
   if (__builtin_expect(any_amb != 0, 0)) {
+#ifdef DYN_EXP_NO_CERT_FALLBACK  // development (WRONG results): the test and the branch, but no recomputation
+    ++fallbacks;
+    return;
+#endif
     unsigned amb = 0;  // wave-uniform: bit j = some lane's certificate failed in register j
 #pragma unroll
     for (int j = 0; j < CPL; ++j) amb |= __any(out[j] != hi[j]) ? 1u << j : 0u;
