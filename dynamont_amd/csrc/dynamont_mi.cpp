@@ -1267,10 +1267,9 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     HIP_TRY(a, b->d_cols1.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_cols2.ensure(std::max<uint64_t>(8, b->total_cols * 8)));
     HIP_TRY(a, b->d_trans.ensure(std::max<uint64_t>(16, b->n * 16)));
-    HIP_TRY(a, b->d_pooled.ensure(3 * m.num_kmers * 8));
-    HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->stream));
-    HIP_TRY(a, b->d_poolwork.ensure(std::max<size_t>(8, dynk::pool_stats_work_bytes(b->total_cols))));
-    HIP_TRY(a, b->d_pooltemp.ensure(std::max<size_t>(8, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers))));
+    // (the DEVICE-resident pooled statistics -- a radix sort and a segmented sum behind every training launch, 2.4 % of it --
+    //  have one reader, dyn_batch_device_pooled for the multi-GPU all-reduce: they are computed when it asks, round 5)
+    b->pooled_on_device = false;
   }
 
   // HBM budget for the page pool
@@ -1489,10 +1488,10 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   // (Running the per-segment kernels on a stream of their own, beside the next batch's read queue, was measured:
   //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
   if (calc) dynk::launch_segments(q.descs, nr, rows_total, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
-  if (job == DynJob::Train)
-    HIP_TRY(a, dynk::launch_pool_stats(q.descs, nr, max_N, q.st, b->d_kmers.as<int32_t>(), q.tr, b->d_pooled.as<double>(), m.num_kmers,
-                                       b->total_cols, b->d_poolwork.p, b->d_pooltemp.p, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers),
-                                       a->stream));
+  if (job == DynJob::Train) {
+    b->pool_nr = nr;
+    b->pool_max_N = max_N;
+  }
   HIP_TRY(a, hipEventRecord(ev[2], a->stream));
   HIP_TRY(a, hipEventRecord(b->ev_done, a->stream));
   HIP_TRY(a, hipGetLastError());
@@ -2335,7 +2334,25 @@ int dyn_train_batch(dyn_aligner* a, uint64_t n_reads, const double* signals,
 
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
   if (!b || !b->trained) return DYN_ERR_INVALID_ARGUMENT;
-  // filled on the device by k_pool_stats during dyn_batch_train (enqueue_job)
+  // Computed on the first call (k_pool_stats: the per-column sums of the training launch, sorted by k-mer and summed in a
+  // fixed order -- the host's pooled sum bit for bit), on the compute stream, and waited for.
+  if (!b->pooled_on_device) {
+    dyn_aligner* a = b->a;
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (int rc = need_device(a)) return rc;
+    if (int rc = dyneng::session_quiesce(a)) return rc;  // (rocPRIM's sort does not start beside resident waves)
+    const dynhost::PoreModel& m = a->model;
+    HIP_TRY(a, b->d_pooled.ensure(3 * m.num_kmers * 8));
+    HIP_TRY(a, hipMemsetAsync(b->d_pooled.p, 0, 3 * m.num_kmers * 8, a->stream));
+    HIP_TRY(a, b->d_poolwork.ensure(std::max<size_t>(8, dynk::pool_stats_work_bytes(b->total_cols))));
+    HIP_TRY(a, b->d_pooltemp.ensure(std::max<size_t>(8, dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers))));
+    const dynk::TrainBuffers tr{b->d_colw.as<double>(), b->d_cols1.as<double>(), b->d_cols2.as<double>(), b->d_trans.as<double>()};
+    HIP_TRY(a, dynk::launch_pool_stats(b->d_descs.as<ReadDesc>(), b->pool_nr, b->pool_max_N, b->d_state.as<ReadState>(), b->d_kmers.as<int32_t>(), tr,
+                                       b->d_pooled.as<double>(), m.num_kmers, b->total_cols, b->d_poolwork.p, b->d_pooltemp.p,
+                                       dynk::pool_stats_temp_bytes(b->total_cols, m.num_kmers), a->stream));
+    HIP_TRY(a, hipStreamSynchronize(a->stream));
+    b->pooled_on_device = true;
+  }
   if (d_pooled3n) *d_pooled3n = b->d_pooled.p;
   if (count) *count = 3 * b->a->model.num_kmers;
   return DYN_OK;

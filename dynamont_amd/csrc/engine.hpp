@@ -237,6 +237,10 @@ struct dyn_batch {
   dyn_align_out* out_align = nullptr;
   dyn_train_out* out_train = nullptr;
   double* out_pooled = nullptr;
+  // dyn_batch_device_pooled computes the device-resident pooled statistics on its first call: what it needs of the launch
+  bool pooled_on_device = false;
+  int pool_nr = 0;
+  uint32_t pool_max_N = 0;
   int rc = DYN_OK;             // result of the pipeline stages
   std::string error;           // message for rc != DYN_OK (copied to the handle by dyn_batch_wait)
   bool done = false;

@@ -485,7 +485,8 @@ int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n);
  * next call on the batch. */
 int dyn_batch_device_results(dyn_batch* b, void** d_rows, uint64_t* capacity, void** d_z_status);
 /* Device-resident pooled sufficient statistics (3*num_kmers doubles) of the last
- * dyn_batch_train, for an RCCL all-reduce. */
+ * dyn_batch_train, for an RCCL all-reduce. Computed by the first call (a sort by k-mer and a fixed-order sum of the
+ * launch's per-column sums, on the handle's compute stream) and waited for: training that never asks does not pay for it. */
 int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count);
 int dyn_batch_timing(const dyn_batch* b, dyn_timing* t);
 
