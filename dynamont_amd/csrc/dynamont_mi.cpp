@@ -1695,10 +1695,11 @@ bool session_candidate(const dyn_batch* b) {
   const dyn_aligner* a = b->a;
   // (b->async: a caller's ticket. The batch of a MERGED launch is the engine's own and stays one launch: its members report
   //  that launch and their share of it.)
-  // align(calc_probabilities=1) only. Training tickets were tried (round 5, k_session<JOB_TRAIN>): the kernels that follow each
-  // of them on the copy-out stream -- rocPRIM's radix sort for the fixed-order pooled statistics -- did not progress beside a
-  // resident session (8 CUs left free for them, their queue's scratch allocated beforehand): every ticket's results arrived
-  // when the session ENDED. Training stays one launch per batch.
+  // align(calc_probabilities=1) only. Training tickets were tried twice (round 5, k_session<JOB_TRAIN>). First the kernels that
+  // followed each of them -- rocPRIM's radix sort for the device-resident pooled statistics -- did not start beside resident
+  // waves; those statistics are computed on demand since (dyn_batch_device_pooled). Then, with nothing following a training
+  // ticket, sessions measured 805.6 / 810.5 against 810.7 / 813.9 Msamp/s for one launch per batch: 1 024 reads on 1 024
+  // waves keep a launch's waves busy 0.98 of it already. Training stays one launch per batch.
   return a->s_session && !a->host_only && !a->ntk && b->async && b->job == DynJob::AlignFull &&
          (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
 }
