@@ -2337,9 +2337,9 @@ int dyn_batch_device_pooled(dyn_batch* b, void** d_pooled3n, uint64_t* count) {
   if (!b || !b->trained) return DYN_ERR_INVALID_ARGUMENT;
   // Computed on the first call (k_pool_stats: the per-column sums of the training launch, sorted by k-mer and summed in a
   // fixed order -- the host's pooled sum bit for bit), on the compute stream, and waited for.
+  dyn_aligner* a = b->a;
+  std::lock_guard<std::mutex> lk(a->mu);
   if (!b->pooled_on_device) {
-    dyn_aligner* a = b->a;
-    std::lock_guard<std::mutex> lk(a->mu);
     if (int rc = need_device(a)) return rc;
     if (int rc = dyneng::session_quiesce(a)) return rc;  // (rocPRIM's sort does not start beside resident waves)
     const dynhost::PoreModel& m = a->model;
