@@ -1665,6 +1665,7 @@ int session_open(dyn_aligner* a, bool mixed, const SessionGeom& g) {
   sa.pool.ctl = paged ? a->ctl.as<uint32_t>() : nullptr;
   sa.pool.log_rows = log_r;
   sa.pool.n_pages = n_pages_total;
+  sa.pool.reserve_after = paged ? 64u : 0u;  // a stream never ends: a large request must not starve behind small ones
   sa.m1 = a->model.log_m1;
   sa.e2 = a->model.log_e2;
   sa.idle_limit_ticks = (uint64_t)(a->sess_idle_s * 1e8);

@@ -1188,6 +1188,10 @@ __device__ __forceinline__ void ctl_store(uint32_t* p, uint32_t v) {
 // recovers) raises the abort word, which drains the queue -- the grid always terminates, and the host
 // reports the launch as failed instead of hanging the device.
 constexpr int CTL_LOCK = 0, CTL_HEAD = 1, CTL_FREE = 2, CTL_ABORT = 3, CTL_PROVISIONED = 4, CTL_WAITING = 5;
+// (round 5, paged sessions: PagePool::reserve_after) a wave that has waited for pages for ~2 ms RESERVES its request: [6] pages the others must leave on the stack,
+// [7] the reserving wave (slot + 1; 0 = nobody). Without it a request for many pages (a 100 k-sample read: ~390) can lose
+// against a stream of small ones for as long as reads keep coming -- in a resident session, for ever.
+constexpr int CTL_RESERVE = 6, CTL_RESERVE_OWNER = 7;
 constexpr int LOCK_SPINS_MAX = 1 << 24;   // x ~0.3 us
 constexpr int PAGE_WAITS_MAX = 1 << 18;   // x ~30 us
 
@@ -1235,30 +1239,58 @@ __device__ __forceinline__ void pages_give(const PagePool& pool, const WaveCtx& 
   queue_unlock(ctl, w.lane);
 }
 
-// `count` pages from the free list -> pt[0 .. count); the wave holds no pages while it waits.
+// `count` pages from the free list -> pt[0 .. count); the wave holds no pages while it waits. `me` = the wave's slot + 1.
 // Returns false when the launch was aborted.
-__device__ __forceinline__ bool pages_take(const PagePool& pool, const WaveCtx& w, uint32_t count) {
+__device__ __forceinline__ bool pages_take(const PagePool& pool, const WaveCtx& w, uint32_t count, uint32_t me) {
   uint32_t* ctl = pool.ctl;
+  auto sload = [&](int word) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[word])); };
   if (w.lane == 0) __hip_atomic_fetch_add(&ctl[CTL_WAITING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool ok = false;
   for (int waits = 0; !ok; ++waits) {
-    if (__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_ABORT])) != 0) break;
+    if (sload(CTL_ABORT) != 0) break;
     if (waits > PAGE_WAITS_MAX) {
       if (w.lane == 0) ctl_store(&ctl[CTL_ABORT], 1u);
       break;
     }
-    // look before locking: the lock is only worth taking when the request can be served
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE])) < count) {
+    // look before locking: the lock is only worth taking when the request can be served -- beside what another wave has
+    // reserved -- or when it is time to reserve
+    const uint32_t owner = sload(CTL_RESERVE_OWNER);
+    const uint32_t kept = (owner != 0 && owner != me) ? sload(CTL_RESERVE) : 0u;
+    const bool reserve_now = pool.reserve_after != 0 && owner == 0 && (uint32_t)waits >= pool.reserve_after;
+    if (!reserve_now && sload(CTL_FREE) < count + kept) {
       for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127);  // pages come back every ~20 us at best
       continue;
     }
     queue_lock(ctl, w.lane);
-    const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_FREE]));
-    if (fc >= count) {
+    const uint32_t fc = sload(CTL_FREE);
+    const uint32_t owner2 = sload(CTL_RESERVE_OWNER);
+    const uint32_t kept2 = (owner2 != 0 && owner2 != me) ? sload(CTL_RESERVE) : 0u;
+    if (fc >= count + kept2) {
       for (uint32_t k = w.lane; k < count; k += 64) w.pt[k] = ctl_load(&pool.free_list[fc - count + k]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (w.lane == 0) ctl_store(&ctl[CTL_FREE], fc - count);
+      if (w.lane == 0) {
+        ctl_store(&ctl[CTL_FREE], fc - count);
+        if (owner2 == me) {
+          ctl_store(&ctl[CTL_RESERVE], 0u);
+          ctl_store(&ctl[CTL_RESERVE_OWNER], 0u);
+        }
+      }
       ok = true;
+    } else if (pool.reserve_after != 0 && owner2 == 0 && (uint32_t)waits >= pool.reserve_after) {
+      if (w.lane == 0) {  // from here on the others leave `count` pages on the stack
+        ctl_store(&ctl[CTL_RESERVE], count);
+        ctl_store(&ctl[CTL_RESERVE_OWNER], me);
+      }
+    }
+    queue_unlock(ctl, w.lane);
+    if (!ok)
+      for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+  if (!ok && sload(CTL_RESERVE_OWNER) == me) {  // aborted while holding a reservation
+    queue_lock(ctl, w.lane);
+    if (w.lane == 0) {
+      ctl_store(&ctl[CTL_RESERVE], 0u);
+      ctl_store(&ctl[CTL_RESERVE_OWNER], 0u);
     }
     queue_unlock(ctl, w.lane);
   }
@@ -1458,7 +1490,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_read_queue(const QueueArgs q, const Read
         if (have < rd.n_pages) {  // a wave without an arena (or, with another queue order, too small a one)
           if (have) pages_give(q.pool, w, 0, have);
           have = 0;
-          if (!pages_take(q.pool, w, rd.n_pages)) break;
+          if (!pages_take(q.pool, w, rd.n_pages, (uint32_t)slot + 1u)) break;
           have = rd.n_pages;
         } else if (have - rd.n_pages >= 8 && 8 * (have - rd.n_pages) >= have &&
                    __builtin_amdgcn_readfirstlane((int)ctl_load(&ctl[CTL_WAITING])) != 0) {
@@ -1615,7 +1647,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
       if (held < rd.n_pages) {
         if (held) pages_give(sa.pool, w, 0, held);
         held = 0;
-        if (!pages_take(sa.pool, w, rd.n_pages)) {
+        if (!pages_take(sa.pool, w, rd.n_pages, slot + 1u)) {
           // waited for pages for seconds: the session is over; what is incomplete is published again (session_recover)
           if (w.lane == 0) ctl_store(&ctl[S_ABORT], 3u);
           break;

@@ -95,6 +95,8 @@ struct PagePool {
   uint32_t* ctl;
   int log_rows;         // rows per page = 1 << log_rows
   uint32_t n_pages;
+  uint32_t reserve_after;  // waits (x ~30 us) after which a wave RESERVES its request for pages; 0 = never (one launch per batch:
+                           // the queue is finite and its order planned). Paged sessions: 64
 };
 constexpr int QUEUE_CTL_WORDS = 32;   // 32-bit words reserved for ctl (stats start at word 8, 8-byte aligned)
 constexpr int QUEUE_STATS = 8;        // first stats word (as uint32 index)
