@@ -194,15 +194,36 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> dynamont_amd/libdynamont_mi.so (in-tree, so it travels)."""
+    """hipcc --offload-arch=gfx950 -> dynamont_amd/libdynamont_mi.so (in-tree, so it travels). One object per source under
+    build/obj/<hash of the flags>/ (compiled in parallel, recompiled only when the source or any header is newer), then
+    one link: the same flags and the same device code as a single hipcc command over all sources."""
     if os.environ.get("DYN_LIB_PATH") or (not force and not needs_build()):
         return LIB_PATH  # (a library named by DYN_LIB_PATH is built by whoever named it)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wno-unused-result", "-pthread", "-ldl", "-lz", "-o", LIB_PATH + ".tmp"]
-    cmd += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-pthread"]
+    flags += os.environ.get("DYN_HIPCC_EXTRA", "").split()  # kernel experiments: -DDYN_EXP_...
+    objdir = os.path.join(os.path.dirname(HERE), "build", "obj", hashlib.sha1(" ".join(flags).encode()).hexdigest()[:12])
+    os.makedirs(objdir, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc_path()] + flags + ["-x", "hip", "-c", path, "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB_PATH + ".tmp"] + objs + ["-ldl", "-lz"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

@@ -491,41 +491,57 @@ static bool model_allows_strict(const dynhost::PoreModel& m) {
 // stopped there), and a parked stream costs one idle hardware queue.
 static std::mutex g_sess_stream_m;
 static std::vector<hipStream_t> g_sess_streams[32];
-static void park_session_stream(dyn_aligner* a) {
-  if (!a->s_session) return;
-  if (std::getenv("DYN_DESTROY_SESSION_STREAM")) {
+
+extern "C++" {
+namespace dyneng {
+// shared with rccl_comm.cpp: a dyn_comm's stream is of the same kind and is parked the same way
+hipStream_t take_masked_stream(int device, int n_cus) {
+  if (device >= 0 && device < 32) {
+    std::lock_guard<std::mutex> lk(g_sess_stream_m);
+    if (!g_sess_streams[device].empty()) {
+      hipStream_t s = g_sess_streams[device].back();
+      g_sess_streams[device].pop_back();
+      return s;
+    }
+  }
+  if (n_cus <= 0) return nullptr;
+  std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
+  for (int c = 0; c < n_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return s;
+}
+
+void park_masked_stream(int device, hipStream_t s) {
+  if (!s) return;
+  if (std::getenv("DYN_DESTROY_SESSION_STREAM") || device < 0 || device >= 32) {
     // for processes that create ONE handle and run under rocprofv3 (tools/profile_round.sh): the profiler's exit handler
     // faults on a queue that is still alive, and the first destroy of a process has always returned
-    (void)hipStreamDestroy(a->s_session);
-    a->s_session = nullptr;
+    (void)hipStreamDestroy(s);
     return;
   }
   std::lock_guard<std::mutex> lk(g_sess_stream_m);
-  if (a->device >= 0 && a->device < 32) g_sess_streams[a->device].push_back(a->s_session);
+  g_sess_streams[device].push_back(s);
+}
+}  // namespace dyneng
+}  // extern "C++"
+
+static void park_session_stream(dyn_aligner* a) {
+  if (!a->s_session) return;
+  dyneng::park_masked_stream(a->device, a->s_session);
   a->s_session = nullptr;
 }
 
 static int make_session_stream(dyn_aligner* a, int reserved_cus) {
-  if (!a->s_session && a->device >= 0 && a->device < 32) {
-    std::lock_guard<std::mutex> lk(g_sess_stream_m);
-    if (!g_sess_streams[a->device].empty()) {
-      a->s_session = g_sess_streams[a->device].back();
-      g_sess_streams[a->device].pop_back();
-    }
-  }
   // Reserved CUs are not masked out: a session is ONE workgroup per CU it uses (150 KB of LDS each), so a grid of
   // n_cus - reserved workgroups leaves `reserved` CUs empty wherever the dispatcher puts it. The mask enables every CU (the
   // stream serves any mode); what it buys is the hardware queue.
   a->sess_cus = std::max(1, a->n_cus - std::max(0, reserved_cus));
-  if (!a->s_session) {
-    std::vector<uint32_t> mask((size_t)(a->n_cus + 31) / 32, 0u);
-    for (int c = 0; c < a->n_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-    if (hipExtStreamCreateWithCUMask(&a->s_session, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      a->s_session = nullptr;
-      return DYN_ERR_DEVICE;
-    }
-  }
+  if (!a->s_session) a->s_session = dyneng::take_masked_stream(a->device, a->n_cus);
+  if (!a->s_session) return DYN_ERR_DEVICE;
   if (!a->sess_flags && hipHostMalloc(reinterpret_cast<void**>(&a->sess_flags), SESSION_FLAGS * 4, hipHostMallocCoherent) != hipSuccess) {
     (void)hipGetLastError();
     park_session_stream(a);

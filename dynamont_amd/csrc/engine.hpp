@@ -286,6 +286,10 @@ namespace dyneng {
 
 // ---- shared between dynamont_mi.cpp and async_engine.cpp -------------------------------------
 int need_device(dyn_aligner* a);
+// CU-masked streams (every CU enabled: a hardware queue of their own) are parked per device and reused, never destroyed
+// (dynamont_mi.cpp); nullptr when the runtime provides none. The session stream and a dyn_comm's stream come from here.
+hipStream_t take_masked_stream(int device, int n_cus);
+void park_masked_stream(int device, hipStream_t s);
 // per-batch buffers come from / go back to the handle's BufCache
 void attach_cache(dyn_batch* b);
 // validateInput + sequenceToKmers of every read; fills b->reads / b->h_kmers / capacity / max_T / max_N

@@ -16,8 +16,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -35,6 +38,7 @@ struct Rccl {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional: a peer that has gone shows up here first
   std::string error;
 
   bool load() {
@@ -72,6 +76,7 @@ struct Rccl {
     DYN_R(AllReduce, "ncclAllReduce");
     DYN_R(AllGather, "ncclAllGather");
 #undef DYN_R
+    CommGetAsyncError = reinterpret_cast<decltype(CommGetAsyncError)>(dlsym(lib, "ncclCommGetAsyncError"));
     return true;
   }
 };
@@ -88,12 +93,14 @@ struct dyn_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1, device = 0;
   hipStream_t stream = nullptr;
-  bool stream_masked = false;    // created with hipExtStreamCreateWithCUMask (a hardware queue of its own)
+  bool stream_masked = false;    // a CU-masked stream (a hardware queue of its own), parked per device when the handle goes
+  double timeout_s = 300.0;      // DYN_COMM_TIMEOUT_S: how long one exchange may take before the communicator is aborted
   uint64_t* d_counts = nullptr;  // [n_ranks] rows per rank (all-gather target)
   void* d_recv = nullptr;        // root: gathered rows
   size_t recv_bytes = 0;
   std::vector<void*> retired;    // receive buffers that were outgrown: freed with the communicator (hipFree waits for the whole
-                                 // device, i.e. for the END of a resident read queue -- never in the middle of a run)
+                                 // device, i.e. for the END of a resident read queue -- never in the middle of a run). Growth
+                                 // is x1.5, so what is retired adds up to at most TWICE the live buffer
   std::string last_error;
   // rows every rank announced in the last dyn_comm_gather_counts (the exchange dyn_comm_gather_rows then performs)
   std::vector<uint64_t> counts;
@@ -104,8 +111,24 @@ struct dyn_comm {
 // A failure BETWEEN the collectives of one exchange (an allocation on the root, an RCCL call inside the group) would leave
 // the peers blocked in their half of it: the communicator is aborted instead, so that their pending operations return
 // with an error. The handle is unusable afterwards (every later call fails).
+static bool comm_trace() {
+  static const bool on = std::getenv("DYN_COMM_TRACE") != nullptr;
+  return on;
+}
+#define C_TRACE(c, ...)                                             \
+  do {                                                              \
+    if (comm_trace()) {                                             \
+      std::fprintf(stderr, "[dyn_comm rank %d] ", (c)->rank);       \
+      std::fprintf(stderr, __VA_ARGS__);                            \
+      std::fprintf(stderr, "\n");                                   \
+      std::fflush(stderr);                                          \
+    }                                                               \
+  } while (0)
+
 static void abort_comm(dyn_comm* c) {
+  C_TRACE(c, "abort: ncclCommAbort ...");
   if (c->comm && !c->aborted) (void)g_rccl.CommAbort(c->comm);
+  C_TRACE(c, "abort: done");
   c->comm = nullptr;
   c->aborted = true;
 }
@@ -172,20 +195,16 @@ int dyn_comm_create(const uint8_t* id128, int rank, int n_ranks, int device, dyn
   }
   // A stream with a hardware queue of its own where the runtime provides one (a CU-masked stream, every CU enabled): an RCCL
   // kernel waits for its peers while it runs, and whatever shares its hardware queue waits with it -- the copies and small
-  // kernels that feed a resident read queue must not (tools/ubench/resident_probe.hip).
+  // kernels that feed a resident read queue must not (tools/ubench/resident_probe.hip). Such streams are parked per device
+  // and reused (dyneng::take_masked_stream): a communicator created and destroyed in a loop costs no hardware queue per turn.
   {
     int n_cus = 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cus > 0) {
-      std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
-      for (int k = 0; k < n_cus; ++k) mask[(size_t)k / 32] |= 1u << (k % 32);
-      if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        c->stream = nullptr;
-      } else {
-        c->stream_masked = true;
-      }
+      c->stream = dyneng::take_masked_stream(device, n_cus);
+      c->stream_masked = c->stream != nullptr;
     }
   }
+  if (const char* t = std::getenv("DYN_COMM_TIMEOUT_S")) c->timeout_s = std::max(0.05, std::atof(t));
   if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
       hipMalloc(reinterpret_cast<void**>(&c->d_counts), sizeof(uint64_t) * (size_t)n_ranks) != hipSuccess) {
     put_err(err, errcap, "HIP error while setting up the communicator's stream");
@@ -204,8 +223,10 @@ void dyn_comm_destroy(dyn_comm* c) {
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_recv) (void)hipFree(c->d_recv);
   for (void* p : c->retired) (void)hipFree(p);
-  // (a CU-masked stream is left to the runtime: destroying a second one in a process did not return on ROCm 7.2, dynamont_mi.cpp)
-  if (c->stream && !c->stream_masked) (void)hipStreamDestroy(c->stream);
+  // (a CU-masked stream is parked for the next communicator or handle of the process: destroying a second one in a process
+  // did not return on ROCm 7.2, dynamont_mi.cpp)
+  if (c->stream && c->stream_masked) dyneng::park_masked_stream(c->device, c->stream);
+  else if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -230,6 +251,46 @@ const char* dyn_comm_last_error(const dyn_comm* c) { return c ? c->last_error.c_
       return DYN_ERR_DEVICE;                                                                    \
     }                                                                                           \
   } while (0)
+
+// The end of an exchange: the stream has passed the collective. RCCL's kernels wait for their peers ON THE DEVICE, so a peer
+// that has gone (a crashed rank, a job that was cancelled on one GPU) would leave hipStreamSynchronize waiting for ever: the
+// wait polls instead, asks RCCL for asynchronous errors, and after DYN_COMM_TIMEOUT_S (300 s) aborts the communicator --
+// ncclCommAbort ends the local kernels -- and fails the call. The handle is unusable afterwards, like after any abort.
+static int wait_exchange(dyn_comm* c, const char* what) {
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  int spins = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) return DYN_OK;
+    if (q != hipErrorNotReady) {
+      c->last_error = std::string("HIP error: ") + hipGetErrorString(q) + " while waiting for " + what;
+      abort_comm(c);
+      return DYN_ERR_DEVICE;
+    }
+    const double waited = std::chrono::duration<double>(clock::now() - t0).count();
+    if ((++spins & 63) == 0 && g_rccl.CommGetAsyncError && c->comm) {
+      ncclResult_t ar = ncclSuccess;
+      if (g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+        C_TRACE(c, "%s: asynchronous error %d after %.3f s", what, (int)ar, waited);
+        c->last_error = std::string("RCCL error: ") + g_rccl.GetErrorString(ar) + " (asynchronous) during " + what +
+                        ": the communicator was aborted";
+        abort_comm(c);
+        (void)hipStreamSynchronize(c->stream);
+        return DYN_ERR_DEVICE;
+      }
+    }
+    if (waited > c->timeout_s) {
+      C_TRACE(c, "%s: timeout after %.1f s", what, waited);
+      c->last_error = std::string(what) + " did not complete within " + std::to_string(c->timeout_s) +
+                      " s (DYN_COMM_TIMEOUT_S): a peer has gone or never arrived; the communicator was aborted";
+      abort_comm(c);
+      (void)hipStreamSynchronize(c->stream);  // the aborted kernels leave
+      return DYN_ERR_DEVICE;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.002 ? 20 : waited < 0.1 ? 100 : 1000));
+  }
+}
 
 // rows this rank contributes: 0 when its batch failed (the error is kept; the rank still takes part in the collectives)
 static int local_rows(dyn_comm* c, dyn_batch* b, void** d_rows, uint64_t* n_rows) {
@@ -262,6 +323,9 @@ int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out) {
   C_TRY_X(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
   N_TRY_X(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
   c->counts.assign((size_t)c->n_ranks, 0);
+  // (the copies out come AFTER the bounded wait: a copy into pageable memory blocks its caller until the stream gets there,
+  // i.e. for as long as the collective in front of it waits for a peer)
+  if (int rc = wait_exchange(c, "the all-gather of row counts")) return rc;
   C_TRY_X(c, hipMemcpyAsync(c->counts.data(), c->d_counts, sizeof(uint64_t) * c->counts.size(), hipMemcpyDeviceToHost, c->stream));
   C_TRY_X(c, hipStreamSynchronize(c->stream));
   c->counts_valid = true;
@@ -293,7 +357,7 @@ int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* r
   constexpr size_t ROW = sizeof(dyn_segment_row);
   const bool too_small = c->rank == root && rows_out && rows_cap < total;
   if (c->rank == root && c->recv_bytes < total * ROW) {
-    if (c->d_recv) c->retired.push_back(c->d_recv);  // (growth is geometric: what is retired adds up to less than what is live)
+    if (c->d_recv) c->retired.push_back(c->d_recv);  // (growth x1.5: the retired buffers add up to at most twice the live one)
     c->d_recv = nullptr;
     c->recv_bytes = 0;
     const size_t want = std::max<size_t>(total * ROW + total * ROW / 2, ROW);
@@ -316,10 +380,14 @@ int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* r
   } else if (mine) {
     N_TRY_X(c, g_rccl.Send(d_rows, mine * ROW, ncclUint8, root, c->comm, c->stream));
   }
+  C_TRACE(c, "gather_rows: ncclGroupEnd ...");
   N_TRY_X(c, g_rccl.GroupEnd());
-  if (c->rank == root && rows_out && !too_small && total)
+  C_TRACE(c, "gather_rows: group enqueued, waiting");
+  if (int rc = wait_exchange(c, "the gather of segment rows")) return rc;  // the batch's buffers may be released after this call
+  if (c->rank == root && rows_out && !too_small && total) {
     C_TRY_X(c, hipMemcpyAsync(rows_out, c->d_recv, total * ROW, hipMemcpyDeviceToHost, c->stream));
-  C_TRY_X(c, hipStreamSynchronize(c->stream));  // the batch's buffers may be released after this call
+    C_TRY_X(c, hipStreamSynchronize(c->stream));
+  }
   if (too_small) {  // the exchange itself is complete on every rank: nothing hangs, the root may call again with room
     c->last_error = "dyn_comm_gather_rows: rows_cap is smaller than the sum of all ranks' rows (dyn_comm_gather_counts tells it)";
     return DYN_ERR_INVALID_ARGUMENT;
@@ -349,8 +417,11 @@ int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n) {
   C_TRY_X(c, hipSetDevice(c->device));
   // linear-domain sums (w, s1, s2)[numKmers]: a plain sum all-reduce is exact up to fp64 association
   N_TRY_X(c, g_rccl.AllReduce(d_pooled, d_pooled, count, ncclDouble, ncclSum, c->comm, c->stream));
-  if (pooled3n) C_TRY_X(c, hipMemcpyAsync(pooled3n, d_pooled, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  C_TRY_X(c, hipStreamSynchronize(c->stream));
+  if (int wrc = wait_exchange(c, "the all-reduce of pooled statistics")) return wrc;
+  if (pooled3n) {
+    C_TRY_X(c, hipMemcpyAsync(pooled3n, d_pooled, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    C_TRY_X(c, hipStreamSynchronize(c->stream));
+  }
   return DYN_OK;
 }
 
