@@ -352,6 +352,14 @@ void copy_msg(char* buf, uint64_t cap, const std::string& s) {
     }                                                                                     \
   } while (0)
 
+// A getter's copy off the device: on the handle's own non-blocking stream and waited for there. The data is complete when a
+// getter may be called (the synchronous job calls return after the compute stream has passed the batch, dyn_batch_wait after
+// the copy-out stream has); a null-stream hipMemcpy would ALSO wait for the resident session kernel that later tickets keep
+// open (the session stream is not a non-blocking one) and serialise a caller's stream of batches.
+hipError_t copy_out(dyn_aligner* a, void* dst, const void* src, size_t bytes) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, a->s_get);
+  return e != hipSuccess ? e : hipStreamSynchronize(a->s_get);
+}
 
 }  // namespace
 
@@ -602,7 +610,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
                               " (the MI355X build has no CPU compute path)");
     park_session_stream(a);
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_get})
       if (s) (void)hipStreamDestroy(s);
     if (a->sess_flags) (void)hipHostFree(a->sess_flags);
     a->d_model.release();
@@ -623,6 +631,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&a->s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&a->s_get, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   // The resident read queue needs a hardware queue of its own: plain streams share four per process, and a kernel that stays
   // resident blocks whatever is queued behind it in the same one -- the copies and small kernels it is waiting for included
   // (tools/ubench/resident_probe.hip). A CU-masked stream (all CUs enabled) always gets its own. No such stream, or
@@ -633,8 +642,12 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.001, std::atof(f));
   }
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
-  if ((e = hipMemcpy(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size(),
-                     hipMemcpyHostToDevice)) != hipSuccess)
+  // (uploads on the handle's own non-blocking stream: a null-stream copy would wait for another handle's resident session)
+  auto upload = [&](void* dst, const void* src, size_t bytes) {
+    hipError_t ue = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, a->stream);
+    return ue != hipSuccess ? ue : hipStreamSynchronize(a->stream);
+  };
+  if ((e = upload(a->d_model.p, a->model.table.data(), sizeof(Emis) * a->model.table.size())) != hipSuccess)
     return fail(e, "hipMemcpy(model)");
   {
     std::vector<dynmath::SoftplusNode> tab(dynmath::SP_NODES + dynmath::EXP128_NODES + dynmath::STRICT_EXP_WORDS / 2);
@@ -643,7 +656,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     std::memcpy(tab.data() + dynmath::SP_NODES + dynmath::EXP128_NODES, dynmath::strict_exp_table(),
                 dynmath::STRICT_EXP_WORDS * 8);  // 2^(k/128) of the strict exp
     if ((e = a->d_sptab.ensure(sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess) return fail(e, "hipMalloc(softplus table)");
-    if ((e = hipMemcpy(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = upload(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess)
       return fail(e, "hipMemcpy(softplus table)");
   }
   *out = a;
@@ -685,7 +698,7 @@ void dyn_aligner_destroy(dyn_aligner* a) {
     a->cache.park(a->device);
     if (trace) std::fprintf(stderr, "[dyn] destroy %p: buffers parked; destroying streams\n", (void*)a);
     park_session_stream(a);
-    for (hipStream_t s : {a->stream, a->s_in, a->s_out})
+    for (hipStream_t s : {a->stream, a->s_in, a->s_out, a->s_get})
       if (s) (void)hipStreamDestroy(s);
     if (trace) std::fprintf(stderr, "[dyn] destroy %p: done\n", (void*)a);
   }
@@ -998,11 +1011,11 @@ int dyn_batch_signals(dyn_batch* b, double* out, uint64_t count) {
     const dyn_batch* g = b->group->g;
     const uint64_t first = b->n ? g->reads[b->g_read0].sig_off : 0;
     if ((first + count) * 8 > g->d_sig.bytes) return DYN_ERR_INVALID_ARGUMENT;
-    HIP_TRY(a, hipMemcpy(out, g->d_sig.as<double>() + first, count * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(a, copy_out(a, out, g->d_sig.as<double>() + first, count * 8));
     return DYN_OK;
   }
   if (count * 8 > b->d_sig.bytes) return DYN_ERR_INVALID_ARGUMENT;
-  HIP_TRY(a, hipMemcpy(out, b->d_sig.p, count * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(a, copy_out(a, out, b->d_sig.p, count * 8));
   return DYN_OK;
 }
 
@@ -2278,7 +2291,7 @@ int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out) {
   const uint64_t read0 = src == b ? 0 : b->g_read0, seg0 = src == b ? 0 : b->g_seg0;
   std::vector<ReadState> st(src->n);
   if (b->n)
-    HIP_TRY(a, hipMemcpy(st.data() + read0, static_cast<const ReadState*>(src->d_state.p) + read0, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
+    HIP_TRY(a, copy_out(a, st.data() + read0, static_cast<const ReadState*>(src->d_state.p) + read0, b->n * sizeof(ReadState)));
   const bool want_rows = b->last_calc && (out->sequence_positions || out->signal_positions || out->probabilities || out->states);
   if (want_rows && out->capacity < b->capacity) {
     a->last_error = "dyn_align_out.capacity is smaller than dyn_segment_capacity()";
@@ -2290,7 +2303,7 @@ int dyn_batch_fetch(dyn_batch* b, dyn_align_out* out) {
   std::lock_guard<std::mutex> lk(pool_mu);  // also guards the handle's h_rows staging
   if (want_rows && b->capacity) {
     HIP_TRY(a, a->h_rows.ensure(b->capacity * sizeof(SegRow)));
-    HIP_TRY(a, hipMemcpy(a->h_rows.p, static_cast<const SegRow*>(src->d_rows.p) + seg0, b->capacity * sizeof(SegRow), hipMemcpyDeviceToHost));
+    HIP_TRY(a, copy_out(a, a->h_rows.p, static_cast<const SegRow*>(src->d_rows.p) + seg0, b->capacity * sizeof(SegRow)));
     rows = static_cast<const SegRow*>(a->h_rows.p) - seg0;  // unpack_align indexes rows by the batch's own segment offsets
   }
   unpack_align(src, st.data(), rows, out, &pool, read0, b->n, seg0);
@@ -2326,13 +2339,13 @@ int dyn_batch_fetch_train(dyn_batch* b, dyn_train_out* out, double* pooled3n) {
   std::vector<ReadState> st(b->n);
   std::vector<double> cw(b->total_cols), c1(b->total_cols), c2(b->total_cols), tr(2 * b->n);
   if (b->n) {
-    HIP_TRY(a, hipMemcpy(st.data(), b->d_state.p, b->n * sizeof(ReadState), hipMemcpyDeviceToHost));
-    HIP_TRY(a, hipMemcpy(tr.data(), b->d_trans.p, b->n * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(a, copy_out(a, st.data(), b->d_state.p, b->n * sizeof(ReadState)));
+    HIP_TRY(a, copy_out(a, tr.data(), b->d_trans.p, b->n * 16));
   }
   if (b->total_cols) {
-    HIP_TRY(a, hipMemcpy(cw.data(), b->d_colw.p, b->total_cols * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(a, hipMemcpy(c1.data(), b->d_cols1.p, b->total_cols * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(a, hipMemcpy(c2.data(), b->d_cols2.p, b->total_cols * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(a, copy_out(a, cw.data(), b->d_colw.p, b->total_cols * 8));
+    HIP_TRY(a, copy_out(a, c1.data(), b->d_cols1.p, b->total_cols * 8));
+    HIP_TRY(a, copy_out(a, c2.data(), b->d_cols2.p, b->total_cols * 8));
   }
   finalise_train(b, st.data(), cw.data(), c1.data(), c2.data(), tr.data(), out, pooled3n);
   return DYN_OK;

@@ -135,6 +135,8 @@ struct dyn_aligner {
   hipStream_t stream = nullptr;  // compute stream: every kernel of every batch of this handle, in submission order
   hipStream_t s_in = nullptr;    // H2D of the asynchronous pipeline
   hipStream_t s_out = nullptr;   // D2H of the asynchronous pipeline
+  hipStream_t s_get = nullptr;   // the getters' copies (dyn_batch_fetch, _fetch_train, _signals): non-blocking, so that they do
+                                 // not wait -- as a null-stream hipMemcpy would -- for a resident session that later tickets keep open
   dyneng::DevBuf d_model;
   dyneng::DevBuf d_sptab;  // softplus table (dp_math.hpp), staged into LDS by every DP workgroup
   uint64_t mem_budget = 0;

@@ -186,3 +186,43 @@ def test_page_starved_tickets_share_the_pool_of_a_paged_session(models, monkeypa
     s = al.session_stats()
     assert s["aborted"] == 0 and s["sessions"] >= 1 and s["tickets"] == 12
     al.close()
+
+
+def test_getters_of_a_completed_ticket_do_not_wait_for_the_session(models):
+    """dyn_batch_fetch / dyn_batch_signals copied with a null-stream hipMemcpy, which waits for the resident
+    session kernel that LATER tickets keep open -- a caller fetching from ticket k with k+1.. in flight was held until the
+    pipeline ran dry. The getters copy on the handle's own non-blocking stream now: fetching from the first ticket returns
+    while the others are still being worked on, the rows are the ticket's, and the session is neither aborted nor drained
+    (all tickets in ONE session)."""
+    import time
+
+    from dynamont_amd._dynamont import AlignBatchResult
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    small = synth.make_reads(4800, 640, "rna004", mean, sd, (200, 420))
+    big = synth.make_reads(4801, 1024, "rna004", mean, sd, 2000)
+    p_small, p_big = synth.pack_reads(small), synth.pack_reads(big)
+    al = Aligner(models["syn9"], "rna004", device=0)
+    want = al.align_batch([r.signal for r in small], [r.sequence for r in small], True)
+    al.align_async(*p_big, True).close()            # warm: pool, buffers
+    s0 = al.session_stats()
+    first = al.align_async(*p_small, True)
+    rest = [al.align_async(*p_big, True) for _ in range(8)]   # ~0.3 s of GPU work behind the first ticket
+    first.wait()
+    t0 = time.perf_counter()
+    again = AlignBatchResult(want.n, int(want.seg_offsets[-1]))
+    import ctypes
+    rc = al._L.dyn_batch_fetch(first._h, ctypes.byref(again._c))
+    t_fetch = time.perf_counter() - t0
+    assert rc == 0
+    t0 = time.perf_counter()
+    for t in rest:
+        t.wait()
+    t_rest = time.perf_counter() - t0
+    _same(again, want)
+    _same(first.result, want)
+    assert t_fetch < t_rest, (t_fetch, t_rest)     # (a null-stream copy returned when the LAST ticket's session ended: t_rest ~ 0)
+    for t in [first] + rest:
+        t.close()
+    s1 = al.session_stats()
+    assert s1["aborted"] == s0["aborted"] == 0 and s1["sessions"] - s0["sessions"] == 1 and s1["tickets"] - s0["tickets"] == 9
+    al.close()

@@ -421,3 +421,25 @@ def test_native_csv_sink_frames_header_and_error_lines(native_lib, tmp_path):
     assert zstd_io.decompress(data) == b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
     assert csv.value == 80 and nerr.value == 2
     assert open(errs).read().splitlines() == ["error: worker, boom\tN: 12\tRid: r1\tSid: s1", "error: worker, bang\tN: 7\tRid: r2\tSid: s2"]
+
+
+def test_console_scripts_carry_the_reference_names_and_resolve(capsys):
+    """pyproject.toml declares `dynamont-resquiggle` / `dynamont-train` like /root/reference/pyproject.toml:46-48 does; the
+    entry points import and answer --help (no GPU, no library call)."""
+    import importlib
+
+    import pytest
+    import tomli
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as f:
+        scripts = tomli.load(f)["project"]["scripts"]
+    assert set(scripts) == {"dynamont-resquiggle", "dynamont-train"}
+    for name, target in scripts.items():
+        module, func = target.split(":")
+        main = getattr(importlib.import_module(module), func)
+        assert callable(main)
+        with pytest.raises(SystemExit) as e:
+            main(["--help"])
+        assert e.value.code == 0
+        text = capsys.readouterr().out
+        assert "--raw" in text and "--basecalls" in text and "--pore" in text

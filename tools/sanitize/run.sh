@@ -4,16 +4,18 @@
 #   2. the CPU tests of the file readers, the formatter and the sink against those builds
 #      (DYN_LIB_PATH selects the library dynamont_amd/_native.py loads; the sanitizer runtime is preloaded into python)
 #   3. the byte-level fuzz of BGZF / BAM records / VBZ chunks / model TSV / CSV rows (fuzz_host.cpp), >= 1e5 mutations
-# Output: profiles/r05/sanitizers.txt (summary) + fuzz_asan_ubsan.txt / fuzz_tsan.txt. Exit code 0 = no report anywhere.
+# Output: $OUT/sanitizers.txt (default profiles/r06) (summary) + fuzz_asan_ubsan.txt / fuzz_tsan.txt. Exit code 0 = no report anywhere.
 set -u
 cd "$(dirname "$0")/../.."
-OUT=profiles/r05
+OUT=${OUT:-profiles/r06}
 mkdir -p "$OUT"
 N_ASAN=${N_ASAN:-40000}
 N_TSAN=${N_TSAN:-4000}
 TESTS="tests/test_bam_reader.py tests/test_pod5_native.py tests/test_format_pinning.py tests/test_harness.py tests/test_abi_host.py"
 fail=0
 make -s -C tools/sanitize -j"$(nproc)" all || exit 2
+# (no pipeline around the block: a `{ ...; } | tee` runs it in a subshell and `fail` would stay 0 out here)
+exec > >(tee "$OUT/sanitizers.txt") 2>&1
 {
   echo "# host-side sanitizer runs ($(date -u +%Y-%m-%dT%H:%MZ), $(g++ --version | head -1))"
   # The Python tests run on the ASan + UBSan build only: CPython under a preloaded TSan runtime deadlocks in its own start-up
@@ -40,5 +42,5 @@ make -s -C tools/sanitize -j"$(nproc)" all || exit 2
   echo "exit code $rc"
   [ "$rc" = 0 ] || fail=1
   echo "## result: $([ $fail = 0 ] && echo 'no sanitizer report, every run exit code 0' || echo 'FAILURES above')"
-} 2>&1 | tee "$OUT/sanitizers.txt"
+}
 exit $fail
