@@ -76,6 +76,7 @@ WORKLOADS = {
     "cfg3": ("cfg3", None, 2),
     "cfg4_share": ("cfg4", 4096, 4),
     "cfg5_share": ("cfg5", 1024, 8),
+    "short_reads": ("short_reads", None, 2),
 }
 
 
@@ -107,6 +108,10 @@ def parse():
     ap.add_argument("--no-plain", action="store_true", help="skip the `plain_arithmetic` record (the same workload with strict mode off)")
     ap.add_argument("--no-polya", action="store_true", help="skip the `cfg2_polya` record (N = 1: cfg2 with every read flagged)")
     ap.add_argument("--no-scale-ref", action="store_true", help="skip the `scale_ref` record (N = 1: configs[3]'s per-GPU share on one GPU)")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the `cfg3` record (N = 1: BASELINE configs[2], 4 096 DNA reads of 10 k-100 k samples)")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` record (N = 1: configs[4]'s per-GPU share, the Baum-Welch statistics pass)")
+    ap.add_argument("--no-short", action="store_true", help="skip the `short_reads` record (N = 1: 16 384 reads of 150-400 bases, narrower than the band)")
+    ap.add_argument("--no-cold", action="store_true", help="skip `e2e_cli.cold` (the CLI on the same dataset in a fresh child process, process start to exit)")
     ap.add_argument("--no-sessions", action="store_true", help="experiment: one launch per batch (no resident read queue)")
     ap.add_argument("--exchange-stall-ms", type=float, default=60.0,
                     help="N > 1: an exchange of the two untimed probe steps slower than this = RCCL's kernels are not served beside "
@@ -139,16 +144,19 @@ def load_traffic():
     return None
 
 
-def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -> dict:
+def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0, sub: str = "e2e", cold: bool = False) -> dict:
     """north_star's "throughput on synthetic pod5+bam": the dynamont-resquiggle counterpart end to end, in this process.
     A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
     dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
     Timed: model load, BAM parse, pod5 open + VBZ decode, pA calibration + normalisation + Hampel on the device, the
     DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool and the
-    batch buffers are the ones the bench's own handle has just parked (a fresh process allocates them: ~1 s on clean VRAM)."""
+    batch buffers are the ones the bench's own handle has just parked (a fresh process allocates them: ~1 s on clean VRAM).
+    `cold`: the SAME dataset once more in a FRESH CHILD PROCESS after this process has given all its device memory back
+    (dyn_release_cached_memory): `python -m dynamont_amd.segmentation.segment ...`, wall clock from process start to exit --
+    what a user who types the command waits for (interpreter, imports, library load, model parse, pool allocation included)."""
     from dynamont_amd import synth
     from dynamont_amd.segmentation import segment as seg
-    d = os.path.join(workdir, "e2e")
+    d = os.path.join(workdir, sub)
     os.makedirs(d, exist_ok=True)
     model = synth.write_model(os.path.join(d, "syn9.model"), 9, seed=7, stdev=0.15)
     _, mean, sd = synth.read_model_file(model)
@@ -161,9 +169,10 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -
     del reads
     t_gen = time.perf_counter() - t0
     out = os.path.join(d, "out.csv")
+    cli = ["-r", os.path.join(d, "in"), "-b", bam, "-o", out, "--mode", "basic", "-p", "rna004", "--model_path", model,
+           "--strict-ties", strict] + (["--batch-reads", str(batch_reads)] if batch_reads else [])
     t0 = time.perf_counter()
-    seg.main(["-r", os.path.join(d, "in"), "-b", bam, "-o", out, "--mode", "basic", "-p", "rna004", "--model_path", model,
-              "--strict-ties", strict] + (["--batch-reads", str(batch_reads)] if batch_reads else []))
+    seg.main(cli)
     dt = time.perf_counter() - t0
     err = out + ".errors" if os.path.exists(out + ".errors") else None
     rec = {"value": round(samples / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "reads": distinct * rep,
@@ -176,7 +185,25 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0) -
            "error_lines": sum(1 for _ in open(err)) if err else 0, "strict_mode": strict,
            "batch_reads": batch_reads or "CLI default",
            "timed": "segment.main: model load, BAM parse, pod5 VBZ decode, device preprocessing, DP, CSV format, zstd, write",
-           "not_timed": "interpreter start-up; allocation of the lattice pool and of the batch buffers (those the bench's own handle has just parked are taken over)"}
+           "not_timed": "interpreter start-up; allocation of the lattice pool and of the batch buffers (those the bench's own handle has just parked are taken over) -- `cold` times all of it"}
+    if cold:
+        import dynamont_amd
+        warm_bytes = os.path.getsize(out + ".zst") if os.path.exists(out + ".zst") else None
+        for f in (out + ".zst", out + ".errors"):
+            if os.path.exists(f):
+                os.remove(f)
+        dynamont_amd.release_cached_memory()   # the child starts on a device that holds nothing of ours
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "dynamont_amd.segmentation.segment"] + cli, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        dtc = time.perf_counter() - t0
+        same = warm_bytes is not None and os.path.exists(out + ".zst") and os.path.getsize(out + ".zst") == warm_bytes
+        rec["cold"] = {"value": round(samples / dtc / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dtc, 3), "returncode": r.returncode,
+                       "of_warm": round(dt / dtc, 3), "output_bytes_equal_warm": same,
+                       "timed": "a fresh child process, Popen to exit: interpreter start-up, imports, library load, model parse, allocation of the "
+                                "lattice pool and every buffer on a device this process has released, then everything `timed` above"}
+        if r.returncode != 0:
+            rec["cold"]["stderr_tail"] = r.stderr.decode(errors="replace")[-500:]
     return rec
 
 
@@ -204,7 +231,7 @@ class Workload:
     """the stream of distinct batches of one workload, in caller-owned host arrays (cached per name)"""
     _cache: dict = {}
 
-    def __init__(self, name: str, rank: int, args, model_cache: dict, workdir: str):
+    def __init__(self, name: str, rank: int, args, model_cache: dict, workdir: str, n_distinct: int = 0):
         from dynamont_amd import synth
         import numpy as np
         cfgname, per_batch, n_batches = WORKLOADS[name]
@@ -214,7 +241,7 @@ class Workload:
         if args.reads:
             cfg["n_reads"] = args.reads
         self.name, self.cfg = name, cfg
-        self.n_batches = max(1, args.batches or n_batches)
+        self.n_batches = max(1, n_distinct or args.batches or n_batches)
         self.pore = cfg["pore"]
         _, _rna, self.k = synth.PORES[self.pore]
         if self.k not in model_cache:
@@ -235,11 +262,15 @@ class Workload:
         self.samples_of = [int(b[1][-1]) for b in self.batches]
 
     @classmethod
-    def get(cls, name, rank, args, model_cache, workdir):
+    def get(cls, name, rank, args, model_cache, workdir, n_distinct=0):
         key = (name, rank)
         if key not in cls._cache:
-            cls._cache[key] = cls(name, rank, args, model_cache, workdir)
+            cls._cache[key] = cls(name, rank, args, model_cache, workdir, n_distinct)
         return cls._cache[key]
+
+    @classmethod
+    def drop(cls, name, rank):
+        cls._cache.pop((name, rank), None)   # (a side record's batches: gigabytes of host memory the next record wants)
 
 
 def measure(al, wl: Workload, args, steps: int, warmup: int, step0: int, mode: str, exch, sync):
@@ -376,7 +407,9 @@ def roofline_of(m: dict, workload: str, mode: str, args, profile: dict) -> dict:
         "cells_total": int(cells_total), "kernel_ms_total": round(kernel_ms_total, 3), "avg_launch_ms": round(ms_dp, 3),
         # share of wave time per phase (device cycle counters)
         "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
-                            "waiting_for_pages": round(kern["wave_wait_share"] / n_launch, 4)},
+                            # one launch per batch: the launches' own counters; resident queue: wave-cycles of paged sessions
+                            # spent getting pages / lifetime wave-cycles (dyn_aligner_session_page_wait)
+                            "waiting_for_pages": round(kern["wave_wait_share"] / n_launch + (sess.get("wave_cycles_pages", 0) / sess["wave_cycles_life"] if sess["wave_cycles_life"] else 0.0), 4)},
         "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(kernel_ms_total * share("ms_backward"), 3),
                                       "frac": round(cells_total * KBWD_BYTES_PER_CELL / (kernel_ms_total * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
                    "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(kernel_ms_total * share("ms_forward"), 3),
@@ -425,39 +458,6 @@ class Exchange:
         self.comm.close()
 
 
-class RehearsalExchange:
-    """DYN_BENCH_ONE_DEVICE=1 only (control-flow rehearsal of N ranks on a 1-GPU box, never a measurement): RCCL cannot put
-    two ranks on one device, so the exchange is stood in for by a torch.distributed gather / all-reduce of the ticket's HOST
-    results, padded to the largest batch. The line says so (`exchange.implementation`)."""
-
-    def __init__(self, dist, torch, rank, world, cap_rows_per_rank, num_kmers):
-        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
-        self.cap, self.num_kmers = max(1, cap_rows_per_rank), num_kmers
-        self.n_ranks = dist.get_world_size()
-        self.rows_gathered = 0
-        self.comm = self  # (.n_ranks)
-
-    def step(self, ticket, mode):
-        torch, dist = self.torch, self.dist
-        if mode == "train":
-            t = torch.zeros(3 * self.num_kmers, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return
-        res = ticket.result
-        n = int(res.seg_offsets[res.n]) if hasattr(res, "seg_offsets") else 0
-        buf = torch.zeros(1 + self.cap, dtype=torch.float64)
-        buf[0] = n
-        if n:
-            buf[1:1 + n] = torch.from_numpy(res.probabilities[:n].copy())
-        out = [torch.zeros_like(buf) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(buf, out, dst=0)
-        if self.rank == 0:
-            self.rows_gathered += int(sum(float(o[0]) for o in out))
-
-    def close(self):
-        pass
-
-
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -491,8 +491,15 @@ def main():
     #   DYN_BENCH_ONE_DEVICE=1   every rank uses cuda:0
     #   DYN_BENCH_FORCE_DIST=1   run the exchange even with a single rank (exercises dyn_comm_* on one GPU)
     backend = os.environ.get("DYN_BENCH_BACKEND", "nccl")
+    one_device = bool(os.environ.get("DYN_BENCH_ONE_DEVICE")) and n_gpus > 1
     if os.environ.get("DYN_BENCH_ONE_DEVICE"):
         local_rank = 0
+        if one_device:
+            # RCCL refuses two ranks of a communicator on one device; with a NCCL_HOSTID of its own every rank looks like a
+            # one-GPU node and RCCL connects them by sockets over loopback: the exchange below is then the REAL dyn_comm_* code
+            # (count all-gather, grouped ncclSend / ncclRecv, ncclAllReduce) on a transport that is not xGMI
+            from dynamont_amd import parallel
+            parallel.one_device_rccl_env(rank)
     elif torch.cuda.device_count() < n_gpus:
         raise SystemExit(f"bench.py: --gpus {n_gpus} but only {torch.cuda.device_count()} device(s) visible; refusing to measure fewer GPUs than asked for")
     torch.cuda.set_device(local_rank)
@@ -534,14 +541,16 @@ def main():
     if use_dist:
         # RCCL's kernels (37 KB of LDS, 248-256 registers) do not fit beside a resident session: a few CUs stay free for them
         reserved_cus = args.reserve_cus
+        if one_device:
+            # N ranks share the card: every rank's sessions take an N-th of the CUs the reserve leaves (a session is one
+            # workgroup per CU it uses and two sessions cannot share a CU: 150 KB of LDS each)
+            n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+            reserved_cus = n_cus - max(1, (n_cus - args.reserve_cus) // n_gpus)
         al.set_session_mode(not args.no_sessions, reserved_cus)
         cap_local = max(al.segment_capacity(b[3]) for b in wl.batches) if args.mode == "align" else 0
         t = torch.tensor([cap_local], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if os.environ.get("DYN_BENCH_ONE_DEVICE") and n_gpus > 1:
-            exch = RehearsalExchange(dist, torch, rank, n_gpus, int(t.item()), al.num_kmers)
-        else:
-            exch = Exchange(dist, torch, rank, n_gpus, local_rank, coll_dev, int(t.item()), al.num_kmers)
+        exch = Exchange(dist, torch, rank, n_gpus, local_rank, coll_dev, int(t.item()), al.num_kmers)
     elif args.no_sessions:
         al.set_session_mode(False)
 
@@ -593,21 +602,25 @@ def main():
                 best = tm0 if best is None or tm0["ms_total"] < best["ms_total"] else best
             resident = best
 
-    def side_record(al_, wl_, steps_, strict_, note):
+    def side_record(al_, wl_, steps_, strict_, note, mode_=None):
         """a secondary workload / mode on the same terms as the headline: own warm-up, own timed region, own roofline"""
+        mode_ = mode_ or args.mode
         al_.set_strict(strict_)
-        mm = measure(al_, wl_, args, steps_, 1, 0, args.mode, exch, sync)
+        mm = measure(al_, wl_, args, steps_, 1, 0, mode_, exch, sync)
         el, smp, rds = mm["elapsed"], mm["samples"], mm["reads"]
         if use_dist:
             t_ = torch.tensor([el, -float(smp)], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)   # slowest rank; (samples are equal per rank: weak scaling)
             el = float(t_[0].item())
             smp, rds = smp * n_gpus, rds * n_gpus
-        rf = roofline_of(mm, wl_.name, args.mode, args, profile)
-        return {"workload": wl_.name, "strict_mode": {"start": "ties"}.get(strict_, strict_), "steps": steps_, "value": round(smp / el / 1e6, 3), "unit": "Msamp/s",
+        rf = roofline_of(mm, wl_.name, mode_, args, profile)
+        return {"workload": wl_.name, "mode": mode_, "strict_mode": {"start": "ties"}.get(strict_, strict_), "steps": steps_, "value": round(smp / el / 1e6, 3), "unit": "Msamp/s",
                 "ms_per_step": round(el * 1e3 / steps_, 3), "reads_per_s": round(rds / el, 1),
+                "reads_per_batch": wl_.batches[0][4], "samples_per_batch": wl_.samples_of[0], "distinct_batches": wl_.n_batches,
                 "strict_reads_per_step": mm["launches"]["reads_strict"] / max(1, mm["steps_done"]),
-                "roofline_frac": rf["frac"], "wave_occupancy": rf["wave_occupancy"], "kernel_ms_total": rf["kernel_ms_total"],
+                "roofline_frac": rf["frac"], "bytes_per_cell": rf["bytes_per_cell"], "kernel": rf["kernel"].split(" (")[0],
+                "wave_occupancy": rf["wave_occupancy"], "waiting_for_pages": rf["wave_time_share"]["waiting_for_pages"],
+                "kernel_ms_total": rf["kernel_ms_total"], "cells_total": rf["cells_total"],
                 "launches": rf["launches"], "batches_per_launch": rf["batches_per_launch"], "batches_in_flight": mm["depth"], "note": note}
 
     # ---- what bit-exactness costs: the same steps on the plain arithmetic (strict mode off), outside the headline region
@@ -655,8 +668,9 @@ def main():
             line["rccl_ranks"] = exch.comm.n_ranks
             assert line["rccl_ranks"] == n_gpus, "the exchange must span every rank of the measurement"
             line["exchange"] = {
-                "implementation": "REHEARSAL on one device (DYN_BENCH_ONE_DEVICE): torch.distributed stand-in for the exchange, not a measurement"
-                                  if isinstance(exch, RehearsalExchange) else "dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp): " +
+                "implementation": ("ONE-DEVICE REHEARSAL (DYN_BENCH_ONE_DEVICE: every rank on cuda:0, a NCCL_HOSTID per rank, RCCL's socket "
+                                   "transport over loopback -- the exchange code is the real one, the transport is not xGMI: not a scaling "
+                                   "measurement) of " if one_device else "") + "dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp): " +
                                   ("dyn_comm_gather_counts + dyn_comm_gather_rows -- 8-byte count all-gather, then one ncclSend per peer / ncclRecv per peer "
                                    "on rank 0 in one group, from the batch's device rows; rank 0 copies the gathered rows to page-locked host memory"
                                    if args.mode == "align" else "dyn_comm_allreduce_pooled -- ncclAllReduce(sum, double) in place on the device-resident (w, s1, s2)[4^k]"),
@@ -666,7 +680,7 @@ def main():
                 "resident_queue": resident_with_exchange, "reserved_cus": reserved_cus if resident_with_exchange else 0, "observed": sessions_with_exchange,
                 "rccl_channel_cap": rccl_channel_cap and {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS")},
             }
-            line["collective_backend"] = "rehearsal" if isinstance(exch, RehearsalExchange) else "rccl (dyn_comm_*)"
+            line["collective_backend"] = "rccl (dyn_comm_*)" + (", one-device rehearsal over loopback sockets" if one_device else "")
             if args.mode == "align":
                 line["gather_lands_in"] = "rank0_pinned_host"
             line["per_rank_ms"] = [round(x, 2) for x in per_rank_ms]
@@ -692,16 +706,47 @@ def main():
             wl_s = Workload.get("cfg4_share", rank, args, model_cache, workdir)
             line["scale_ref"] = side_record(al, wl_s, max(4, min(8, args.steps)), args.strict,
                                             "configs[3]'s per-GPU share (4 096 reads per batch), the workload of every rank at N > 1, without the exchange")
-    al.close()  # (parks the lattice pool: the CLI's handle below takes it over instead of allocating its own)
+        if not args.no_short:
+            # reads narrower than the band (N < 400 columns: bw = N / 2): every row still occupies 448 lane slots, so the
+            # cells-based fraction shows what a narrow band costs
+            wl_n = Workload.get("short_reads", rank, args, model_cache, workdir)
+            line["short_reads"] = side_record(al, wl_n, max(4, min(8, args.steps)), args.strict,
+                                              "16 384 reads of 150-400 bases per batch: fewer lattice columns than the band is wide "
+                                              "(half band = N / 2, NT_aligner_api.cpp:243); roofline_frac counts IN-BAND cells only")
+            Workload.drop("short_reads", rank)
+        if not args.no_train:
+            # BASELINE configs[4]'s per-GPU share: the Baum-Welch statistics pass (log-domain backward sweep + posterior chain)
+            wl_t = Workload.get("cfg5_share", rank, args, model_cache, workdir, n_distinct=4)
+            line["train"] = side_record(al, wl_t, max(8, min(16, args.steps)), args.strict,
+                                        "configs[4]'s per-GPU share: train() on 1 024 rna004 reads x ~20 k per batch, one launch per batch; "
+                                        "16 algorithmic bytes per cell (write + read of one fp64 lattice row)", mode_="train")
+            Workload.drop("cfg5_share", rank)
+    al.close()  # (parks the lattice pool: the next handle takes it over instead of allocating its own)
     if exch is not None:
         exch.close()
+    if rank == 0 and n_gpus == 1 and not use_dist and args.mode == "align" and workload == "cfg2" and not args.reads and not args.no_cfg3:
+        # BASELINE configs[2]: another pore, hence another handle. 4 096 DNA reads of 10 k-100 k samples per batch do not get an
+        # arena each (1 024 arenas of the longest read: 550 GB): a PAGED session, posteriors in place (24.125 B per cell)
+        try:
+            Workload.drop("cfg2_polya", rank), Workload.drop("cfg4_share", rank)
+            wl_3 = Workload.get("cfg3", rank, args, model_cache, workdir, n_distinct=1)
+            al3 = Aligner(wl_3.model_path, wl_3.pore, mode="basic", band=400, device=local_rank)
+            line["cfg3"] = side_record(al3, wl_3, max(4, min(6, args.steps)), args.strict,
+                                       "BASELINE configs[2]: 4 096 dna_r10_400bps reads, 800-8 000 bases (10 k-100 k samples), page-starved: "
+                                       "a paged session, posteriors in place")
+            al3.close()
+            Workload.drop("cfg3", rank)
+        except Exception as e:  # the headline stands on its own
+            line["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
         try:
             strict = {"start": "ties"}.get(args.strict, args.strict)
-            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, strict, args.e2e_batch_reads)
+            big = None
             if args.e2e_large_reads > args.e2e_reads:
-                shutil.rmtree(os.path.join(workdir, "e2e"), ignore_errors=True)
-                big = run_e2e_cli(args.e2e_large_reads, workdir, strict, args.e2e_batch_reads)
+                big = run_e2e_cli(args.e2e_large_reads, workdir, strict, args.e2e_batch_reads, sub="e2e_large")
+                shutil.rmtree(os.path.join(workdir, "e2e_large"), ignore_errors=True)
+            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, strict, args.e2e_batch_reads, cold=not args.no_cold)
+            if big is not None:
                 line["e2e_cli"]["large"] = {k_: big[k_] for k_ in ("value", "unit", "wall_s", "reads", "reads_per_s", "samples", "input", "output", "error_lines")}
         except Exception as e:  # the headline stands on its own
             line.setdefault("e2e_cli", {})["error"] = f"{type(e).__name__}: {e}"

@@ -499,6 +499,9 @@ class Aligner:
             _raise(rc, self.last_error())
         d = {k: getattr(t, k) for k, _ in N.DynSessionStats._fields_}
         d["wave_occupancy"] = d["wave_cycles_busy"] / d["wave_cycles_life"] if d["wave_cycles_life"] else 0.0
+        pw = C.c_uint64(0)
+        self._L.dyn_aligner_session_page_wait(self._h, C.byref(pw))   # paged sessions: the part of `idle` spent getting pages
+        d["wave_cycles_pages"] = int(pw.value)
         return d
 
     def set_train_zcheck(self, on: bool) -> None:
@@ -789,6 +792,30 @@ class RcclComm:
         if rc != N.DYN_OK:
             _raise(rc, (self._L.dyn_comm_last_error(self._h) or b"").decode())
         return (rows[:total] if rows is not None else None), counts
+
+    def _check(self, rc):
+        if rc != N.DYN_OK:
+            _raise(rc, (self._L.dyn_comm_last_error(self._h) or b"").decode())
+
+    def gather_bytes(self, payload: bytes, root: int = 0):
+        """dyn_comm_gather_bytes: one bytes object per rank to ``root`` through the code path of ``gather_rows`` (count
+        all-gather, grouped ncclSend / ncclRecv). Returns the list of per-rank payloads on ``root``, None elsewhere."""
+        buf = np.frombuffer(payload, dtype=np.uint8) if payload else np.zeros(0, dtype=np.uint8)
+        counts = np.zeros(self.n_ranks, dtype=np.uint64)
+        self._check(self._L.dyn_comm_gather_bytes(self._h, buf.ctypes.data if buf.size else None, buf.size, int(root), _ptr(counts, N.c_u64_p)))
+        if self.rank != root:
+            return None
+        total = int(counts.sum())
+        out = np.empty(max(1, total), dtype=np.uint8)
+        self._check(self._L.dyn_comm_gathered_bytes(self._h, out.ctypes.data, total))
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return [out[offs[r]:offs[r + 1]].tobytes() for r in range(self.n_ranks)]
+
+    def allreduce(self, x: np.ndarray, op: str = "sum") -> np.ndarray:
+        """dyn_comm_allreduce_f64: elementwise sum / max over the ranks of a float64 vector (a copy is returned)."""
+        out = np.ascontiguousarray(x, dtype=np.float64).copy()
+        self._check(self._L.dyn_comm_allreduce_f64(self._h, _ptr(out, N.c_double_p), out.size, {"sum": 0, "max": 1}[op]))
+        return out
 
     def allreduce_pooled(self, batch, num_kmers: int) -> np.ndarray:
         out = np.empty(3 * int(num_kmers))

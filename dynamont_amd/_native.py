@@ -89,6 +89,7 @@ SIGNATURES = {
     "dyn_aligner_info": (C.c_int, [C.c_void_p, C.POINTER(DynInfo)]),
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_session_stats": (C.c_int, [C.c_void_p, C.POINTER(DynSessionStats)]),
+    "dyn_aligner_session_page_wait": (C.c_int, [C.c_void_p, c_u64_p]),
     "dyn_aligner_set_session_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
@@ -165,6 +166,9 @@ SIGNATURES = {
     "dyn_comm_gather_counts": (C.c_int, [C.c_void_p, C.c_void_p, c_u64_p]),
     "dyn_comm_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, c_u64_p]),
     "dyn_comm_allreduce_pooled": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
+    "dyn_comm_gather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, c_u64_p]),
+    "dyn_comm_gathered_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "dyn_comm_allreduce_f64": (C.c_int, [C.c_void_p, c_double_p, C.c_uint64, C.c_int]),
     "dyn_multi_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.c_int,
                                    C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]),
     "dyn_multi_destroy": (None, [C.c_void_p]),

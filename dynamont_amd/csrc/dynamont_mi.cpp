@@ -204,7 +204,20 @@ hipError_t ensure_pool_buffer(int device, int kind, DevBuf& b, size_t want, doub
       slot = ParkedBuf{};
     }
   }
-  return b.ensure(want, headroom);
+  hipError_t e = b.ensure(want, headroom);
+  if (e == hipErrorOutOfMemory && parking_enabled() && device >= 0 && device < PARK_DEVICES) {
+    // The planner counts parked bytes as available (they are): a parked buffer of ANOTHER kind -- the separate posterior plane
+    // of a predecessor whose successor keeps its posteriors in place -- may be what this allocation needs.
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_park_m);
+    for (int k = 0; k < PARK_KINDS; ++k)
+      if (g_park[device][k].p) {
+        (void)hipFree(g_park[device][k].p);
+        g_park[device][k] = ParkedBuf{};
+      }
+    e = b.ensure(want, headroom);
+  }
+  return e;
 }
 }  // namespace
 
@@ -1628,6 +1641,7 @@ int session_collect(dyn_aligner* a, int blk) {
   t.wave_cycles_busy += st[0];
   t.wave_cycles_idle += st[1];
   t.wave_cycles_life += st[2];
+  a->sess_page_wait_cycles += st[5];
   t.waves += ss.pend_waves[blk];
   if (cw[dynk::S_ABORT]) t.aborted += 1;
   ss.pending[blk] = false;
@@ -2101,6 +2115,17 @@ extern "C" int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out)
     if (int rc = session_quiesce(a)) return rc;
   }
   *out = a->sess_total;
+  return DYN_OK;
+}
+
+extern "C" int dyn_aligner_session_page_wait(dyn_aligner* a, uint64_t* wave_cycles_waiting_for_pages) {
+  if (!a || !wave_cycles_waiting_for_pages) return DYN_ERR_INVALID_ARGUMENT;
+  if (!a->host_only && a->s_session) {
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (int rc = need_device(a)) return rc;
+    if (int rc = session_quiesce(a)) return rc;
+  }
+  *wave_cycles_waiting_for_pages = a->sess_page_wait_cycles;
   return DYN_OK;
 }
 

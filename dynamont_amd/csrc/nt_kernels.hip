@@ -1587,7 +1587,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
 
   uint32_t* ctl = sa.ctl;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
-  uint64_t cyc_busy = 0, cyc_idle = 0, n_done = 0;
+  uint64_t cyc_busy = 0, cyc_idle = 0, cyc_pages = 0, n_done = 0;
   uint32_t cur = 0, tail_seen = 0;   // the ticket this wave looks at; tickets it knows to be published
   bool have = false;
   SessionTicket tk{};
@@ -1645,9 +1645,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const ReadDesc rd = descs[g - tk.base];
     if (PAGED) {
       if (held < rd.n_pages) {
+        const uint64_t tp = __builtin_amdgcn_s_memtime();
         if (held) pages_give(sa.pool, w, 0, held);
         held = 0;
-        if (!pages_take(sa.pool, w, rd.n_pages, slot + 1u)) {
+        const bool got = pages_take(sa.pool, w, rd.n_pages, slot + 1u);
+        cyc_pages += __builtin_amdgcn_s_memtime() - tp;   // (part of cyc_idle; apart: what the page pool costs)
+        if (!got) {
           // waited for pages for seconds: the session is over; what is incomplete is published again (session_recover)
           if (w.lane == 0) ctl_store(&ctl[S_ABORT], 3u);
           break;
@@ -1708,6 +1711,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     atomicAdd(&stats[2], life);
     atomicMax(&stats[3], life);
     atomicAdd(&stats[4], (unsigned long long)n_done);
+    if (PAGED) atomicAdd(&stats[5], (unsigned long long)cyc_pages);
   }
 }
 

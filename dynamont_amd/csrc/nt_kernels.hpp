@@ -158,7 +158,8 @@ static_assert(sizeof(SessionTicket) == 128, "one cache line pair per record");
 constexpr int SESSION_TSTATS = 2;        // first statistics word of a ticket's control block (as uint32 index, 8-byte aligned)
 constexpr int SESSION_TCTL_WORDS = 32;
 // session control words (device memory, 32-bit): next global read index, tickets published, closed, abort; 64-bit statistics
-// from word SESSION_STATS on: wave-cycles busy (claim to release), idle, lifetime, longest lifetime, reads done
+// from word SESSION_STATS on: wave-cycles busy (claim to release), idle, lifetime, longest lifetime, reads done, [5] the part
+// of idle spent getting pages (paged sessions)
 constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS = 8, SESSION_CTL_WORDS = 32;
 
 struct SessionArgs {

@@ -101,6 +101,9 @@ struct dyn_comm {
   std::vector<void*> retired;    // receive buffers that were outgrown: freed with the communicator (hipFree waits for the whole
                                  // device, i.e. for the END of a resident read queue -- never in the middle of a run). Growth
                                  // is x1.5, so what is retired adds up to at most TWICE the live buffer
+  void* d_stage = nullptr;       // dyn_comm_gather_bytes / dyn_comm_allreduce_f64: the caller's HOST payload on the device
+  size_t stage_bytes = 0;
+  uint64_t gathered_bytes = 0;   // root: what the last dyn_comm_gather_bytes left in d_recv
   std::string last_error;
   // rows every rank announced in the last dyn_comm_gather_counts (the exchange dyn_comm_gather_rows then performs)
   std::vector<uint64_t> counts;
@@ -222,6 +225,7 @@ void dyn_comm_destroy(dyn_comm* c) {
   if (c->comm && !c->aborted) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->d_stage) (void)hipFree(c->d_stage);
   for (void* p : c->retired) (void)hipFree(p);
   // (a CU-masked stream is parked for the next communicator or handle of the process: destroying a second one in a process
   // did not return on ROCm 7.2, dynamont_mi.cpp)
@@ -310,6 +314,59 @@ static int local_rows(dyn_comm* c, dyn_batch* b, void** d_rows, uint64_t* n_rows
   return rc;
 }
 
+// ---- the variable-length gather both front ends share (segment rows of a batch; a rank's bytes) -----------------------
+// counts: every rank's number of UNITS (8-byte all-gather over n_ranks entries) -> c->counts
+static int exchange_counts(dyn_comm* c, uint64_t mine) {
+  C_TRY_X(c, hipSetDevice(c->device));
+  C_TRY_X(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+  N_TRY_X(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
+  c->counts.assign((size_t)c->n_ranks, 0);
+  // (the copies out come AFTER the bounded wait: a copy into pageable memory blocks its caller until the stream gets there,
+  // i.e. for as long as the collective in front of it waits for a peer)
+  if (int rc = wait_exchange(c, "the all-gather of counts")) return rc;
+  C_TRY_X(c, hipMemcpyAsync(c->counts.data(), c->d_counts, sizeof(uint64_t) * c->counts.size(), hipMemcpyDeviceToHost, c->stream));
+  C_TRY_X(c, hipStreamSynchronize(c->stream));
+  return DYN_OK;
+}
+
+// payload: c->counts[r] units of `unit` bytes from every rank r -> root's d_recv, back to back in rank order. One ncclSend per
+// non-root rank, one ncclRecv per peer on the root, in one group: each peer's payload crosses its own link to the root once.
+static int exchange_payload(dyn_comm* c, const void* d_send, size_t unit, int root, const char* what) {
+  const std::vector<uint64_t>& counts = c->counts;
+  C_TRY_X(c, hipSetDevice(c->device));
+  uint64_t total = 0;
+  for (uint64_t n : counts) total += n;
+  if (c->rank == root && c->recv_bytes < total * unit) {
+    if (c->d_recv) c->retired.push_back(c->d_recv);  // (growth x1.5: the retired buffers add up to at most twice the live one)
+    c->d_recv = nullptr;
+    c->recv_bytes = 0;
+    const size_t want = std::max<size_t>(total * unit + total * unit / 2, 16);
+    C_TRY_X(c, hipMalloc(&c->d_recv, want));
+    c->recv_bytes = want;
+  }
+  if (total == 0) return DYN_OK;  // (every rank knows: nobody posts anything)
+  const uint64_t mine = counts[(size_t)c->rank];
+  C_TRACE(c, "%s: ncclGroupEnd ...", what);
+  N_TRY_X(c, g_rccl.GroupStart());
+  if (c->rank == root) {
+    uint64_t off = 0;
+    for (int r = 0; r < c->n_ranks; ++r) {
+      char* dst = static_cast<char*>(c->d_recv) + off * unit;
+      if (r == root) {
+        if (counts[(size_t)r]) C_TRY_X(c, hipMemcpyAsync(dst, d_send, counts[(size_t)r] * unit, hipMemcpyDeviceToDevice, c->stream));
+      } else if (counts[(size_t)r]) {
+        N_TRY_X(c, g_rccl.Recv(dst, counts[(size_t)r] * unit, ncclUint8, r, c->comm, c->stream));
+      }
+      off += counts[(size_t)r];
+    }
+  } else if (mine) {
+    N_TRY_X(c, g_rccl.Send(d_send, mine * unit, ncclUint8, root, c->comm, c->stream));
+  }
+  N_TRY_X(c, g_rccl.GroupEnd());
+  C_TRACE(c, "%s: group enqueued, waiting", what);
+  return wait_exchange(c, what);
+}
+
 int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out) {
   if (!c || !b) return DYN_ERR_INVALID_ARGUMENT;
   if (c->aborted) {
@@ -319,15 +376,7 @@ int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out) {
   void* d_rows = nullptr;
   uint64_t mine = 0;
   const int local_rc = local_rows(c, b, &d_rows, &mine);  // a failed batch announces 0 rows: the peers must not hang
-  C_TRY_X(c, hipSetDevice(c->device));
-  C_TRY_X(c, hipMemcpyAsync(c->d_counts + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-  N_TRY_X(c, g_rccl.AllGather(c->d_counts + c->rank, c->d_counts, sizeof(uint64_t), ncclUint8, c->comm, c->stream));
-  c->counts.assign((size_t)c->n_ranks, 0);
-  // (the copies out come AFTER the bounded wait: a copy into pageable memory blocks its caller until the stream gets there,
-  // i.e. for as long as the collective in front of it waits for a peer)
-  if (int rc = wait_exchange(c, "the all-gather of row counts")) return rc;
-  C_TRY_X(c, hipMemcpyAsync(c->counts.data(), c->d_counts, sizeof(uint64_t) * c->counts.size(), hipMemcpyDeviceToHost, c->stream));
-  C_TRY_X(c, hipStreamSynchronize(c->stream));
+  if (int rc = exchange_counts(c, mine)) return rc;
   c->counts_valid = true;
   if (counts_out) std::memcpy(counts_out, c->counts.data(), sizeof(uint64_t) * c->counts.size());
   return local_rc;
@@ -351,39 +400,12 @@ int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* r
   void* d_rows = nullptr;
   uint64_t mine = 0;
   if (counts[(size_t)c->rank]) (void)local_rows(c, b, &d_rows, &mine);  // (complete already: no waiting here)
-  C_TRY_X(c, hipSetDevice(c->device));
   uint64_t total = 0;
   for (uint64_t n : counts) total += n;
   constexpr size_t ROW = sizeof(dyn_segment_row);
   const bool too_small = c->rank == root && rows_out && rows_cap < total;
-  if (c->rank == root && c->recv_bytes < total * ROW) {
-    if (c->d_recv) c->retired.push_back(c->d_recv);  // (growth x1.5: the retired buffers add up to at most twice the live one)
-    c->d_recv = nullptr;
-    c->recv_bytes = 0;
-    const size_t want = std::max<size_t>(total * ROW + total * ROW / 2, ROW);
-    C_TRY_X(c, hipMalloc(&c->d_recv, want));
-    c->recv_bytes = want;
-  }
-  // the rows: each peer's link to the root carries its rows once
-  N_TRY_X(c, g_rccl.GroupStart());
-  if (c->rank == root) {
-    uint64_t off = 0;
-    for (int r = 0; r < c->n_ranks; ++r) {
-      char* dst = static_cast<char*>(c->d_recv) + off * ROW;
-      if (r == root) {
-        if (counts[(size_t)r]) C_TRY_X(c, hipMemcpyAsync(dst, d_rows, counts[(size_t)r] * ROW, hipMemcpyDeviceToDevice, c->stream));
-      } else if (counts[(size_t)r]) {
-        N_TRY_X(c, g_rccl.Recv(dst, counts[(size_t)r] * ROW, ncclUint8, r, c->comm, c->stream));
-      }
-      off += counts[(size_t)r];
-    }
-  } else if (mine) {
-    N_TRY_X(c, g_rccl.Send(d_rows, mine * ROW, ncclUint8, root, c->comm, c->stream));
-  }
-  C_TRACE(c, "gather_rows: ncclGroupEnd ...");
-  N_TRY_X(c, g_rccl.GroupEnd());
-  C_TRACE(c, "gather_rows: group enqueued, waiting");
-  if (int rc = wait_exchange(c, "the gather of segment rows")) return rc;  // the batch's buffers may be released after this call
+  // the batch's buffers may be released after this call
+  if (int rc = exchange_payload(c, d_rows, ROW, root, "the gather of segment rows")) return rc;
   if (c->rank == root && rows_out && !too_small && total) {
     C_TRY_X(c, hipMemcpyAsync(rows_out, c->d_recv, total * ROW, hipMemcpyDeviceToHost, c->stream));
     C_TRY_X(c, hipStreamSynchronize(c->stream));
@@ -393,6 +415,74 @@ int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* r
     return DYN_ERR_INVALID_ARGUMENT;
   }
   return local_rc;
+}
+
+// the caller's host payload on the device (grow-only; hipFree waits for the whole device: never in the middle of a run)
+static int stage_payload(dyn_comm* c, const void* host, uint64_t n_bytes) {
+  C_TRY(c, hipSetDevice(c->device));
+  if (c->stage_bytes < n_bytes) {
+    if (c->d_stage) c->retired.push_back(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    const size_t want = std::max<size_t>(n_bytes + n_bytes / 2, 4096);
+    C_TRY(c, hipMalloc(&c->d_stage, want));
+    c->stage_bytes = want;
+  }
+  if (n_bytes) {
+    C_TRY(c, hipMemcpyAsync(c->d_stage, host, n_bytes, hipMemcpyHostToDevice, c->stream));
+    C_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return DYN_OK;
+}
+
+int dyn_comm_gather_bytes(dyn_comm* c, const void* bytes, uint64_t n_bytes, int root, uint64_t* counts_out) {
+  if (!c || root < 0 || root >= c->n_ranks || (n_bytes && !bytes)) return DYN_ERR_INVALID_ARGUMENT;
+  if (c->aborted) {
+    c->last_error = "the communicator was aborted by an earlier failure";
+    return DYN_ERR_DEVICE;
+  }
+  c->counts_valid = false;
+  c->gathered_bytes = 0;
+  // a rank that cannot stage its payload still takes part (with 0 bytes), then reports: its peers never block on it
+  const int local_rc = stage_payload(c, bytes, n_bytes);
+  if (int rc = exchange_counts(c, local_rc == DYN_OK ? n_bytes : 0)) return rc;
+  if (counts_out) std::memcpy(counts_out, c->counts.data(), sizeof(uint64_t) * c->counts.size());
+  if (int rc = exchange_payload(c, c->d_stage, 1, root, "the gather of bytes")) return rc;
+  if (c->rank == root)
+    for (uint64_t n : c->counts) c->gathered_bytes += n;
+  return local_rc;
+}
+
+int dyn_comm_gathered_bytes(dyn_comm* c, void* out, uint64_t out_cap) {
+  if (!c || (!out && c->gathered_bytes)) return DYN_ERR_INVALID_ARGUMENT;
+  if (out_cap < c->gathered_bytes) {
+    c->last_error = "dyn_comm_gathered_bytes: out_cap is smaller than the sum of the counts of the last dyn_comm_gather_bytes";
+    return DYN_ERR_INVALID_ARGUMENT;
+  }
+  if (c->gathered_bytes) {
+    C_TRY(c, hipSetDevice(c->device));
+    C_TRY(c, hipMemcpyAsync(out, c->d_recv, c->gathered_bytes, hipMemcpyDeviceToHost, c->stream));
+    C_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return DYN_OK;
+}
+
+int dyn_comm_allreduce_f64(dyn_comm* c, double* inout, uint64_t n, int op) {
+  if (!c || (n && !inout) || op < 0 || op > 1) return DYN_ERR_INVALID_ARGUMENT;
+  if (c->aborted) {
+    c->last_error = "the communicator was aborted by an earlier failure";
+    return DYN_ERR_DEVICE;
+  }
+  if (!n) return DYN_OK;
+  if (int rc = stage_payload(c, inout, n * sizeof(double))) {
+    abort_comm(c);  // the peers are (or will be) inside ncclAllReduce: fail them fast
+    return rc;
+  }
+  N_TRY_X(c, g_rccl.AllReduce(c->d_stage, c->d_stage, n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+  if (int rc = wait_exchange(c, "the all-reduce")) return rc;
+  C_TRY_X(c, hipMemcpyAsync(inout, c->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  C_TRY_X(c, hipStreamSynchronize(c->stream));
+  return DYN_OK;
 }
 
 int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n) {

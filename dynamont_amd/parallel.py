@@ -1,11 +1,18 @@
 """Multi-GPU plumbing: reads are independent, so a job shards them across one
-process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
-There is no data-path collective. The only exchanges are
+process per GPU, started by ``torch.distributed.run``. There is no data-path collective. The only exchanges are
 
-  * gather_rows      per-read segment rows -> rank 0 (BASELINE.json config 4),
-  * allreduce_sum    pooled sufficient statistics (w, s1, s2)[numKmers] (config 5).
+  * gather_bytes     a rank's rows (its part of the compressed output frame, its ``.errors`` lines) -> rank 0
+                     (BASELINE.json config 4),
+  * allreduce_sum    pooled sufficient statistics (w, s1, s2)[numKmers] and the per-batch sums (config 5).
 
-This module never touches the DP itself; tensors are plain byte/float64 buffers.
+ONE exchange stack: on GPUs the payloads travel through the library's own RCCL path, ``dyn_comm_*``
+(dynamont_amd/csrc/rccl_comm.cpp: count all-gather + grouped ncclSend / ncclRecv, ncclAllReduce) -- what
+``bench.py --gpus N`` times and ``tests/test_gpu_comm_ranks.py`` exercises at 2 and 4 ranks. ``torch.distributed``
+only starts the ranks, hands the 128-byte communicator id round, broadcasts a few control strings and holds the final
+barrier. CPU rehearsals (backend "gloo", no GPU: ``tests/test_parallel_gloo.py``) carry the payloads over torch instead
+(``DYN_DIST_EXCHANGE=torch``); ``Comm.implementation`` says which one a job used.
+
+This module never touches the DP itself; payloads are plain byte / float64 buffers.
 """
 from __future__ import annotations
 
@@ -35,7 +42,7 @@ def shard_by_cost(costs, world: int) -> list[list[int]]:
 class Comm:
     """Thin wrapper so callers do not depend on torch when running single-process."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, xchg=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -43,12 +50,27 @@ class Comm:
         self.rank = dist.get_rank() if self.active else 0
         self.world = dist.get_world_size() if self.active else 1
         self.device = device if device is not None else "cpu"
+        # dynamont_amd._dynamont.RcclComm over all ranks (dyn_comm_*): carries every payload when present
+        self.xchg = xchg
+
+    @property
+    def implementation(self) -> str:
+        if self.xchg is not None:
+            return "dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp): dyn_comm_gather_bytes / dyn_comm_allreduce_f64 over RCCL"
+        return "torch.distributed (%s): CPU rehearsal of the exchange" % (self.dist.get_backend() if self.active else "single process")
+
+    def close(self):
+        if self.xchg is not None:
+            self.xchg.close()
+            self.xchg = None
 
     def allreduce_sum(self, x: np.ndarray) -> np.ndarray:
         """Sum of a float64 vector over ranks (sufficient statistics are linear-domain sums, so a
         plain sum all-reduce is exact up to fp64 association)."""
         if not self.active:
             return x
+        if self.xchg is not None:
+            return self.xchg.allreduce(x, "sum")
         t = self.torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
@@ -96,18 +118,51 @@ def init_from_env():
     import torch
     import torch.distributed as dist
     backend = os.environ.get("DYN_DIST_BACKEND", "nccl")
-    local_rank = 0 if os.environ.get("DYN_DIST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = bool(os.environ.get("DYN_DIST_ONE_DEVICE"))
+    local_rank = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    exchange = os.environ.get("DYN_DIST_EXCHANGE", "dyn_comm" if backend == "nccl" else "torch")
+    if one_device and exchange == "dyn_comm":
+        one_device_rccl_env(int(os.environ.get("RANK", "0")))
     if not dist.is_initialized():
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    return Comm(device=f"cuda:{local_rank}" if backend == "nccl" else "cpu"), local_rank
+    comm = Comm(device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+    if exchange == "dyn_comm":
+        from dynamont_amd._dynamont import RcclComm
+        uid = broadcast_bytes(comm, RcclComm.unique_id() if comm.rank == 0 else b"", 128)
+        comm.xchg = RcclComm(uid, comm.rank, comm.world, local_rank)
+    return comm, local_rank
+
+
+def one_device_rccl_env(rank: int) -> None:
+    """Rehearsals with every rank on ONE device (a 1-GPU box): RCCL refuses two ranks of a communicator on the same device
+    ("Duplicate GPU detected": same host hash, same bus id), so every rank gets its own NCCL_HOSTID -- the ranks then look
+    like one-GPU nodes and RCCL connects them by its socket transport over loopback. Everything above the transport is the
+    real thing. Must run before the process' first RCCL call."""
+    import os
+    os.environ.setdefault("NCCL_HOSTID", "dyn-one-device-rank-%d" % rank)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("NCCL_NET", "Socket")
+
+
+def broadcast_bytes(comm: "Comm", data: bytes, n: int, src: int = 0) -> bytes:
+    """``n`` bytes of rank ``src`` on every rank (control plane: torch.distributed) -- the communicator id."""
+    import torch
+    buf = torch.zeros(n, dtype=torch.uint8, device=comm.device)
+    if comm.rank == src:
+        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    comm.dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().numpy().tobytes())
 
 
 def gather_bytes(comm: "Comm", payload: bytes, dst: int = 0):
     """Variable-length gather of one bytes object per rank (CSV rows, error lines) to ``dst``."""
+    if comm.xchg is not None:
+        return comm.xchg.gather_bytes(payload, root=dst)
     import torch
     t = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else torch.zeros(0, dtype=torch.uint8)
     parts = comm.gather_rows(t.to(comm.device), dst=dst)
@@ -118,6 +173,8 @@ def gather_bytes(comm: "Comm", payload: bytes, dst: int = 0):
 
 def any_rank(comm: "Comm", flag: bool) -> bool:
     """Logical OR of a flag over ranks."""
+    if comm.xchg is not None:
+        return bool(comm.xchg.allreduce(np.array([1.0 if flag else 0.0]), "max")[0] > 0.5)
     import torch
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=comm.device)
     comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
@@ -169,6 +226,9 @@ def abort(comm: "Comm | None", exc: BaseException, grace_s: float = 5.0) -> None
     print(f"rank {comm.rank if comm else 0}: aborting the job", file=sys.stderr, flush=True)
     threading.Timer(grace_s, lambda: os._exit(1)).start()
     remove_scratch()
+    # (the dyn_comm communicator is NOT destroyed here -- ncclCommDestroy is collective; this process leaves through
+    # os._exit, its peers' exchanges then fail by RCCL's asynchronous error or at DYN_COMM_TIMEOUT_S, and under
+    # torch.distributed.run the agent kills them as soon as this rank has exited non-zero)
     try:
         if comm is not None and comm.dist.is_initialized():
             comm.dist.destroy_process_group()

@@ -26,6 +26,21 @@ from dynamont_amd.pod5_io import VbzSlice, get_signal, get_signal_adc, get_signa
 from dynamont_amd.segmentation.utils import get_model, hampel, segmentation_to_string
 from dynamont_amd.zstd_io import open_writer
 
+
+def _stamp(name: str) -> None:
+    """DYN_CLI_TRACE=1: a timeline of the run on stderr, seconds since the process was started (DYN_CLI_T0 = the parent's
+    time.time() at Popen, else since this module was imported) -- where a cold start goes (tools/cold_start_trace.py)"""
+    import os
+    import time
+    if os.environ.get("DYN_CLI_TRACE"):
+        t0 = float(os.environ.get("DYN_CLI_T0") or _IMPORTED_AT)
+        print("[cli %8.3f s] %s" % (time.time() - t0, name), file=sys.stderr, flush=True)
+
+
+import time as _time  # noqa: E402
+
+_IMPORTED_AT = _time.time()
+
 CSV_HEADER = b"readid,signalid,start,end,basepos,base,motif,state,posterior_probability,polish\n"
 POLYA = "AAAAAAAAA"
 
@@ -683,6 +698,9 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
     rank, world = (comm.rank, comm.world) if comm else (0, 1)
     if comm:
         device = local_rank
+        if rank == 0:
+            print(f"exchange: {comm.implementation}", file=sys.stderr, flush=True)
+        LAST_RUN["exchange"] = comm.implementation
     # Every process owns a native sink (csv_sink.cpp). One process: it writes the output file. One process per GPU: every
     # rank formats AND compresses its own rows into a part of the frame (compression is the largest host cost of the
     # output: 11 core-seconds per 32 768 reads -- left to rank 0 it would cap the job at one GPU's speed); at the end the
@@ -714,7 +732,9 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
     with parallel.abort_on_error(comm):
         pipe = None
         try:
+            _stamp("segment(): creating the aligner")
             aligner = Aligner(model_path, pore, mode=mode, threads=1, band=400, device=device)
+            _stamp("aligner ready (model parsed, device initialised, tables uploaded)")
             if mem_budget_gib:
                 aligner.set_mem_budget(int(mem_budget_gib * (1 << 30)))
             aligner.set_strict(strict_ties)
@@ -736,6 +756,7 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 threads = host_threads or max(2, min(16, available_cpus() // local_world - (4 if local_world == 1 else 2)))
                 pipe = sink = _NativePipeline(aligner, part, raw=not host_preprocess, depth=depth, threads=threads,
                                               first=rank == 0, last=world == 1, errfile=part_err, level=zstd_level)
+                _stamp("sink open")
                 if not host_preprocess and _native_bam(basecalls):
                     # BAM basecalls: the jobs arrive as columns (this rank's share of them); raw files that can point at their
                     # compressed chunks (.pod5, VBZ) are served without a Python object per read, any other reader read by read
@@ -743,6 +764,8 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                         prepared = prepare_job_columns(jb, data_path, sink.put)
                         if prepared is not None:
                             pipe.submit_columns(*prepared)
+                            if pipe.submitted <= 2:
+                                _stamp("batch %d submitted" % (pipe.submitted - 1))
                             continue
                         pending = []
                         for i, job in enumerate(jobs_from_columns(jb, data_path)):
@@ -771,8 +794,10 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                             pending = []
                     if pending:
                         pipe.submit(pending)
+                _stamp("every batch submitted")
                 pipe.close()
                 pipe = None
+                _stamp("pipeline closed: output complete")
                 if comm is not None:
                     _gather_parts(comm, parallel, outfile, part, part_err)
                 parallel.remove_scratch()
@@ -828,11 +853,14 @@ def segment(data_path: str, basecalls: str, processes: int, outfile: str, model_
                 q.put("kill")
                 writer.join()
             close_raw_cache()
+    if comm is not None:
+        comm.close()  # (collective: every rank has finished its exchanges)
     if comm is not None and comm.dist.is_initialized():
         comm.dist.barrier()  # normal completion only
 
 
 def main(argv=None) -> None:
+    _stamp("main() entered (interpreter started, modules imported)")
     args = parse(argv)
     outfile = args.outfile
     if isdir(outfile):

@@ -328,11 +328,15 @@ def main(argv=None) -> None:
         model_path = get_model(args.pore)
         assert exists(model_path), f"Default model not found for pore: {args.pore}, {model_path}"
     print(f"Loaded model: {basename(model_path)}", file=sys.stderr)
+    if comm is not None and comm.rank == 0:
+        print(f"exchange: {comm.implementation}", file=sys.stderr, flush=True)
     # a failing rank ends the whole job instead of leaving the others in their next all-reduce (parallel.abort)
     with parallel.abort_on_error(comm):
         train(args.raw, args.basecalls, args.batch_size, args.epochs, param_file, "basic", model_path, args.max_batches,
               args.pore, args.qscore, device=local_rank if comm else args.device, aggregate=args.aggregate, comm=comm,
               host_preprocess=args.host_preprocess, reference_zcheck=args.reference_zcheck)
+        if comm is not None:
+            comm.close()  # (collective: every rank has finished its exchanges)
 
 
 if __name__ == "__main__":

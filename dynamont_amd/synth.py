@@ -165,6 +165,9 @@ CONFIGS = {
     # not a BASELINE config: cfg2 with reads that start with a polyA tail of 20-150 bases, as real direct-RNA reads do --
     # every read carries a structural tie (bench.py --workload cfg2_polya: what bit-exact borders cost on such data)
     "cfg2_polya": dict(pore="rna004", n_reads=1024, n_bases=2000, seed=2, polya=(20, 150)),
+    # not a BASELINE config: reads SHORTER than the band is wide (N < 400 lattice columns: bw = N / 2 < 200,
+    # NT_aligner_api.cpp:243) -- the narrow-band case, whose cells cost a lane slot each whether they are in the band or not
+    "short_reads": dict(pore="rna004", n_reads=16384, n_bases=(150, 400), seed=6),
 }
 
 

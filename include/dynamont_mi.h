@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 6 /* 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
+#define DYN_ABI_VERSION 7 /* 7: dyn_aligner_session_page_wait, dyn_comm_gather_bytes / _gathered_bytes / _allreduce_f64 (additive). 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -241,6 +241,11 @@ int dyn_aligner_info(const dyn_aligner* a, dyn_info* info);
 /* Totals over the handle's CLOSED sessions (dyn_session_stats above). Closes an open session first and waits until its
  * waves have left -- call it when the tickets of interest have been waited for. */
 int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out);
+/* (ABI 7, additive) The part of dyn_session_stats.wave_cycles_idle that waves of PAGED sessions (page-starved batches: reads of
+ * 100 k samples, BASELINE configs[2]) spent getting their lattice pages from the shared pool -- giving back what they held,
+ * waiting for the free list to hold their request, taking it. Same units and the same closing behaviour as above. No
+ * counterpart in the reference (it allocates eight T x B matrices per read, NT_aligner_api.cpp:249-262). */
+int dyn_aligner_session_page_wait(dyn_aligner* a, uint64_t* wave_cycles_waiting_for_pages);
 /* enabled = 0: no resident read queue on this handle (one launch per batch, as DYN_NO_SESSION=1 does for a process).
  * enabled = 1: sessions of n_cus - reserved_cus workgroups, one per compute unit. A resident session leaves 9.5 KB of LDS and 152
  * registers per lane free on every CU it occupies: the library's own small kernels run beside it. A kernel whose workgroups need
@@ -622,14 +627,30 @@ const char* dyn_comm_last_error(const dyn_comm* c);
  * the count exchange itself; a root that cannot know the total in advance calls dyn_comm_gather_counts first and
  * allocates sum(counts). rows_cap < total on root: the exchange completes on every rank (nothing hangs), the rows are
  * dropped and root gets DYN_ERR_INVALID_ARGUMENT.
- * A HIP / RCCL failure in the middle of an exchange aborts the communicator (ncclCommAbort): the peers' pending
- * operations fail instead of blocking, every later call on the handle returns DYN_ERR_DEVICE. */
+ * A HIP / RCCL failure in the middle of an exchange aborts the communicator (ncclCommAbort), and so does an exchange that is
+ * not complete after DYN_COMM_TIMEOUT_S seconds (default 300; a peer that died or never arrived -- RCCL's kernels wait for
+ * their peers on the device, so the wait is a polled one): the call fails with DYN_ERR_DEVICE, every later call on the
+ * handle returns DYN_ERR_DEVICE at once. */
 int dyn_comm_gather_counts(dyn_comm* c, dyn_batch* b, uint64_t* counts_out);
 int dyn_comm_gather_rows(dyn_comm* c, dyn_batch* b, int root, dyn_segment_row* rows_out, uint64_t rows_cap,
                          uint64_t* counts_out);
 /* Collective. `b` = a trained batch or a ticket of dyn_batch_train[_raw]_async. Sum over ranks of the device-resident
  * pooled statistics (dyn_batch_device_pooled; reduced in place), copied to pooled3n (3 * num_kmers doubles, may be NULL). */
 int dyn_comm_allreduce_pooled(dyn_comm* c, dyn_batch* b, double* pooled3n);
+/* (ABI 7, additive) The same exchange for payloads that live in HOST memory -- what the multi-rank CLIs move: a rank's part
+ * of the compressed output frame and its `.errors` lines to rank 0 (the reference's listener collects every worker's rows,
+ * src/dynamont/segmentation/segment.py:296-325,69-107), the training loop's per-batch sums (train.py:195-220 over all ranks).
+ * dyn_comm_gather_bytes: collective. n_bytes of `bytes` from every rank to `root` through the code path of
+ * dyn_comm_gather_rows (8-byte count all-gather, then one ncclSend per peer / ncclRecv per peer on the root in one group;
+ * the payload is staged on the device first). counts_out[r] (n_ranks entries, may be NULL) = rank r's n_bytes, on every rank.
+ * On root the gathered bytes stay in the communicator's device buffer until the next gather:
+ * dyn_comm_gathered_bytes copies them out, back to back in rank order (out_cap >= sum of the counts; not a collective).
+ * dyn_comm_allreduce_f64: collective. Elementwise over ranks, in place on the caller's n doubles; op 0 = sum, 1 = max.
+ * Bounded like every exchange here: DYN_COMM_TIMEOUT_S (default 300) seconds or an asynchronous RCCL error abort the
+ * communicator and fail the call -- a peer that has gone costs its peers an error, not a hang. */
+int dyn_comm_gather_bytes(dyn_comm* c, const void* bytes, uint64_t n_bytes, int root, uint64_t* counts_out);
+int dyn_comm_gathered_bytes(dyn_comm* c, void* out, uint64_t out_cap);
+int dyn_comm_allreduce_f64(dyn_comm* c, double* inout, uint64_t n, int op);
 
 #ifdef __cplusplus
 }

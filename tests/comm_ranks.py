@@ -162,6 +162,18 @@ def run_rank(scenario, rank, n, workdir, model):
         own = b.fetch_train(pooled=True).pooled
         summed = comm.allreduce_pooled(b, al.num_kmers)
         save("E", own=own, summed=summed)
+    # F: the CLIs' payloads (host memory) through the same exchange: a ragged byte gather to rank 0 and to the last rank (rank 1
+    # sends nothing), sum and max all-reduce of a small float64 vector
+    payload = (b"rank%d|" % rank) * (1 + 50000 * rank) if rank != 1 else b""
+    for root in (0, n - 1):
+        parts = comm.gather_bytes(payload, root=root)
+        if rank == root:
+            out["F_ok_root%d" % root] = bool(parts == [((b"rank%d|" % r) * (1 + 50000 * r) if r != 1 else b"") for r in range(n)])
+        else:
+            out["F_none_root%d" % root] = parts is None
+    v = np.array([1.0 + rank, -float(rank), 0.5])
+    out["F_sum"] = comm.allreduce(v, "sum").tolist()
+    out["F_max"] = comm.allreduce(v, "max").tolist()
     comm.close()
     al.close()
     print("RESULT " + json.dumps(out), flush=True)

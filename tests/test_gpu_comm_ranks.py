@@ -64,6 +64,11 @@ def test_gather_and_allreduce_across_ranks(models, tmp_path, n):
     for r in range(1, n):
         host += own[r]
     assert host[: len(host) // 3].sum() > 1000.0   # total weight = the samples of all ranks' reads
+    # F: the CLIs' host payloads through the same code path (dyn_comm_gather_bytes / dyn_comm_allreduce_f64)
+    assert res[0]["F_ok_root0"] and res[n - 1]["F_ok_root%d" % (n - 1)]
+    assert all(res[r].get("F_none_root0", True) and res[r].get("F_none_root%d" % (n - 1), True) for r in range(n))
+    for r in range(n):
+        assert res[r]["F_sum"] == [n * (n + 1) / 2, -n * (n - 1) / 2, 0.5 * n] and res[r]["F_max"] == [float(n), 0.0, 0.5]
     if n == 2:
         assert np.array_equal(summed[0].view(np.uint64), host.view(np.uint64))   # two addends: no association to differ in
     else:

@@ -1,7 +1,9 @@
-"""GPU (-m gpu): the CLIs under torch.distributed.run with two ranks (both on cuda:0, gloo for the
-collectives -- a 1-GPU box cannot host two RCCL ranks): reads are sharded, rank 0 gathers the CSV rows
-(BASELINE config 4) / pooled statistics are all-reduced (config 5). Results must equal the
-single-process run up to row order."""
+"""GPU (-m gpu): the CLIs under torch.distributed.run with two and four ranks, all on cuda:0. The payloads travel through
+the product's ONE exchange stack, dyn_comm_* over real RCCL (every rank gets its own NCCL_HOSTID, so RCCL takes the ranks
+for one-GPU nodes and connects them by sockets over loopback: dynamont_amd/parallel.py one_device_rccl_env); gloo only
+carries torch.distributed's control plane (the communicator id, control strings, the final barrier). Reads are sharded,
+rank 0 gathers the ranks' parts of the output frame (BASELINE config 4) / pooled statistics are all-reduced (config 5).
+Results must equal the single-process run up to row order."""
 import os
 import subprocess
 import sys
@@ -19,11 +21,13 @@ pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib")]
 
 
 def _torchrun(module, args, port, ranks=2):
-    env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", PYTHONPATH=ROOT)
+    env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", DYN_DIST_EXCHANGE="dyn_comm", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(port), "-m", module] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+    # the same exchange implementation `bench.py --gpus N` names (test_bench_gpus_n_launches_its_own_ranks below)
+    assert "exchange: dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp)" in r.stderr, r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("ranks", [2, 4])   # (a GPU box lets one job put 6 processes on its card: pytest itself + 4 ranks stay inside)
@@ -82,9 +86,10 @@ def test_train_two_ranks_allreduce(models, tmp_path):
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_bench_gpus_n_launches_its_own_ranks(tmp_path, ranks):
     """`python bench.py --gpus N` WITHOUT a launcher (what a driver may type): bench.py starts its N ranks itself as a
-    child torch.distributed.run and prints ONE line that says n_gpus N. Rehearsal hooks: every rank on cuda:0, gloo, and a
-    torch.distributed stand-in for the exchange (a 1-GPU box cannot host two RCCL ranks; the real exchange is dyn_comm_*,
-    tests/test_gpu_rccl_comm.py) -- the line must SAY that it is a rehearsal. Without the hooks the same command must refuse
+    child torch.distributed.run and prints ONE line that says n_gpus N. Rehearsal hooks: every rank on cuda:0, gloo for torch's
+    bracket collectives; the exchange of every step is the REAL one -- dyn_comm_gather_counts / _rows over RCCL, a NCCL_HOSTID
+    per rank (sockets over loopback) -- beside resident sessions that share the card's CUs between the ranks; the line must SAY
+    that it is a one-device rehearsal and name dyn_comm_*. Without the hooks the same command must refuse
     a box with one device instead of measuring one GPU and calling it N. (4 ranks: a GPU box lets one job put 6 processes on its
     card, this test runner included; gloo at world 8 runs on the CPU, tests/test_parallel_gloo.py.)"""
     import json
@@ -99,7 +104,8 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path, ranks):
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["strict_mode"] == "ties" and len(d["per_rank_ms"]) == ranks
-    assert "REHEARSAL" in d["exchange"]["implementation"] and d["exchange"]["rows_gathered_rank0"] > 0
+    assert "ONE-DEVICE REHEARSAL" in d["exchange"]["implementation"] and "dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp)" in d["exchange"]["implementation"]
+    assert d["exchange"]["rows_gathered_rank0"] > 0 and d["collective_backend"].startswith("rccl (dyn_comm_*)")
     if ranks != 2:
         return
     env.pop("DYN_BENCH_ONE_DEVICE")
