@@ -145,18 +145,14 @@ def load_traffic():
     return None
 
 
-def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0, sub: str = "e2e", cold: bool = False) -> dict:
-    """north_star's "throughput on synthetic pod5+bam": the dynamont-resquiggle counterpart end to end, in this process.
-    A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
-    dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
-    Timed: model load, BAM parse, pod5 open + VBZ decode, pA calibration + normalisation + Hampel on the device, the
-    DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool and the
-    batch buffers are the ones the bench's own handle has just parked (a fresh process allocates them: ~1 s on clean VRAM).
-    `cold`: the SAME dataset once more in a FRESH CHILD PROCESS after this process has given all its device memory back
-    (dyn_release_cached_memory): `python -m dynamont_amd.segmentation.segment ...`, wall clock from process start to exit --
-    what a user who types the command waits for (interpreter, imports, library load, model parse, pool allocation included)."""
+_E2E_DATASETS: dict = {}
+
+
+def make_e2e_dataset(n_reads: int, workdir: str, sub: str) -> dict:
+    """the synthetic .pod5 + BAM dataset of an e2e_cli record (written once per `sub`, CPU only: no GPU call)"""
+    if sub in _E2E_DATASETS:
+        return _E2E_DATASETS[sub]
     from dynamont_amd import synth
-    from dynamont_amd.segmentation import segment as seg
     d = os.path.join(workdir, sub)
     os.makedirs(d, exist_ok=True)
     model = synth.write_model(os.path.join(d, "syn9.model"), 9, seed=7, stdev=0.15)
@@ -168,43 +164,67 @@ def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0, s
     raw, bam, _ = synth.write_dataset(os.path.join(d, "in"), "ds", reads, "rna004", seed=1, container="pod5", replicate=rep, basecalls="bam")
     samples = sum(len(r.signal) for r in reads) * rep
     del reads
-    t_gen = time.perf_counter() - t0
-    out = os.path.join(d, "out.csv")
-    cli = ["-r", os.path.join(d, "in"), "-b", bam, "-o", out, "--mode", "basic", "-p", "rna004", "--model_path", model,
-           "--strict-ties", strict] + (["--batch-reads", str(batch_reads)] if batch_reads else [])
+    ds = {"dir": d, "model": model, "raw": raw, "bam": bam, "samples": samples, "reads": distinct * rep, "distinct": distinct, "rep": rep,
+          "t_gen": time.perf_counter() - t0, "out": os.path.join(d, "out.csv")}
+    _E2E_DATASETS[sub] = ds
+    return ds
+
+
+def e2e_cli_args(ds: dict, strict: str, batch_reads: int = 0) -> list:
+    return ["-r", os.path.join(ds["dir"], "in"), "-b", ds["bam"], "-o", ds["out"], "--mode", "basic", "-p", "rna004", "--model_path", ds["model"],
+            "--strict-ties", strict] + (["--batch-reads", str(batch_reads)] if batch_reads else [])
+
+
+def run_e2e_cold(ds: dict, strict: str, batch_reads: int, vram: str) -> dict:
+    """The dataset through `python -m dynamont_amd.segmentation.segment ...` in a FRESH CHILD PROCESS, wall clock from Popen
+    to exit -- what a user who types the command waits for: interpreter start-up, imports, library load, model parse,
+    allocation of the lattice pool and of every buffer, then everything the warm record times. `vram` says in what state
+    the device was: the driver scrubs memory a process has freed before it hands it out again (tools/ubench/vmm_probe.hip:
+    112 GiB come in 0.000 s when clean and in 3-7 s right after another process has freed them)."""
+    for f in (ds["out"] + ".zst", ds["out"] + ".errors"):
+        if os.path.exists(f):
+            os.remove(f)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     t0 = time.perf_counter()
-    seg.main(cli)
+    r = subprocess.run([sys.executable, "-m", "dynamont_amd.segmentation.segment"] + e2e_cli_args(ds, strict, batch_reads), env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    rec = {"value": round(ds["samples"] / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "returncode": r.returncode, "vram": vram,
+           "output_bytes": os.path.getsize(ds["out"] + ".zst") if os.path.exists(ds["out"] + ".zst") else None}
+    if r.returncode != 0:
+        rec["stderr_tail"] = r.stderr.decode(errors="replace")[-500:]
+    return rec
+
+
+def run_e2e_cli(n_reads: int, workdir: str, strict: str, batch_reads: int = 0, sub: str = "e2e") -> dict:
+    """north_star's "throughput on synthetic pod5+bam": the dynamont-resquiggle counterpart end to end, in this process.
+    A .pod5 file (VBZ-compressed int16 chunks) and an unaligned BAM (dorado's tags) written by synth.write_dataset ->
+    dynamont_amd.segmentation.segment.main -> out.csv.zst (reference: src/dynamont/segmentation/segment.py:261-371).
+    Timed: model load, BAM parse, pod5 open + VBZ decode, pA calibration + normalisation + Hampel on the device, the
+    DP, CSV formatting, zstd, file write. Not timed: interpreter start-up, dataset generation; the lattice pool and the
+    batch buffers are the ones the bench's own handle has just parked -- the `cold` records time all of it."""
+    from dynamont_amd.segmentation import segment as seg
+    ds = make_e2e_dataset(n_reads, workdir, sub)
+    out, raw, bam = ds["out"], ds["raw"], ds["bam"]
+    for f in (out + ".zst", out + ".errors"):
+        if os.path.exists(f):
+            os.remove(f)
+    t0 = time.perf_counter()
+    seg.main(e2e_cli_args(ds, strict, batch_reads))
     dt = time.perf_counter() - t0
     err = out + ".errors" if os.path.exists(out + ".errors") else None
-    rec = {"value": round(samples / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "reads": distinct * rep,
-           "reads_per_s": round(distinct * rep / dt, 1), "samples": samples,
+    rec = {"value": round(ds["samples"] / dt / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dt, 3), "reads": ds["reads"],
+           "reads_per_s": round(ds["reads"] / dt, 1), "samples": ds["samples"],
            "input": f"{os.path.basename(raw)} ({os.path.getsize(raw) / 1e6:.0f} MB, VBZ) + {os.path.basename(bam)} ({os.path.getsize(bam) / 1e6:.1f} MB); "
-                    f"{distinct} distinct synthetic rna004 reads x {rep}, written by synth.write_dataset in {t_gen:.1f} s (not timed)",
+                    f"{ds['distinct']} distinct synthetic rna004 reads x {ds['rep']}, written by synth.write_dataset in {ds['t_gen']:.1f} s (not timed)",
            "output": (f"out.csv.zst, {os.path.getsize(out + '.zst') / 1e6:.1f} MB (one zstd frame, level 3) holding "
                       f"{seg.LAST_RUN.get('csv_bytes', 0) / 1e6:.0f} MB of CSV rows") if os.path.exists(out + ".zst") else None,
+           "output_bytes": os.path.getsize(out + ".zst") if os.path.exists(out + ".zst") else None,
            "batches_in_flight": seg.LAST_RUN.get("depth"), "compress_threads": seg.LAST_RUN.get("compress_threads"),
            "error_lines": sum(1 for _ in open(err)) if err else 0, "strict_mode": strict,
            "batch_reads": batch_reads or "CLI default",
            "timed": "segment.main: model load, BAM parse, pod5 VBZ decode, device preprocessing, DP, CSV format, zstd, write",
            "not_timed": "interpreter start-up; allocation of the lattice pool and of the batch buffers (those the bench's own handle has just parked are taken over) -- `cold` times all of it"}
-    if cold:
-        import dynamont_amd
-        warm_bytes = os.path.getsize(out + ".zst") if os.path.exists(out + ".zst") else None
-        for f in (out + ".zst", out + ".errors"):
-            if os.path.exists(f):
-                os.remove(f)
-        dynamont_amd.release_cached_memory()   # the child starts on a device that holds nothing of ours
-        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        t0 = time.perf_counter()
-        r = subprocess.run([sys.executable, "-m", "dynamont_amd.segmentation.segment"] + cli, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        dtc = time.perf_counter() - t0
-        same = warm_bytes is not None and os.path.exists(out + ".zst") and os.path.getsize(out + ".zst") == warm_bytes
-        rec["cold"] = {"value": round(samples / dtc / 1e6, 3), "unit": "Msamp/s", "wall_s": round(dtc, 3), "returncode": r.returncode,
-                       "of_warm": round(dt / dtc, 3), "output_bytes_equal_warm": same,
-                       "timed": "a fresh child process, Popen to exit: interpreter start-up, imports, library load, model parse, allocation of the "
-                                "lattice pool and every buffer on a device this process has released, then everything `timed` above"}
-        if r.returncode != 0:
-            rec["cold"]["stderr_tail"] = r.stderr.decode(errors="replace")[-500:]
     return rec
 
 
@@ -482,6 +502,19 @@ def main():
         if cpu_proc.returncode != 0:
             print("cpu baseline failed:\n" + err.decode(errors="replace")[-2000:], file=sys.stderr)
 
+    # e2e_cli.cold, first leg: the CLI in a fresh child process BEFORE this process touches the GPU -- the device as the bench
+    # found it (whatever ran before has long exited: its memory is scrubbed)
+    cold_first = None
+    want_e2e = rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and "WORLD_SIZE" not in os.environ \
+        and not os.environ.get("DYN_BENCH_FORCE_DIST")
+    if want_e2e and not args.no_cold:
+        try:
+            strict0 = {"start": "ties"}.get(args.strict, args.strict)
+            cold_first = run_e2e_cold(make_e2e_dataset(args.e2e_reads, workdir, "e2e"), strict0, args.e2e_batch_reads,
+                                      "as the bench found it (before this process touched the GPU)")
+        except Exception as e:  # the headline stands on its own
+            cold_first = {"error": f"{type(e).__name__}: {e}"}
+
     import torch
     import torch.distributed as dist
 
@@ -735,20 +768,6 @@ def main():
     al.close()  # (parks the lattice pool: the next handle takes it over instead of allocating its own)
     if exch is not None:
         exch.close()
-    if rank == 0 and n_gpus == 1 and not use_dist and args.mode == "align" and workload == "cfg2" and not args.reads and not args.no_cfg3:
-        # BASELINE configs[2]: another pore, hence another handle. 4 096 DNA reads of 10 k-100 k samples per batch do not get an
-        # arena each (1 024 arenas of the longest read: 550 GB): a PAGED session, posteriors in place (24.125 B per cell)
-        try:
-            Workload.drop("cfg2_polya", rank), Workload.drop("cfg4_share", rank)
-            wl_3 = Workload.get("cfg3", rank, args, model_cache, workdir, n_distinct=1)
-            al3 = Aligner(wl_3.model_path, wl_3.pore, mode="basic", band=400, device=local_rank)
-            line["cfg3"] = side_record(al3, wl_3, max(4, min(6, args.steps)), args.strict,
-                                       "BASELINE configs[2]: 4 096 dna_r10_400bps reads, 800-8 000 bases (10 k-100 k samples), page-starved: "
-                                       "a paged session, posteriors in place")
-            al3.close()
-            Workload.drop("cfg3", rank)
-        except Exception as e:  # the headline stands on its own
-            line["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist:
         try:
             strict = {"start": "ties"}.get(args.strict, args.strict)
@@ -756,11 +775,45 @@ def main():
             if args.e2e_large_reads > args.e2e_reads:
                 big = run_e2e_cli(args.e2e_large_reads, workdir, strict, args.e2e_batch_reads, sub="e2e_large")
                 shutil.rmtree(os.path.join(workdir, "e2e_large"), ignore_errors=True)
-            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, strict, args.e2e_batch_reads, cold=not args.no_cold)
+            line["e2e_cli"] = run_e2e_cli(args.e2e_reads, workdir, strict, args.e2e_batch_reads)
             if big is not None:
                 line["e2e_cli"]["large"] = {k_: big[k_] for k_ in ("value", "unit", "wall_s", "reads", "reads_per_s", "samples", "input", "output", "error_lines")}
         except Exception as e:  # the headline stands on its own
             line.setdefault("e2e_cli", {})["error"] = f"{type(e).__name__}: {e}"
+    if rank == 0 and n_gpus == 1 and not use_dist and args.mode == "align" and workload == "cfg2" and not args.reads and not args.no_cfg3:
+        # BASELINE configs[2]: another pore, hence another handle. 4 096 DNA reads of 10 k-100 k samples per batch do not get an
+        # arena each (1 024 arenas of the longest read: 550 GB): a PAGED session, posteriors in place (24.125 B per cell)
+        try:
+            Workload.drop("cfg2_polya", rank), Workload.drop("cfg4_share", rank)
+            wl_3 = Workload.get("cfg3", rank, args, model_cache, workdir, n_distinct=1)
+            al3 = Aligner(wl_3.model_path, wl_3.pore, mode="basic", band=400, device=local_rank)
+            line["cfg3"] = side_record(al3, wl_3, max(4, min(8, args.steps)), args.strict,
+                                       "BASELINE configs[2]: 4 096 dna_r10_400bps reads, 800-8 000 bases (10 k-100 k samples), page-starved: "
+                                       "a paged session, posteriors in place")
+            al3.close()
+            Workload.drop("cfg3", rank)
+        except Exception as e:  # the headline stands on its own
+            line["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and n_gpus == 1 and args.mode == "align" and not args.no_e2e and not use_dist and not args.no_cold and line.get("e2e_cli", {}).get("wall_s"):
+        try:
+            strict = {"start": "ties"}.get(args.strict, args.strict)
+            if True:  # (second leg of e2e_cli.cold)
+                import dynamont_amd
+                warm = line["e2e_cli"]
+                dynamont_amd.release_cached_memory()  # second leg: every byte this process held has JUST been freed
+                after = run_e2e_cold(make_e2e_dataset(args.e2e_reads, workdir, "e2e"), strict, args.e2e_batch_reads,
+                                     "right after this process freed its lattice pools (~130-250 GB): the child's allocations wait for the driver's scrubbing")
+                cold = dict(cold_first or {})
+                cold["timed"] = ("a fresh child process, Popen to exit: interpreter start-up, imports, library load, model parse, allocation of the "
+                                 "lattice pool and every buffer, then everything the warm record times")
+                for rec_ in (cold, after):
+                    if rec_.get("wall_s"):
+                        rec_["of_warm"] = round(warm["wall_s"] / rec_["wall_s"], 3)
+                        rec_["output_bytes_equal_warm"] = rec_.get("output_bytes") == warm.get("output_bytes")
+                cold["after_release"] = after
+                warm["cold"] = cold
+        except Exception as e:  # the headline stands on its own
+            line["e2e_cli"]["cold"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line))
     shutil.rmtree(workdir, ignore_errors=True)  # models, the cpu_baseline's files, the e2e datasets and their output

@@ -219,6 +219,27 @@ hipError_t ensure_pool_buffer(int device, int kind, DevBuf& b, size_t want, doub
   }
   return e;
 }
+
+// The three arrays of a lattice pool together. A buffer taken over from a predecessor's parked pool may be far larger than
+// asked for (a handle that served reads of 100 k samples, in place: one 250 GB array) and leave no room for the others:
+// on out-of-memory everything the handle holds of the pool is released and the three are allocated again at their sizes.
+hipError_t ensure_pool(int device, DevBuf& ws, size_t ws_bytes, DevBuf& lpe, size_t lpe_bytes, DevBuf& bits, size_t bits_bytes, double headroom) {
+  auto all = [&]() -> hipError_t {
+    hipError_t e = ensure_pool_buffer(device, 0, ws, ws_bytes, headroom);
+    if (e == hipSuccess && lpe_bytes) e = ensure_pool_buffer(device, 1, lpe, lpe_bytes, headroom);
+    if (e == hipSuccess && bits_bytes) e = ensure_pool_buffer(device, 2, bits, bits_bytes, headroom);
+    return e;
+  };
+  hipError_t e = all();
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    ws.release();
+    lpe.release();
+    bits.release();
+    e = all();
+  }
+  return e;
+}
 }  // namespace
 
 extern "C" void dyn_release_cached_memory(void) {
@@ -602,9 +623,30 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   dyn_aligner* a = new dyn_aligner();
   a->threads = threads;
   a->ntk = ntk;
+  // DYN_TRACE_HOST=1: where a handle's creation goes (tools/cold_start_trace.py)
+  const bool trace_create = std::getenv("DYN_TRACE_HOST") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
+  auto tc_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(); };
+  // The HIP runtime comes up (50-60 ms in a fresh process) on a helper thread while this one parses the model file (~110 ms
+  // for a 9-mer table): a cold dynamont-resquiggle run is start-up bound below ~10 k reads.
+  std::thread hip_warm;
+  if (device != DYN_DEVICE_HOST_ONLY)
+    hip_warm = std::thread([device] {
+      int dv = device;
+      if (dv < 0 && hipGetDevice(&dv) != hipSuccess) return;
+      if (hipSetDevice(dv) == hipSuccess) (void)hipFree(nullptr);
+      (void)hipGetLastError();
+    });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } hip_warm_join{hip_warm};
   try {
     a->model.load(model_path ? model_path : "", pore, band);
     if (!model_allows_strict(a->model)) a->strict_mode = 0;
+    if (trace_create) std::fprintf(stderr, "[dyn] create: model parsed at %.1f ms\n", tc_ms());
   } catch (const std::invalid_argument& e) {
     copy_msg(err, errcap, e.what());
     delete a;
@@ -619,6 +661,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     *out = a;
     return DYN_OK;
   }
+  if (hip_warm.joinable()) hip_warm.join();
   auto fail = [&](hipError_t e, const char* what) {
     copy_msg(err, errcap, std::string("HIP error: ") + hipGetErrorString(e) + " at " + what +
                               " (the MI355X build has no CPU compute path)");
@@ -639,6 +682,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   a->device = device;
   a->cache.device = device;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  if (trace_create) std::fprintf(stderr, "[dyn] create: HIP runtime up (hipSetDevice) at %.1f ms\n", tc_ms());
   if ((e = hipDeviceGetAttribute(&a->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail(e, "hipDeviceGetAttribute");
   if (const char* f = std::getenv("DYN_QUEUE_CUS")) a->n_cus = std::max(1, std::atoi(f));  // experiments: fewer persistent workgroups
   if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -654,6 +698,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     (void)make_session_stream(a, rsv ? std::atoi(rsv) : 0);  // failure: the handle simply has no resident read queue
     if (const char* f = std::getenv("DYN_SESSION_IDLE_S")) a->sess_idle_s = std::max(0.001, std::atof(f));
   }
+  if (trace_create) std::fprintf(stderr, "[dyn] create: streams at %.1f ms\n", tc_ms());
   if ((e = a->d_model.ensure(sizeof(Emis) * a->model.table.size())) != hipSuccess) return fail(e, "hipMalloc(model)");
   // (uploads on the handle's own non-blocking stream: a null-stream copy would wait for another handle's resident session)
   auto upload = [&](void* dst, const void* src, size_t bytes) {
@@ -672,6 +717,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
     if ((e = upload(a->d_sptab.p, tab.data(), sizeof(dynmath::SoftplusNode) * tab.size())) != hipSuccess)
       return fail(e, "hipMemcpy(softplus table)");
   }
+  if (trace_create) std::fprintf(stderr, "[dyn] create: tables uploaded, done at %.1f ms\n", tc_ms());
   *out = a;
   return DYN_OK;
 }
@@ -1398,9 +1444,8 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     if (grow) {  // growing releases the old buffer, which earlier work on the compute stream may still be using
       HIP_TRY(a, hipStreamSynchronize(a->stream));
       const double headroom = std::min(1.15, std::max(1.0, (double)cap_pages / (double)std::max<uint64_t>(1, target)));
-      HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, target * ws_pp, headroom));
-      if (calc && lpe_separate) HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, target * lpe_pp, headroom));
-      if (calc) HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, target * bits_pp, headroom));
+      HIP_TRY(a, ensure_pool(a->device, a->ws, target * ws_pp, a->lpe, (calc && lpe_separate) ? target * lpe_pp : 0, a->bits,
+                             calc ? target * bits_pp : 0, headroom));
     }
     uint64_t n_pages = std::min<uint64_t>(a->ws.bytes / ws_pp, cap_pages);  // (a buffer taken over from a parked pool may exceed this handle's budget)
     if (calc && lpe_separate) n_pages = std::min<uint64_t>(n_pages, a->lpe.bytes / lpe_pp);
@@ -1683,9 +1728,8 @@ int session_open(dyn_aligner* a, bool mixed, const SessionGeom& g) {
   if (a->ws.bytes < n_pages_total * ws_pp || (separate && a->lpe.bytes < n_pages_total * lpe_pp) || a->bits.bytes < n_pages_total * bits_pp ||
       (paged && a->free_list.bytes < (size_t)n_pages_total * 4)) {
     if (ss.pending[ss.blk]) HIP_TRY(a, hipEventSynchronize(ss.ev_end[ss.blk]));
-    HIP_TRY(a, ensure_pool_buffer(a->device, 0, a->ws, n_pages_total * ws_pp, 1.0));
-    if (separate) HIP_TRY(a, ensure_pool_buffer(a->device, 1, a->lpe, n_pages_total * lpe_pp, 1.0));
-    HIP_TRY(a, ensure_pool_buffer(a->device, 2, a->bits, n_pages_total * bits_pp, 1.0));
+    HIP_TRY(a, ensure_pool(a->device, a->ws, n_pages_total * ws_pp, a->lpe, separate ? n_pages_total * lpe_pp : 0, a->bits,
+                           n_pages_total * bits_pp, 1.0));
     if (paged) HIP_TRY(a, a->free_list.ensure((size_t)n_pages_total * 4, 1.0));
   }
   if (paged) HIP_TRY(a, a->ctl.ensure(dynk::QUEUE_CTL_WORDS * 4, 1.0));

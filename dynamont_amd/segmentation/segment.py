@@ -883,6 +883,15 @@ def main(argv=None) -> None:
             device=args.device, batch_reads=args.batch_reads, mem_budget_gib=args.mem_budget,
             host_preprocess=args.host_preprocess, depth=args.depth, strict_ties=args.strict_ties, host_threads=args.host_threads,
             zstd_level=args.zstd_level)
+    _stamp("segment() returned (aligner closed)")
+    if argv is None and not int(__import__("os").environ.get("WORLD_SIZE", "1") or 1) > 1:
+        # Invoked as the command (console script / python -m), single process, everything written and closed: leave without
+        # the interpreter's and the HIP runtime's orderly teardown (0.3 s in which ~130 GB of device memory are handed back
+        # allocation by allocation -- the driver reclaims them with the process anyway). Callers of main([...]) are not affected.
+        import os
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -225,3 +225,36 @@ def test_getters_of_a_completed_ticket_do_not_wait_for_the_session(models):
     s1 = al.session_stats()
     assert s1["aborted"] == s0["aborted"] == 0 and s1["sessions"] - s0["sessions"] == 1 and s1["tickets"] - s0["tickets"] == 9
     al.close()
+
+
+def test_successor_of_a_handle_that_parked_one_huge_array(models):
+    """A handle that served page-starved batches in place (reads of 100 k samples: ONE array of most of the HBM) parks it; its
+    successor needs three arrays (an arena per wave, separate posteriors) and takes the huge one over as its first -- the other
+    two then do not fit. ensure_pool releases what the handle holds of the pool and allocates the three at their own sizes
+    (bench.py met this between its cfg3 record and the CLI's handle: HIP out of memory)."""
+    import dynamont_amd
+    dynamont_amd.release_cached_memory()
+    _, mean, sd = synth.read_model_file(models["syn9"])
+    long_reads = synth.make_reads(4900, 1100, "dna_r10_400bps", mean, sd, (7000, 8000))   # ~90 k-100 k samples each
+    al = Aligner(models["syn9"], "dna_r10_400bps", device=0)
+    t = al.align_async(*synth.pack_reads(long_reads), True)
+    r = t.wait()
+    assert (r.status == 0).all()
+    tm = t.timing()
+    t.close()
+    big_pool_gb = tm["pool_pages"] * tm["page_rows"] * 448 * 8 / 1e9
+    al.close()                                    # parks the pool
+    assert tm["lp_inplace"] == 1 and big_pool_gb > 180, (tm["lp_inplace"], big_pool_gb)
+    reads = synth.make_reads(4901, 1024, "rna004", mean, sd, 2000)
+    al2 = Aligner(models["syn9"], "rna004", device=0)
+    want = al2.align_batch([x.signal for x in reads[:64]], [x.sequence for x in reads[:64]], True)
+    t2 = al2.align_async(*synth.pack_reads(reads), True)
+    got = t2.wait()
+    assert (got.status == 0).all() and t2.timing()["launches"] == 0   # the resident queue: an arena per wave, three arrays
+    for i in range(64):
+        lo, hi = int(want.seg_offsets[i]), int(want.seg_offsets[i]) + int(want.n_segments[i])
+        glo = int(got.seg_offsets[i])
+        assert np.array_equal(got.signal_positions[glo:glo + hi - lo], want.signal_positions[lo:hi])
+    t2.close()
+    al2.close()
+    dynamont_amd.release_cached_memory()

@@ -28,5 +28,5 @@ for run in range(3):
     dt = time.perf_counter() - t0
     print("==== run %d: rc %d, %.3f s wall = %.1f Msamp/s" % (run, r.returncode, dt, samples / dt / 1e6))
     lines = r.stderr.splitlines()
-    keep = [l for l in lines if l.startswith("[cli")] if run < 2 else lines[:120]
+    keep = [l for l in lines if l.startswith("[cli")] if run < 2 else [l for l in lines if l.startswith("[cli") or "create:" in l or "destroy" in l or "publish 1" in l or "publish 2" in l or "publish 3" in l][:60]
     print("\n".join(keep))
