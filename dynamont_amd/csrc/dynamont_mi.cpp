@@ -402,7 +402,7 @@ void attach_cache(dyn_batch* b) {
   dyneng::BufCache* c = &b->a->cache;
   for (DevBuf* d : {&b->d_sig, &b->d_kmers, &b->d_par, &b->d_state, &b->d_rows, &b->d_segrow, &b->d_medhi,
                     &b->d_medlo, &b->d_descs, &b->d_colw, &b->d_cols1, &b->d_cols2, &b->d_trans, &b->d_pooled, &b->d_poolwork, &b->d_pooltemp, &b->d_pp,
-                    &b->d_pathn, &b->d_norm, &b->d_meta})
+                    &b->d_pathn, &b->d_norm, &b->d_meta, &b->d_wide})
     d->cache = c;
   for (PinnedBuf* h : {&b->h_kmers, &b->h_descs, &b->h_state, &b->h_rows, &b->h_stats, &b->h_sig}) h->cache = c;
 }
@@ -429,6 +429,7 @@ int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, cons
                  const char* seqs, const uint64_t* seq_offsets, HelperPool* pool) {
   b->n = n;
   b->reads.assign(n, HostRead());
+  b->n_wide = 0;
   uint64_t cap = 0, flat = 0;
   for (uint64_t i = 0; i < n; ++i) {
     HostRead& r = b->reads[i];
@@ -439,9 +440,16 @@ int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, cons
     r.kc = r.L >= (uint64_t)m.k ? r.L - (uint64_t)m.k + 1 : 0;
     cap += r.kc;
     r.status = m.validate(r.S, r.L);
-    // 448 band slots per lattice row: a read is computable when its half band min(band / 2, columns / 2) fits them
-    if (r.status == DYN_READ_OK && std::min<uint64_t>(m.half_band, (r.kc + 1) / 2) > (uint64_t)dynk::MAX_HALF_BAND)
-      r.status = DYN_READ_BAND_TOO_WIDE;
+    // 448 band slots per lattice row in the register sweeps: a read whose half band min(band / 2, columns / 2) does not fit
+    // them takes the generic kernel (wide_band.hip), which holds a row of up to 4 096 band columns in LDS
+    if (r.status == DYN_READ_OK) {
+      const uint64_t hb = std::min<uint64_t>(m.half_band, (r.kc + 1) / 2);
+      if (hb > (uint64_t)dynk::WIDE_MAX_HALF_BAND) r.status = DYN_READ_BAND_TOO_WIDE;
+      else if (hb > (uint64_t)dynk::MAX_HALF_BAND) {
+        r.wide = true;
+        ++b->n_wide;
+      }
+    }
     if (r.status == DYN_READ_OK) {
       r.flat_off = flat;
       flat += r.kc;
@@ -777,7 +785,7 @@ int dyn_aligner_info(const dyn_aligner* a, dyn_info* info) {
   info->log_m1 = a->model.log_m1;
   info->log_e1 = a->model.log_e1;
   info->log_e2 = a->model.log_e2;
-  info->max_half_band = dynk::MAX_HALF_BAND;
+  info->max_half_band = dynk::WIDE_MAX_HALF_BAND;
   return DYN_OK;
 }
 
@@ -896,7 +904,7 @@ int dyn_read_strerror(int read_status, char bad_char, char* buf, uint64_t cap) {
     case DYN_READ_TOO_LARGE: s = "Read too large for the device memory budget"; break;
     case DYN_READ_NTK_MISMATCH: s = "NTK alignment failed: alignment scores do not match"; break;
     case DYN_READ_BAD_SIGNAL: s = "Signal could not be decoded"; break;
-    case DYN_READ_BAND_TOO_WIDE: s = "Band wider than this build's 448 band slots for a read of this length"; break;
+    case DYN_READ_BAND_TOO_WIDE: s = "Band wider than this build's 4096 band columns for a read of this length"; break;
     default: copy_msg(buf, cap, "unknown read status"); return DYN_ERR_INVALID_ARGUMENT;
   }
   copy_msg(buf, cap, s);
@@ -1326,12 +1334,16 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   // profiles/r04/strict_mode_cost.json): backward 1.3, forward 1.4; a read spends 0.4 / 0.6 of its time in the two sweeps.
   const int32_t* km = b->kmers();
   std::vector<uint32_t> strict_rows(b->n, 0);
-  std::vector<uint32_t> order;
+  std::vector<uint32_t> order, wide;
   uint64_t n_strict = 0;
   for (uint64_t i = 0; i < b->n; ++i) {
     const HostRead& r = b->reads[i];
     if (r.status != DYN_READ_OK) continue;
     if (a->ntk) continue;  // no read reaches the device; its status is set below
+    if (r.wide) {  // the generic kernel (wide_band.hip): the reference's own arithmetic in every cell, no queue, no pages
+      wide.push_back((uint32_t)i);
+      continue;
+    }
     if (calc && a->strict_mode == 2) strict_rows[i] = 0xffffffffu;
     else if (calc && a->strict_mode == 1) strict_rows[i] = tie_rows(a->model, km + r.flat_off, r.kc, r.S);
     n_strict += strict_rows[i] != 0;
@@ -1493,7 +1505,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   //  cfg2 with 26 % tie reads -- the certified sweeps do not get in each other's way inside a CU. Not kept.)
 
   // read descriptors in processing order; pages of the first round reserved here
-  HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
+  HIP_TRY(a, b->h_descs.ensure(std::max<size_t>(sizeof(ReadDesc), (n_ok + wide.size()) * sizeof(ReadDesc))));
   ReadDesc* descs = b->h_descs.as<ReadDesc>();
   dyn_timing tm{};
   uint64_t rows_total = 0;
@@ -1529,13 +1541,57 @@ int enqueue_job(dyn_batch* b, DynJob job) {
     tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
     tm.samples += r.S;
   }
+  // wide-band reads: their descriptors FOLLOW the queue's (the read queue sees the first n_ok, the per-segment kernels all)
+  uint64_t wide_arena = 0;
+  int wide_groups = 0;
+  if (!wide.empty()) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t room = (uint64_t)((double)(free_b + b->d_wide.bytes) * 0.8);
+    size_t wr = 0;
+    for (uint32_t i : wide) {
+      const HostRead& r = b->reads[i];
+      const uint64_t need = dynk::wide_arena_bytes(r.S + 1, std::min<uint64_t>(m.half_band, (r.kc + 1) / 2), calc);
+      if (need > room) st[i].status = DYN_READ_TOO_LARGE;
+      else {
+        wide_arena = std::max(wide_arena, need);
+        wide[wr++] = i;
+      }
+    }
+    if (wr != wide.size()) {
+      wide.resize(wr);
+      if (b->n) HIP_TRY(a, hipMemcpyAsync(b->d_state.p, st, b->n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
+    }
+    if (!wide.empty()) wide_groups = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)wide.size(), (uint64_t)a->n_cus, room / wide_arena}));
+  }
+  const size_t n_all = n_ok + wide.size();
+  for (size_t k = 0; k < wide.size(); ++k) {
+    const uint32_t i = wide[k];
+    const HostRead& r = b->reads[i];
+    ReadDesc d{};
+    d.T = (uint32_t)(r.S + 1);
+    d.N = (uint32_t)(r.kc + 1);
+    d.bw = (uint32_t)std::min<uint64_t>(m.half_band, d.N / 2);
+    d.read = i;
+    d.ratio = (double)d.N / (double)d.T;
+    d.sig_off = r.sig_off;
+    d.par_off = r.flat_off;
+    d.seg_off = r.seg_off;
+    d.path_off = rows_total;
+    d.first_page = dynk::NO_PAGE;
+    rows_total += d.T;
+    max_N = std::max(max_N, d.N);
+    descs[n_ok + k] = d;
+    tm.cells += (uint64_t)d.T * std::min<uint64_t>(2ull * d.bw + 1, d.N);
+    tm.samples += r.S;
+  }
   if (calc) {
     HIP_TRY(a, b->d_pp.ensure(std::max<uint64_t>(8, rows_total * 8)));
     HIP_TRY(a, b->d_pathn.ensure(std::max<uint64_t>(4, rows_total * 4)));
   }
-  HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_ok * sizeof(ReadDesc))));
-  if (n_ok)
-    HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, n_ok * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(a, b->d_descs.ensure(std::max<size_t>(sizeof(ReadDesc), n_all * sizeof(ReadDesc))));
+  if (n_all)
+    HIP_TRY(a, hipMemcpyAsync(b->d_descs.p, descs, n_all * sizeof(ReadDesc), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(a, b->h_stats.ensure(dynk::QUEUE_CTL_WORDS * 4));
   std::memset(b->h_stats.p, 0, dynk::QUEUE_CTL_WORDS * 4);
 
@@ -1574,20 +1630,42 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   HIP_TRY(a, hipMemcpyAsync(b->h_stats.p, pool.ctl, dynk::QUEUE_CTL_WORDS * 4, hipMemcpyDeviceToHost, a->stream));
   // (Running the per-segment kernels on a stream of their own, beside the next batch's read queue, was measured:
   //  the 0.35 ms gap it closes comes back as a 0.4 ms slower start of that read queue -- same-box A/B, no gain.)
-  if (calc) dynk::launch_segments(q.descs, nr, rows_total, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
+  if (!wide.empty()) {
+    // one workgroup per wide read at a time, each with a lattice arena for the largest of them; behind the read queue on the
+    // compute stream (its results feed the same per-segment kernels / the same host finalisation)
+    HIP_TRY(a, b->d_wide.ensure(256 + (uint64_t)wide_groups * wide_arena));
+    dynk::WideArgs wa{};
+    wa.descs = q.descs + n_ok;
+    wa.n_reads = (int)wide.size();
+    wa.sig = q.sig;
+    wa.par = q.par;
+    wa.st = q.st;
+    wa.tb = q.tb;
+    wa.tr = q.tr;
+    wa.head = b->d_wide.as<uint32_t>();
+    wa.arena = b->d_wide.as<char>() + 256;
+    wa.arena_bytes = wide_arena;
+    wa.exp_tab = reinterpret_cast<const uint64_t*>(a->d_sptab.as<dynmath::SoftplusNode>() + dynmath::SP_NODES + dynmath::EXP128_NODES);
+    wa.m1 = m.log_m1;
+    wa.e2 = m.log_e2;
+    wa.z_fail_status = z_fail;
+    dynk::launch_wide_reads(job == DynJob::Train ? 2 : calc ? 1 : 0, wa, wide_groups, a->stream);
+  }
+  const int nr_all = (int)n_all;
+  if (calc) dynk::launch_segments(q.descs, nr_all, rows_total, max_N, q.st, q.tb, b->d_rows.as<SegRow>(), m.k, a->stream);
   if (job == DynJob::Train) {
-    b->pool_nr = nr;
+    b->pool_nr = nr_all;
     b->pool_max_N = max_N;
   }
   HIP_TRY(a, hipEventRecord(ev[2], a->stream));
   HIP_TRY(a, hipEventRecord(b->ev_done, a->stream));
   HIP_TRY(a, hipGetLastError());
-  tm.reads_ok = n_ok;
+  tm.reads_ok = n_all;
   tm.reads_strict = (uint32_t)n_strict;
   tm.launch_share = 1.0;
   b->strict_flag.assign(b->n, 0);
   for (uint64_t i = 0; i < b->n; ++i) b->strict_flag[i] = strict_rows[i] != 0;
-  tm.launches = nr ? 1 : 0;
+  tm.launches = (nr || !wide.empty()) ? 1 : 0;
   tm.lp_inplace = (calc && !lpe_separate) ? 1 : 0;
   tm.pool_pages = pool.n_pages;
   tm.page_rows = (uint32_t)page_rows;
@@ -1595,7 +1673,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   tm.n_waves = (uint32_t)std::min<size_t>((order.size() + dynk::WAVES_PER_CU - 1) / dynk::WAVES_PER_CU * dynk::WAVES_PER_CU,
                                          (size_t)a->n_cus * dynk::WAVES_PER_CU);
   b->timing = tm;
-  b->n_chunks = nr ? 1 : 0;
+  b->n_chunks = (nr || !wide.empty()) ? 1 : 0;
   b->aligned = job != DynJob::Train;
   b->trained = job == DynJob::Train;
   b->last_calc = calc ? 1 : 0;
@@ -1885,6 +1963,7 @@ int session_plan(dyn_batch* b, bool* use) {
   dyn_aligner* a = b->a;
   *use = false;
   if (!session_candidate(b)) return DYN_OK;
+  if (b->n_wide) return DYN_OK;  // wide-band reads take the generic kernel behind a classic launch
   const SessionNeed need = session_need(b);
   if (!need.n_ok) return DYN_OK;  // nothing to launch
   Session& ss = a->sess;

@@ -174,6 +174,7 @@ struct HostRead {
   uint64_t sig_off = 0, flat_off = 0 /* into kmers / per-column tables */, seg_off = 0;
   int32_t status = 0;
   char bad = 0;
+  bool wide = false;  // half band above the register sweeps' 223: the read takes the generic kernel (wide_band.hip)
 };
 
 enum class DynJob { AlignZ, AlignFull, Train };
@@ -221,6 +222,8 @@ struct dyn_batch {
   dyneng::PinnedBuf h_sig;                     // staging of pageable caller signals (asynchronous path)
   // raw asynchronous path: [offsets | shift | scale | raw samples] staged in h_sig; device-side scratch of the preprocessing
   dyneng::DevBuf d_norm, d_meta;
+  dyneng::DevBuf d_wide;        // wide-band reads (wide_band.hip): queue head + one lattice arena per workgroup
+  uint64_t n_wide = 0;          // reads of this batch that take the generic kernel
   bool has_raw = false;
   RawSource raw_src;
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels

@@ -182,6 +182,29 @@ void launch_session(bool with_strict, int layout, const SessionArgs& a, const vo
 void launch_session_publish(SessionTicket* ring, uint32_t* ctl, const SessionTicket& tk, uint32_t index, uint32_t ring_size, hipStream_t s);
 void launch_session_close(uint32_t* ctl, hipStream_t s);
 
+// ---- any band (wide_band.hip): reads whose half band exceeds MAX_HALF_BAND take a generic kernel, one workgroup per read ----
+constexpr int WIDE_MAX_B = 4096;                          // band columns per row incl. the two guards (2 bw + 3), held in LDS
+constexpr int WIDE_CPT = WIDE_MAX_B / 256;                // band columns per thread
+constexpr int WIDE_MAX_HALF_BAND = (WIDE_MAX_B - 3) / 2;  // 2 046: band <= 4 093
+struct WideArgs {
+  const ReadDesc* descs;   // the wide reads of the batch
+  int n_reads;
+  const double* sig;
+  const Emis* par;
+  ReadState* st;
+  TraceBuffers tb;
+  TrainBuffers tr;
+  char* arena;             // n_groups arenas of arena_bytes: the lattice of the read a workgroup is working on
+  uint64_t arena_bytes;    // >= wide_arena_bytes of the largest wide read
+  uint32_t* head;          // queue head (cleared by launch_wide_reads)
+  const uint64_t* exp_tab; // dynmath::strict_exp_table on the device
+  double m1, e2;
+  int z_fail_status;
+};
+uint64_t wide_arena_bytes(uint64_t T, uint64_t bw, bool calc);
+// job: 0 = Z only, 1 = align(calc_probabilities = true) up to the per-row path arrays (launch_segments follows), 2 = train
+void launch_wide_reads(int job, const WideArgs& a, int n_groups, hipStream_t s);
+
 // P1/P2 on the device: out[i] = hampel((REAL(raw[i]) - shift) / scale); REAL = float when compute_f32.
 // raw_dtype: 0 float32, 1 int16, 2 float64, 3 int16 ADC with per-read float32 calibration (pA = (adc + cal_offset) *
 // cal_scale in float32; cal_* may be null otherwise). norm_tmp: scratch of total samples * sizeof(REAL).

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 7 /* 7: dyn_aligner_session_page_wait, dyn_comm_gather_bytes / _gathered_bytes / _allreduce_f64 (additive). 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
+#define DYN_ABI_VERSION 7 /* 7: dyn_aligner_session_page_wait, dyn_comm_gather_bytes / _gathered_bytes / _allreduce_f64 (additive). 7: half bands 224 .. 2 046 are computed (wide_band.hip). 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -75,10 +75,11 @@ enum dyn_read_status {
   DYN_READ_TOO_LARGE = 8,        /* "Read too large for the device memory budget": this read's lattice alone exceeds
                                     the HBM budget (or 2^31 rows); the reference would raise std::bad_alloc for that
                                     read only (segment.py:172-176), so it is a per-read status, not a batch error */
-  DYN_READ_BAND_TOO_WIDE = 11,   /* "Band wider than this build's 448 band slots for a read of this length": the handle was
-                                    created with band > 447 and the read has more than 447 lattice columns, so that its
-                                    half band min(band / 2, columns / 2) exceeds 223. Shorter reads are computed as the
-                                    reference computes them (for them a band of 448 and a band of 4 000 are the same band). */
+  DYN_READ_BAND_TOO_WIDE = 11,   /* "Band wider than this build's 4096 band columns for a read of this length": the handle was
+                                    created with band > 4 093 and the read has more than 4 093 lattice columns, so that its
+                                    half band min(band / 2, columns / 2) exceeds 2 046 -- what the generic kernel's rows hold
+                                    (wide_band.hip). Every other read is computed as the reference computes it: half bands up
+                                    to 223 by the register sweeps, 224 .. 2 046 by the generic kernel. */
   DYN_READ_BAD_SIGNAL = 10       /* "Signal could not be decoded" (dyn_batch_align_vbz_async): a POD5 chunk of this read is
                                     corrupt, truncated or shorter than the read's [start:end) slice. In the reference the
                                     pod5 reader raises inside the worker and the listener gets ONE line for that read,
@@ -105,7 +106,7 @@ typedef struct dyn_info {
   uint64_t num_kmers;      /* alphabet_size ** kmer_size */
   uint64_t half_band;      /* band / 2 (aligner.cpp:21) */
   double log_m1, log_e1, log_e2; /* NT_aligner_api.cpp:84-86 */
-  uint64_t max_half_band;  /* largest half band this build's kernels support */
+  uint64_t max_half_band;  /* largest half band this build computes (2 046: the generic kernel's; the tuned sweeps': 223) */
 } dyn_info;
 
 /* One output row per segment (= one CSV line of segmentation_to_string, utils.py:193-232).
@@ -225,10 +226,12 @@ int dyn_pore_from_string(const char* s, int* pore_out, char* err, uint64_t errca
  * behaves like the reference's does in this snapshot: reads fail validation with the usual messages or get
  * DYN_READ_NTK_MISMATCH, training returns DYN_ERR_RUNTIME "Training is not implemented for this aligner" (aligner.cpp:
  * 38-44); no kernel runs. Any other value -> DYN_ERR_INVALID_ARGUMENT "Unknown aligner mode: <m>".
- * band: any value, as in the reference (aligner.cpp:21). The kernels hold 448 band slots per lattice row: a read whose
- * half band min(band / 2, columns / 2) exceeds 223 -- band > 447 AND more than 447 lattice columns -- gets the per-read
- * status DYN_READ_BAND_TOO_WIDE, every other read is computed (every caller in the reference fixes band = 400:
- * segment.py:45, utils.py:161). device < 0 -> current HIP device. */
+ * band: any value, as in the reference (aligner.cpp:21). The tuned sweeps hold 448 band slots per lattice row (half bands
+ * up to 223: every caller in the reference fixes band = 400, segment.py:45, utils.py:161). A read whose half band
+ * min(band / 2, columns / 2) exceeds that -- band > 447 AND more than 447 lattice columns -- takes a generic kernel in the
+ * same batch (wide_band.hip: one workgroup per read, rows of up to 4 096 band columns in LDS, the reference's own
+ * arithmetic in every cell: Z bit for bit; align, the Z-only call and train alike; a fraction of the tuned sweeps' rate).
+ * Only a half band above 2 046 is refused, per read: DYN_READ_BAND_TOO_WIDE. device < 0 -> current HIP device. */
 int dyn_aligner_create(const char* model_path, int pore, const char* mode, int threads,
                        uint64_t band, int device, dyn_aligner** out, char* err, uint64_t errcap);
 /* The lattice pool of a destroyed handle (up to ~100 GB; allocating or freeing that much takes seconds) is PARKED per

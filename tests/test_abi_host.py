@@ -54,18 +54,19 @@ def test_constructor_errors_match_reference(models):
     # answers is pinned by G11 on the GPU box (tests/test_gpu_parity.py)
     for mode in ("resquiggle", "ntk", "basic", "nt"):
         Aligner(models["syn5"], "rna002", mode=mode, device="host").close()
-    # band: any value constructs, as in the reference (aligner.cpp:21). The kernels hold 448 band slots per lattice row: what
-    # a band above 447 costs is a per-read status for the reads whose half band min(band / 2, columns / 2) exceeds 223
-    for band in (447, 448, 1000, 10 ** 6):
+    # band: any value constructs, as in the reference (aligner.cpp:21). The register sweeps hold 448 band slots per lattice row;
+    # reads whose half band min(band / 2, columns / 2) exceeds their 223 take the generic kernel (4 096 band columns per row:
+    # half bands up to 2 046), and only beyond THAT a read gets a per-read status
+    for band in (447, 448, 1000, 4093, 4094, 10 ** 6):
         al = Aligner(models["syn5"], "rna002", band=band, device="host")
-        assert al.info.half_band == band // 2 and al.info.max_half_band == 223
-        seqs = ["ACGTA" * 20, "ACGTA" * 90, "ACGTA" * 91, "ACGTA" * 400]      # 96, 446, 451, 1 996 k-mers
-        status, _, _ = al.validate([5000] * 4, seqs)
-        wide = [0, 0, 11, 11] if band // 2 > 223 else [0, 0, 0, 0]       # 447 columns: half band 223; 452: 226
+        assert al.info.half_band == band // 2 and al.info.max_half_band == 2046
+        seqs = ["ACGTA" * 20, "ACGTA" * 90, "ACGTA" * 91, "ACGTA" * 400, "ACGTA" * 819, "ACGTA" * 820]   # .. 1 996, 4 091, 4 096 k-mers
+        status, _, _ = al.validate([10000] * 6, seqs)
+        wide = [0, 0, 0, 0, 0, 11] if band // 2 > 2046 else [0] * 6       # 4 092 columns: half band 2 046; 4 097: 2 048
         assert list(status) == wide, (band, list(status))
         al.close()
     from dynamont_amd._dynamont import read_error_message
-    assert read_error_message(11) == "Band wider than this build's 448 band slots for a read of this length"
+    assert read_error_message(11) == "Band wider than this build's 4096 band columns for a read of this length"
 
 
 @pytest.mark.parametrize("pore,key", [("rna002", "syn5"), ("rna004", "syn9"), ("dna_r9", "syn5"),

@@ -840,26 +840,28 @@ def test_g11_ntk_mode_answers_like_the_reference(models):
 
 
 
-def test_band_above_447_short_reads_equal_the_oracle_long_reads_get_their_status(models):
+def test_band_above_447_short_reads_equal_the_oracle_and_long_reads_take_the_generic_kernel(models):
     """The reference takes any band (aligner.cpp:21). A handle created with band 1 000 computes every read whose half band
-    min(band / 2, columns / 2) fits the kernels' 448 band slots -- here reads of 60 .. 446 k-mers, for the longer of which
-    (402+ columns) the band is WIDER than at band 400 -- exactly as the oracle does at band 1 000, train() included; a read
-    with more columns gets DYN_READ_BAND_TOO_WIDE and leaves the others alone."""
+    min(band / 2, columns / 2) fits the register sweeps' 448 band slots -- here reads of 60 .. 446 k-mers, for the longer of
+    which (402+ columns) the band is WIDER than at band 400 -- exactly as the oracle does at band 1 000, train() included. A read
+    with more columns (half band 348 here) takes the generic kernel (wide_band.hip) IN THE SAME BATCH: the reference's own
+    arithmetic in every cell, so its Z has the oracle's bits."""
     model = models["syn5"]
     _, mean, sd = synth.read_model_file(model)
     reads = synth.make_reads(515, 40, "rna002", mean, sd, (64, 450))
     reads += synth.make_reads(516, 12, "rna002", mean, sd, (430, 450))     # 426 .. 446 k-mers: half band 213 .. 223
     long_read = synth.make_reads(517, 1, "rna002", mean, sd, 700)[0]
     al = Aligner(model, "rna002", band=1000, device=0)
+    assert al.info.max_half_band == 2046
     orc = Oracle(model, synth.PORES["rna002"][0], 1000)
     sigs, seqs = [r.signal for r in reads] + [long_read.signal], [r.sequence for r in reads] + [long_read.sequence]
     res = al.align_batch(sigs, seqs, True)
-    assert res.status[-1] == 11 and res.error(len(reads)) == "Band wider than this build's 448 band slots for a read of this length"
-    for i, r in enumerate(reads):
+    for i, r in enumerate(reads + [long_read]):
         assert res.status[i] == 0, (i, res.error(i))
         got, want = res.read(i), orc.align(r.signal, r.sequence, True)
         assert np.array_equal(got["signal_positions"], want["signal_positions"]) and np.array_equal(got["sequence_positions"], want["sequence_positions"]), i
         assert np.abs(got["probabilities"] - want["probabilities"]).max() <= 1e-6 and abs(got["Z"] - want["Z"]) <= 1e-9 * abs(want["Z"])
+    assert res.read(len(reads))["Z"] == orc.align(long_read.signal, long_read.sequence, True)["Z"]   # the wide read: bit for bit
     # the wider band is a different computation for the reads above 401 columns: more lattice cells in the launch
     wide = [r for r in reads if len(r.sequence) - 4 + 1 > 401]
     cells = {}
@@ -872,7 +874,67 @@ def test_band_above_447_short_reads_equal_the_oracle_long_reads_get_their_status
             h.close()
     assert len(wide) >= 12 and cells[1000] > cells[400]
     tr = al.train_batch(sigs, seqs)
-    assert tr.status[-1] == 11 and (tr.status[:-1] == 0).all()
+    assert (tr.status == 0).all()
+    al.close()
+
+
+@pytest.mark.parametrize("pore,band", [("rna004", 600), ("rna004", 894), ("dna_r10_400bps", 1000), ("rna002", 4093)])
+def test_any_band_long_reads_equal_the_oracle_bit_for_bit(models, pore, band):
+    """Reads of 900 .. 2 600 bases under bands the register sweeps cannot hold (half band 300 .. 1 300): the generic kernel's
+    borders, Z BITS (forward and backward are the reference's operation by operation), posteriors, the Z-only call and
+    train() against the oracle at the same band -- among them reads that START with a structural tie (the polyA pad followed by
+    A's), where the reference's choice rests on the last bits of its logPlus. Asynchronous tickets take the same path (no
+    resident session for them)."""
+    model = model_for(models, pore)
+    _, mean, sd = synth.read_model_file(model)
+    lengths = (900, 2600) if band < 4000 else (2500, 2600)
+    reads = synth.make_reads(5200 + band, 4 if band < 4000 else 2, pore, mean, sd, lengths)
+    if "rna" in pore:
+        reads += synth.make_reads(5300 + band, 2 if band < 4000 else 1, pore, mean, sd, (1000, 1200), polya=(20, 60))
+    al = Aligner(model, pore, band=band, device=0)
+    orc = Oracle(model, synth.PORES[pore][0], band)
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    res = al.align_batch(sigs, seqs, True)
+    t = al.align_async(*synth.pack_reads(reads), True)
+    res_async = t.wait()
+    assert t.timing()["launches"] == 1
+    zonly = al.align_batch(sigs, seqs, False)
+    tr = al.train_batch(sigs, seqs)
+    for i, r in enumerate(reads):
+        want = orc.align(r.signal, r.sequence, True)
+        for got_res in (res, res_async):
+            assert got_res.status[i] == 0, (i, got_res.error(i))
+            got = got_res.read(i)
+            assert np.array_equal(got["signal_positions"], want["signal_positions"]), i
+            assert np.array_equal(got["sequence_positions"], want["sequence_positions"]), i
+            assert got["Z"] == want["Z"], (i, got["Z"], want["Z"])
+            assert np.abs(got["probabilities"] - want["probabilities"]).max() <= 1e-6
+        assert zonly.status[i] == 0 and zonly.Z[i] == want["Z"] and zonly.n_segments[i] == 0
+        wt = orc.train(r.signal, r.sequence, dense=False)
+        assert tr.status[i] == 0 and tr.Z[i] == wt["Z"]
+        assert abs(tr.transitions[3 * i] - wt["m1"]) <= 1e-8 and abs(tr.transitions[3 * i + 2] - wt["e2"]) <= 1e-8
+        a0, cnt = int(tr.em_offsets[i]), int(tr.em_count[i])
+        codes = tr.em_code[a0:a0 + cnt]
+        assert cnt > 100 and np.allclose(tr.em_weight[a0:a0 + cnt], wt["weight"][codes], rtol=1e-7, atol=1e-9)
+        assert np.allclose(tr.em_sum[a0:a0 + cnt], wt["sum"][codes], rtol=1e-7, atol=1e-9)
+    t.close()
+    al.close()
+
+
+def test_band_beyond_the_generic_kernels_rows_is_a_per_read_status(models):
+    """4 096 band columns per row is what the generic kernel holds in LDS: a read whose half band exceeds 2 046 (band > 4 093
+    AND more than 4 093 lattice columns) gets DYN_READ_BAND_TOO_WIDE and leaves the others alone."""
+    model = models["syn5"]
+    _, mean, sd = synth.read_model_file(model)
+    reads = synth.make_reads(5400, 3, "dna_r9", mean, sd, (300, 600))
+    huge = synth.make_reads(5401, 1, "dna_r9", mean, sd, 4300, dwell=3.0)[0]
+    al = Aligner(model, "dna_r9", band=5000, device=0)
+    orc = Oracle(model, synth.PORES["dna_r9"][0], 5000)
+    res = al.align_batch([r.signal for r in reads] + [huge.signal], [r.sequence for r in reads] + [huge.sequence], True)
+    assert res.status[-1] == 11 and res.error(3) == "Band wider than this build's 4096 band columns for a read of this length"
+    for i, r in enumerate(reads):
+        want = orc.align(r.signal, r.sequence, True)
+        assert res.status[i] == 0 and np.array_equal(res.read(i)["signal_positions"], want["signal_positions"])
     al.close()
 
 
