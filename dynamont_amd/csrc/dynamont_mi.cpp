@@ -185,6 +185,17 @@ size_t parked_bytes(int device) {
   return n;
 }
 
+// give back what destroyed handles have parked on `device` (their pools are this process's to use, for whatever needs the room)
+void free_parked(int device) {
+  if (device < 0 || device >= PARK_DEVICES) return;
+  std::lock_guard<std::mutex> lk(g_park_m);
+  for (int k = 0; k < PARK_KINDS; ++k)
+    if (g_park[device][k].p) {
+      (void)hipFree(g_park[device][k].p);
+      g_park[device][k] = ParkedBuf{};
+    }
+}
+
 // grow `b` to at least `want` bytes: a parked buffer that is large enough, else a fresh allocation (after the parked
 // one has been freed: its memory may be what the larger buffer needs)
 hipError_t ensure_pool_buffer(int device, int kind, DevBuf& b, size_t want, double headroom) {
@@ -1547,7 +1558,7 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   if (!wide.empty()) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t room = (uint64_t)((double)(free_b + b->d_wide.bytes) * 0.8);
+    const uint64_t room = (uint64_t)((double)(free_b + b->d_wide.bytes + parked_bytes(a->device)) * 0.8);
     size_t wr = 0;
     for (uint32_t i : wide) {
       const HostRead& r = b->reads[i];
@@ -1633,7 +1644,13 @@ int enqueue_job(dyn_batch* b, DynJob job) {
   if (!wide.empty()) {
     // one workgroup per wide read at a time, each with a lattice arena for the largest of them; behind the read queue on the
     // compute stream (its results feed the same per-segment kernels / the same host finalisation)
-    HIP_TRY(a, b->d_wide.ensure(256 + (uint64_t)wide_groups * wide_arena));
+    {
+      const uint64_t want = 256 + (uint64_t)wide_groups * wide_arena;
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(a, hipMemGetInfo(&free_b, &total_b));
+      if (want > b->d_wide.bytes && want > (uint64_t)((double)free_b * 0.95)) free_parked(a->device);  // (counted as room above)
+      HIP_TRY(a, b->d_wide.ensure(want));
+    }
     dynk::WideArgs wa{};
     wa.descs = q.descs + n_ok;
     wa.n_reads = (int)wide.size();

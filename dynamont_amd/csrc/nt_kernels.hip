@@ -111,6 +111,45 @@ __device__ __forceinline__ void store_row_f64(double* __restrict__ row, int lane
   else row[384 + lane] = x[6];
 }
 
+// ---- out-of-band lanes (experiment DYN_SKIP_OOB) -------------------------------------------------
+// A row holds P = 448 slots for the 2 bw + 1 <= 401 cells of the band: the other >= 47 slots -- 6.7 lanes of the blocked
+// layout, more than half the wave for reads shorter than the band is wide -- carry "no k-mer" cells whose values nobody
+// needs. The lanes that hold NOTHING of a window of the slot ring skip their row stores and their part of the ring DMA.
+// lanes_of_window: the lanes that hold at least one slot of the lattice columns [c0, c0 + len).
+__device__ __forceinline__ uint64_t lanes_of_window(int c0, int len) {
+  const int s0 = pmod(c0);
+  const int l0 = s0 / CPL;
+  const int n = (s0 + len - 1) / CPL - l0 + 1;   // lanes touched (slots s and s - P share a lane: P = 64 CPL)
+  if (n >= 64) return ~0ull;
+  const uint64_t m = (1ull << n) - 1ull;
+  return l0 ? ((m << l0) | (m >> (64 - l0))) : m;
+}
+// a wave-uniform 64-bit value the compiler holds in vector registers (everything derived from band_mid is): into scalar ones
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi32 << 32) | lo32;
+}
+// the half-wave instruction of a row (register 6 of lanes 2l, 2l + 1 comes from lane l < 32): lane l takes part when either does
+__device__ __forceinline__ uint64_t half_mask_of(uint64_t live) {
+  uint64_t x = (live | (live >> 1)) & 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+  x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+  x = (x | (x >> 16)) & 0x00000000ffffffffull;
+  return x;
+}
+#ifdef DYN_SKIP_OOB
+constexpr bool SKIP_OOB = true;
+#else
+constexpr bool SKIP_OOB = false;
+#endif
+// Rows are fetched RING_D + 1 rows ahead of the row that decides the forward sweep's mask, and the band moves at most one
+// column per row: the backward sweep stores the lanes of the band widened by OOB_SLACK columns on either side, the forward
+// sweep fetches those of [lo, lo + W + OOB_SLACK) -- always inside what was stored, always containing the fetched row's band.
+constexpr int OOB_SLACK = 5;
+
 // size_t(t * RATIO): one IEEE fp64 multiply, then truncation (NT_aligner_api.cpp:100).
 __device__ __forceinline__ int band_mid(int t, double ratio) {
   return (int)__dmul_rn((double)t, ratio);
@@ -340,6 +379,21 @@ __device__ __forceinline__ void ring_dma_row(const double* row_lane_ptr, unsigne
       : "memory");
 }
 
+// the same for the lanes of `live` only (`half` = half_mask_of(live)); the others' ring slots keep what they held
+__device__ __forceinline__ void ring_dma_row_masked(const double* row_lane_ptr, unsigned lds_slot_addr, uint64_t live, uint64_t half) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_mov_b64 exec, %2\n\t"
+      "global_load_lds_dwordx4 %0, off" DYN_DMA_MOD "\n\t"
+      "global_load_lds_dwordx4 %0, off offset:1024" DYN_DMA_MOD "\n\t"
+      "global_load_lds_dwordx4 %0, off offset:2048" DYN_DMA_MOD "\n\t"
+      "s_mov_b64 exec, %3\n\t"
+      "global_load_lds_dwordx4 %0, off offset:3072" DYN_DMA_MOD "\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      ::"v"(row_lane_ptr), "s"(__builtin_amdgcn_readfirstlane(lds_slot_addr)), "s"(live), "s"(half)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -394,6 +448,9 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
 
   bool bad_sample = false;
   int lo = band_mid(T - 1, ratio) - bw;
+  // DYN_SKIP_OOB: the lanes whose row stores count (align jobs: the forward sweep fetches exactly these or fewer)
+  constexpr bool MASKED = SKIP_OOB && STORE && ARITH != ARITH_FOLDED;
+  uint64_t store_mask = MASKED ? uniform_u64(lanes_of_window(lo - OOB_SLACK, W + 2 * OOB_SLACK)) : ~0ull;
   const int n_init = lo + bw;  // band column bw+1 of row T-1 (NT_aligner_api.cpp:170)
   int n[CPL];
   double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], e[CPL];
@@ -468,6 +525,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
           }
         }
         lo = new_lo;
+        if constexpr (MASKED) store_mask = uniform_u64(lanes_of_window(lo - OOB_SLACK, W + 2 * OOB_SLACK));
       }
 #pragma unroll
       for (int j = 0; j < CPL; ++j) x1[j] = Yr[j] + m1;
@@ -498,7 +556,11 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
         for (int j = 0; j < CPL; ++j) ls[j] = x2[j] - bE_out[j];
         store_row_f64<true>(out + rt, lane, ls);
       } else if (STORE) {
-        store_row_f64<true>(out + rt, lane, bE_out);
+        if constexpr (MASKED) {
+          if (__builtin_amdgcn_inverse_ballot_w64(store_mask)) store_row_f64<true>(out + rt, lane, bE_out);
+        } else {
+          store_row_f64<true>(out + rt, lane, bE_out);
+        }
       }
     };
     int i = 63;
@@ -587,6 +649,27 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   // (log_norm = -inf), hence e = -inf, hence fM = fE = LPM = LPE = vM = vE = -inf in that slot with
   // no select in the row loop. Both hand-overs happen in the rare block that looks one row ahead.
   int lo = band_mid(1, ratio) - bw;  // band of row 1 (column 0 of row 0 is inside: band_mid(1) <= 1 <= bw)
+  // DYN_SKIP_OOB: lanes whose part of a row is fetched (rows up to RING_D + 1 ahead) / whose posteriors of a row are stored
+  // (the row's band, whichever side of the hand-over `lo` is on when the stores are issued)
+  constexpr bool MASKED = SKIP_OOB && POST;
+  uint64_t dma_mask = ~0ull, dma_half = 0xffffffffull, out_mask = ~0ull;
+  auto set_masks = [&]() {
+    if constexpr (MASKED) {
+      dma_mask = uniform_u64(lanes_of_window(lo, W + OOB_SLACK));
+      dma_half = half_mask_of(dma_mask);
+      out_mask = uniform_u64(lanes_of_window(lo - 1, W + 1));
+    }
+  };
+  set_masks();
+  if constexpr (MASKED) {
+    // lanes that fetch nothing of a row read what their ring slots held before: that must be a harmless number (-inf here;
+    // later, values of rows they did fetch), never the ballot words the previous read's traceback staged in this ring
+    // (a NaN pattern in a slot outside the band would travel into its in-band neighbour through the Viterbi values)
+    auto* ringp = (__attribute__((address_space(3))) double*)(size_t)ring_base;
+#pragma unroll
+    for (int k = 0; k < RING_D * P / 64; ++k) ringp[k * 64 + lane] = NEG_INF;
+    wave_lds_sync_local();
+  }
   int n[CPL];
   // The loop-carried values of a row. The row loop is unrolled by two and ping-pongs between two of these:
   // with one set, "new" values are computed while the "old" ones are still live and hipcc closes every
@@ -636,8 +719,10 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   // ring prologue: rows 2 .. RING_D+1 (row r lives in ring slot r % RING_D)
   const double* __restrict__ dma_src = ws_rd + lane * 2;
   if (POST) {  // rows past T repeat the all -inf row T (backward sweep): RING_D rows are always in flight
-    for (int r = 2; r <= RING_D + 1; ++r)
-      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
+    for (int r = 2; r <= RING_D + 1; ++r) {
+      if constexpr (MASKED) ring_dma_row_masked(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES, dma_mask, dma_half);
+      else ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(r, T)) * P, ring_base + (r % RING_D) * ROW_BYTES);
+    }
   }
 
   // one lattice row: reads the state `in` (row t-1), writes `out` (row t)
@@ -651,7 +736,10 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
       // one hand-counted s_waitcnt serves the whole loop, tail included)
       wait_vmcnt<RING_WAIT>();
       ring_read_row(ring_base + ((t + 1) % RING_D) * ROW_BYTES, lane, out.b);
-      ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
+      if constexpr (MASKED)
+        ring_dma_row_masked(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES, dma_mask, dma_half);
+      else
+        ring_dma_row(dma_src + (size_t)cur_dma.at(w, min(t + 1 + RING_D, T)) * P, ring_base + ((t + 1) % RING_D) * ROW_BYTES);
     }
     from_left(in.fE, fEl);
     if (POST) from_left(in.vE, vEl);
@@ -672,6 +760,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
           if (n[j] == lo + W) set_p(j, entering, strict_tag);  // first band row of this column is t+1
         }
         lo = next_lo;
+        set_masks();
       }
     }
     double a1[CPL], a2[CPL];
@@ -728,7 +817,10 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
       const uint32_t prow = cur_out.at(w, t);
       const size_t rt = (size_t)prow * P;
       // read again only by the traceback, one cell per row: non-temporal; same pairing as the bE rows
-      if (INPLACE) {
+      const bool out_live = MASKED ? __builtin_amdgcn_inverse_ballot_w64(out_mask) : true;
+      if (!out_live) {
+        // (DYN_SKIP_OOB: nothing of this lane lies in the row's band)
+      } else if (INPLACE) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           dyn_f4 v4;
