@@ -16,7 +16,7 @@ run() { name=$1; shift; [[ $name =~ $ONLY ]] || return 0; echo "== $name"; timeo
 # (round 4) the bench's default is strict mode "ties": launches of the MIXED kernel k_read_queue<JOB_ALIGN, true>. The sub-records
 # (plain_arithmetic, e2e_cli) are switched off so that every launch in a profile belongs to the headline region; the plain
 # kernel k_read_queue<JOB_ALIGN, false> is profiled by its own runs (--strict off).
-X="--no-cpu-baseline --no-plain --no-e2e"
+X="--no-cpu-baseline --no-plain --no-e2e --no-short --no-train --no-cfg3 --no-cold"
 # stats runs: no warm-up, no resident leg -- every k_read_queue launch of the process belongs to the timed region, so that
 # rocprofv3's Calls / TotalDurationNs are the bench line's roofline.launches / kernel_ms_total (the engine merges tickets
 # that wait into one launch: launches differ in size, the totals are what has to agree)
