@@ -43,6 +43,12 @@ int hip_fail(dyn_batch* b, hipError_t e, const char* what) {
     if (_e != hipSuccess) return hip_fail((b), _e, #expr);    \
   } while (0)
 
+// a copy of the handle's last error text (written under err_mu by whichever thread failed)
+static std::string last_error_of(dyn_aligner* a) {
+  std::lock_guard<std::mutex> lk(a->err_mu);
+  return a->last_error;
+}
+
 // DYN_TRACE_HOST=1: wall time of the pipeline stages of every batch on stderr
 const bool g_trace = std::getenv("DYN_TRACE_HOST") != nullptr;
 double now_ms() {
@@ -86,7 +92,12 @@ Pipeline::~Pipeline() {
 
 void Pipeline::submit(dyn_batch* b) {
   {
-    std::lock_guard<std::mutex> lk(m);
+    std::unique_lock<std::mutex> lk(m);
+    // Completion words of resident tickets are a ring of SESSION_FLAGS entries (pinned host memory): a caller that kept
+    // that many tickets in flight would have a word reused while its first owner still waits on it. Back-pressure, not an
+    // error: the submit waits until the pipeline has completed enough (no realistic caller gets here: a ticket in flight
+    // holds its batch's buffers).
+    cv_done.wait(lk, [&] { return in_flight + 8 < SESSION_FLAGS; });
     q_front.push_back(b);
     ++in_flight;
     peak_in_flight = std::max(peak_in_flight, in_flight);
@@ -346,7 +357,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   int rc = host_prepare(b, a->model, true, n, b->in_sig_offsets, b->in_seqs, b->in_seq_offsets, &helpers);
   const double t1 = now_ms();
   if (rc != DYN_OK) {
-    b->error = a->last_error;
+    b->error = last_error_of(a);
     return rc;
   }
   const uint64_t total_sig = n ? b->in_sig_offsets[n] - b->in_sig_offsets[0] : 0;
@@ -354,7 +365,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   const double t2 = now_ms();
   rc = alloc_batch_buffers(b, total_sig);
   if (rc != DYN_OK) {
-    b->error = a->last_error;
+    b->error = last_error_of(a);
     return rc;
   }
   const double t3 = now_ms();
@@ -473,7 +484,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   rc = session_plan(b, &resident);
   if (rc == DYN_OK && !resident) rc = session_quiesce(a);
   if (rc != DYN_OK) {
-    b->error = a->last_error;
+    b->error = last_error_of(a);
     return rc;
   }
   hipStream_t s_pre = resident ? a->s_in : a->stream;
@@ -493,7 +504,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   }
   if (resident) {
     rc = session_publish(b);
-    if (rc != DYN_OK) b->error = a->last_error;
+    if (rc != DYN_OK) b->error = last_error_of(a);
     if (g_trace)
       std::fprintf(stderr, "[dyn] front %p: start %.2f prepare %.2f lock %.2f alloc %.2f h2d %.2f publish %.2f ms (resident)\n", (void*)b, t0, t1 - t0,
                    t2 - t1, t3 - t2, t4 - t3, now_ms() - t4);
@@ -501,7 +512,7 @@ int Pipeline::front_stage(dyn_batch* b) {
   }
   rc = enqueue_job(b, b->job);  // records ev_done behind the batch's last kernel
   if (rc != DYN_OK) {
-    b->error = a->last_error;
+    b->error = last_error_of(a);
     return rc;  // front_loop drains the streams of a failed batch
   }
   P_TRY(b, hipStreamWaitEvent(a->s_out, b->ev_done, 0));
@@ -600,7 +611,7 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
       bool again = false;
       rc = session_recover(b, &again);
       if (rc != DYN_OK) {
-        b->error = a->last_error;
+        b->error = last_error_of(a);
         return rc;
       }
       if (!again) break;  // complete after all
@@ -611,7 +622,7 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
     rc = session_finish_enqueue(b, a->s_out);
     if (g_trace) std::fprintf(stderr, "[dyn] back  %p: resident ticket complete after %.2f ms, finish enqueued in %.2f ms\n", (void*)b, f0 - t0, now_ms() - f0);
     if (rc != DYN_OK) {
-      b->error = a->last_error;
+      b->error = last_error_of(a);
       return rc;
     }
     const uint64_t n = b->n;
@@ -626,7 +637,7 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
   const double t1 = now_ms();
   rc = b->in_session ? session_collect_timing(b) : collect_timing(b);
   if (rc != DYN_OK) {
-    b->error = a->last_error;
+    b->error = last_error_of(a);
     return rc;
   }
   const ReadState* st = b->h_state.as<ReadState>();

@@ -76,7 +76,7 @@ hipError_t BufCache::take(bool pinned, size_t want, void** p, size_t* got) {
   }
   const size_t ask = round_up(want);
   hipError_t e = pinned ? hipHostMalloc(p, ask, hipHostMallocDefault) : hipMalloc(p, ask);
-  if (e != hipSuccess) {  // give everything cached back to the runtime and try once more
+  if (e != hipSuccess && !(session_open && session_open->load())) {  // give everything cached back to the runtime and try once more
     (void)hipGetLastError();
     purge();
     e = pinned ? hipHostMalloc(p, ask, hipHostMallocDefault) : hipMalloc(p, ask);
@@ -388,11 +388,16 @@ void copy_msg(char* buf, uint64_t cap, const std::string& s) {
   buf[n] = 0;
 }
 
+// (last_error is written under err_mu: the pipeline's back thread runs session_finish_enqueue / collect_timing without the
+// handle's lock, while the front thread and the caller's thread report their own failures)
 #define HIP_TRY(a, expr)                                                                  \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
     if (_e != hipSuccess) {                                                               \
-      (a)->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr; \
+      {                                                                                   \
+        std::lock_guard<std::mutex> _elk((a)->err_mu);                                    \
+        (a)->last_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr; \
+      }                                                                                   \
       return _e == hipErrorOutOfMemory ? DYN_ERR_OUT_OF_MEMORY : DYN_ERR_DEVICE;          \
     }                                                                                     \
   } while (0)
@@ -508,7 +513,7 @@ int host_prepare(dyn_batch* b, const PoreModel& m, bool pinned, uint64_t n, cons
   return DYN_OK;
 }
 
-int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig) {
+static int alloc_batch_buffers_once(dyn_batch* b, uint64_t total_sig) {
   dyn_aligner* a = b->a;
   HIP_TRY(a, b->d_sig.ensure(std::max<uint64_t>(8, total_sig * 8)));
   HIP_TRY(a, b->d_kmers.ensure(std::max<uint64_t>(4, b->total_cols * 4)));
@@ -517,6 +522,20 @@ int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig) {
   HIP_TRY(a, b->d_rows.ensure(std::max<uint64_t>(sizeof(SegRow), b->capacity * sizeof(SegRow))));
   HIP_TRY(a, b->h_state.ensure(std::max<uint64_t>(sizeof(ReadState), b->n * sizeof(ReadState))));
   return DYN_OK;
+}
+
+// (caller holds a->mu) While a session is open the buffer cache does not free anything to make room (BufCache::session_open):
+// out of memory then means: let the resident waves finish what is published, leave, THEN purge and allocate.
+int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig) {
+  dyn_aligner* a = b->a;
+  int rc = alloc_batch_buffers_once(b, total_sig);
+  if (rc == DYN_ERR_OUT_OF_MEMORY && a->sess_open_hint.load()) {
+    (void)hipGetLastError();
+    if (int q = session_quiesce(a)) return q;
+    a->cache.purge();
+    rc = alloc_batch_buffers_once(b, total_sig);
+  }
+  return rc;
 }
 
 }  // namespace dyneng
@@ -592,6 +611,7 @@ void park_masked_stream(int device, hipStream_t s) {
 
 static void park_session_stream(dyn_aligner* a) {
   if (!a->s_session) return;
+  a->sess_enabled.store(false);
   dyneng::park_masked_stream(a->device, a->s_session);
   a->s_session = nullptr;
 }
@@ -609,6 +629,7 @@ static int make_session_stream(dyn_aligner* a, int reserved_cus) {
     a->sess_flags = nullptr;
     return DYN_ERR_DEVICE;
   }
+  a->sess_enabled.store(true);
   return DYN_OK;
 }
 
@@ -700,6 +721,7 @@ int dyn_aligner_create(const char* model_path, int pore, const char* mode, int t
   }
   a->device = device;
   a->cache.device = device;
+  a->cache.session_open = &a->sess_open_hint;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
   if (trace_create) std::fprintf(stderr, "[dyn] create: HIP runtime up (hipSetDevice) at %.1f ms\n", tc_ms());
   if ((e = hipDeviceGetAttribute(&a->n_cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail(e, "hipDeviceGetAttribute");
@@ -1713,6 +1735,7 @@ int collect_timing(dyn_batch* b) {
   // wave-cycles per phase, summed over all waves of the launch: backward, forward, traceback (+ state
   // write-back and page release), waiting for a read / for pages, lifetime; [5] = longest lifetime
   if (b->h_stats.as<uint32_t>()[3] != 0) {
+    std::lock_guard<std::mutex> elk(a->err_mu);
     a->last_error = "the read queue aborted: a wave waited for the queue lock or for lattice pages for seconds";
     return DYN_ERR_DEVICE;
   }
@@ -1788,13 +1811,6 @@ int session_collect(dyn_aligner* a, int blk) {
   return DYN_OK;
 }
 
-// what a session is launched with (session_choose)
-struct SessionGeom {
-  bool ok = false;
-  int layout = 0, log_r = 8;
-  uint32_t arena_pages = 0;   // layout 0: per wave; paged: the most one read may need
-  uint32_t n_pages = 0;       // of the pool
-};
 
 int session_open(dyn_aligner* a, bool mixed, const SessionGeom& g) {
   const int log_r = g.log_r;
@@ -1883,7 +1899,7 @@ bool session_candidate(const dyn_batch* b) {
   // waves; those statistics are computed on demand since (dyn_batch_device_pooled). Then, with nothing following a training
   // ticket, sessions measured 805.6 / 810.5 against 810.7 / 813.9 Msamp/s for one launch per batch: 1 024 reads on 1 024
   // waves keep a launch's waves busy 0.98 of it already. Training stays one launch per batch.
-  return a->s_session && !a->host_only && !a->ntk && b->async && b->job == DynJob::AlignFull &&
+  return a->sess_enabled.load() && !a->host_only && !a->ntk && b->async && b->job == DynJob::AlignFull &&
          (a->sess_open_hint.load() || b->n >= SESSION_MIN_READS);
 }
 
@@ -1979,6 +1995,7 @@ static bool session_fits(const dyn_aligner* a, const Session& ss, const SessionN
 int session_plan(dyn_batch* b, bool* use) {
   dyn_aligner* a = b->a;
   *use = false;
+  b->sess_geom = SessionGeom{};
   if (!session_candidate(b)) return DYN_OK;
   if (b->n_wide) return DYN_OK;  // wide-band reads take the generic kernel behind a classic launch
   const SessionNeed need = session_need(b);
@@ -1995,6 +2012,9 @@ int session_plan(dyn_batch* b, bool* use) {
   SessionGeom g;
   if (int rc = session_choose(a, b, need, &g)) return rc;
   *use = g.ok;  // (false: the longest read does not fit the pool at all -- the planned classic launch)
+  // the geometry is decided ONCE: session_publish opens the session with it (a second look at hipMemGetInfo could disagree
+  // with this one -- another process, the buffer cache -- and leave an accepted ticket without a session)
+  b->sess_geom = g;
   return DYN_OK;
 }
 
@@ -2028,8 +2048,10 @@ int session_publish(dyn_batch* b) {
     SessionNeed need;
     need.n_ok = n_ok;
     need.max_S = max_S;
-    SessionGeom g;
-    if (int rc = session_choose(a, b, need, &g)) return rc;
+    SessionGeom g = b->sess_geom;  // session_plan's (the open session it may have counted on has been closed since: its own)
+    if (!g.ok) {
+      if (int rc = session_choose(a, b, need, &g)) return rc;
+    }
     if (!g.ok) {
       a->last_error = "session_publish: no session geometry for a ticket session_plan had accepted";
       return DYN_ERR_RUNTIME;

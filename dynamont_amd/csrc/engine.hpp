@@ -46,6 +46,10 @@ struct BufCache {
   // next). Bounded; dyn_release_cached_memory() frees what is parked, DYN_NO_POOL_CACHE=1 switches parking off.
   void park(int device);
   int device = -1;  // set by the handle: take() looks at the device's parked buffers before it allocates
+  // set by the handle: true while a resident session is open. purge() frees with hipFree, which waits for the whole device --
+  // i.e. for resident waves that only leave when the handle (whose lock the caller of take() holds) closes their session. An
+  // allocation that fails meanwhile is reported; alloc_batch_buffers quiesces the session, purges and tries again.
+  const std::atomic<bool>* session_open = nullptr;
 };
 
 struct DevBuf {
@@ -160,6 +164,8 @@ struct dyn_aligner {
   dyneng::DevBuf sess_ctl[2], sess_ring[2];
   dyneng::DevBuf sess_anchor;        // out_base of k_session: the address the ticket records' output offsets count from
   std::atomic<bool> sess_open_hint{false};  // mirrors sess.open for readers that do not hold mu
+  std::atomic<bool> sess_enabled{false};    // mirrors s_session != nullptr likewise (the pipeline's front thread asks under ITS lock)
+  std::mutex err_mu;                        // last_error is written by the caller's thread AND by the pipeline threads
   uint32_t* sess_flags = nullptr;    // [SESSION_FLAGS] pinned, coherent
   dyneng::PinnedBuf sess_hctl;       // D2H target of a control block
   dyneng::Session sess;
@@ -168,6 +174,16 @@ struct dyn_aligner {
   // the idle watchdog of the resident waves, seconds (DYN_SESSION_IDLE_S)
   double sess_idle_s = 20.0;
 };
+
+namespace dyneng {
+// what a session is launched with (session_choose, dynamont_mi.cpp)
+struct SessionGeom {
+  bool ok = false;
+  int layout = 0, log_r = 8;
+  uint32_t arena_pages = 0;   // layout 0: per wave; paged: the most one read may need
+  uint32_t n_pages = 0;       // of the pool
+};
+}  // namespace dyneng
 
 struct HostRead {
   uint64_t S = 0, L = 0, kc = 0;
@@ -224,6 +240,7 @@ struct dyn_batch {
   dyneng::DevBuf d_norm, d_meta;
   dyneng::DevBuf d_wide;        // wide-band reads (wide_band.hip): queue head + one lattice arena per workgroup
   uint64_t n_wide = 0;          // reads of this batch that take the generic kernel
+  dyneng::SessionGeom sess_geom;  // session_plan's decision for this ticket (ok = false: none taken)
   bool has_raw = false;
   RawSource raw_src;
   std::vector<hipEvent_t> events;              // before / after the read queue / after the per-segment kernels

@@ -29,5 +29,7 @@ hipError_t launch_pool_stats(const ReadDesc*, int, uint32_t, const ReadState*, c
                              size_t, hipStream_t) {
   no_device("launch_pool_stats");
 }
+uint64_t wide_arena_bytes(uint64_t T, uint64_t bw, bool calc) { return T * (2 * bw + 3) * (16 + (calc ? 9 : 0)); }
+void launch_wide_reads(int, const WideArgs&, int, hipStream_t) { no_device("launch_wide_reads"); }
 
 }  // namespace dynk
