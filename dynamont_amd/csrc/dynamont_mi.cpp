@@ -1301,7 +1301,7 @@ extern "C" int dyn_session_order(uint64_t n_reads, uint32_t* order_out) {
   std::vector<uint32_t> order(n_reads);
   for (uint64_t k = 0; k < n_reads; ++k) order[k] = (uint32_t)k;
   dyneng::spread_order(order, dyneng::SESSION_TAIL_DIV);
-  std::memcpy(order_out, order.data(), n_reads * sizeof(uint32_t));
+  if (n_reads) std::memcpy(order_out, order.data(), n_reads * sizeof(uint32_t));  // (an empty vector's data() may be null)
   return DYN_OK;
 }
 
