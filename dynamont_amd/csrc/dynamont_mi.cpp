@@ -2074,7 +2074,17 @@ int session_publish(dyn_batch* b) {
       plan_queue(order, need, rows, ss.n_waves, ss.n_pages);
     } else {
       const char* tail_env = std::getenv("DYN_SESSION_TAIL_DIV");  // experiments: 0 = spread every read
+      std::vector<uint32_t> rank(b->n, 0);  // position in the longest-first order
+      for (size_t k = 0; k < order.size(); ++k) rank[order[k]] = (uint32_t)k;
       spread_order(order, tail_env ? std::atoi(tail_env) : SESSION_TAIL_DIV);
+      // The END of a ticket nobody follows (round 6): the last n_waves reads of the order are in flight together whatever their
+      // order -- each wave takes one -- so their pages are asked for together either way; taken LONGEST FIRST the long ones among
+      // them start as early as they can and the waves finish within a short read of each other, instead of one 100 k-sample read,
+      // claimed last, keeping 1 023 waves waiting for the session's close (config 3: ~5 % of an 8-batch run; measured A/B below).
+      if (!std::getenv("DYN_SESSION_NO_TAIL_LPT") && order.size() > ss.n_waves) {
+        auto tail = order.end() - (ptrdiff_t)ss.n_waves;
+        std::stable_sort(tail, order.end(), [&](uint32_t x, uint32_t y) { return rank[x] < rank[y]; });
+      }
     }
   }
 
