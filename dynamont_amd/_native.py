@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # DYN_LIB_PATH: another build of the SAME sources (tools/sanitize: the host side under ASan / UBSan / TSan on the CPU)
 LIB_PATH = os.environ.get("DYN_LIB_PATH") or os.path.join(HERE, "libdynamont_mi.so")
-SOURCES = ["dynamont_mi.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "bam_reader.cpp", "rccl_comm.cpp", "model_format.cpp",
+SOURCES = ["dynamont_mi.cpp", "buffers.cpp", "launch.cpp", "session.cpp", "async_engine.cpp", "pore_model.cpp", "csv_format.cpp", "csv_sink.cpp", "vbz_decode.cpp", "bam_reader.cpp", "rccl_comm.cpp", "model_format.cpp",
            "nt_kernels.hip", "pool_stats.hip", "wide_band.hip"]
-HEADERS = ["engine.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
+HEADERS = ["engine.hpp", "engine_internal.hpp", "zstd_dl.hpp", "vbz_decode.hpp", "nt_kernels.hpp", "pore_model.hpp", "dp_math.hpp", "dp_math_strict.hpp", "strict_exp_table.inc", os.path.join("..", "..", "include", "dynamont_mi.h")]
 
 DYN_DEVICE_HOST_ONLY = -2
 DYN_OK, DYN_ERR_INVALID_ARGUMENT, DYN_ERR_RUNTIME, DYN_ERR_DEVICE, DYN_ERR_OUT_OF_MEMORY = range(5)

@@ -176,7 +176,7 @@ struct dyn_aligner {
 };
 
 namespace dyneng {
-// what a session is launched with (session_choose, dynamont_mi.cpp)
+// what a session is launched with (session_choose, session.cpp)
 struct SessionGeom {
   bool ok = false;
   int layout = 0, log_r = 8;
@@ -307,7 +307,7 @@ struct BatchGroup {
 
 namespace dyneng {
 
-// ---- shared between dynamont_mi.cpp and async_engine.cpp -------------------------------------
+// ---- shared between the engine's translation units (dynamont_mi.cpp, launch.cpp, session.cpp, async_engine.cpp) ----
 int need_device(dyn_aligner* a);
 // CU-masked streams (every CU enabled: a hardware queue of their own) are parked per device and reused, never destroyed
 // (dynamont_mi.cpp); nullptr when the runtime provides none. The session stream and a dyn_comm's stream come from here.
@@ -323,7 +323,7 @@ int host_prepare(dyn_batch* b, const dynhost::PoreModel& m, bool pinned, uint64_
 int alloc_batch_buffers(dyn_batch* b, uint64_t total_sig);
 // enqueue every kernel of `job` on the handle's compute stream without synchronising the host
 int enqueue_job(dyn_batch* b, DynJob job);
-// ---- resident read queue (dynamont_mi.cpp); all under a->mu ----
+// ---- resident read queue (session.cpp); all under a->mu ----
 // could this ticket run in a session at all? (before host_prepare: kind and size only)
 bool session_candidate(const dyn_batch* b);
 // After host_prepare: will the ticket be published into a session (the open one, or one opened for it)? Closes an open
