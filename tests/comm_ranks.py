@@ -111,7 +111,7 @@ def run_rank(scenario, rank, n, workdir, model):
             if rank == 1:
                 print("RESULT " + json.dumps(out), flush=True)
                 if scenario == "stall":
-                    time.sleep(20.0)   # alive, its sockets open, but never in the exchange: only the root's clock can tell
+                    time.sleep(9.0)    # alive, its sockets open, but never in the exchange: only the root's clock can tell
                 os._exit(0)   # no destructors, no ncclCommDestroy: a crashed rank
             t0 = time.time()
             buf = np.empty(int(cnt.sum()) + 1, dtype=RcclComm.ROW)

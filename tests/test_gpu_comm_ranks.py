@@ -94,12 +94,12 @@ def test_a_rank_that_dies_between_counts_and_rows_does_not_hang_the_root(models,
 
 def test_a_rank_that_never_arrives_costs_the_root_its_timeout_not_a_hang(models, tmp_path):
     """Rank 1 stays ALIVE (connections open: RCCL has no asynchronous error to report -- the situation of a peer over xGMI,
-    where no socket closes) but does not join the gather of rows for 20 s. Root gives up at DYN_COMM_TIMEOUT_S = 3 s."""
+    where no socket closes) but does not join the gather of rows for 9 s. Root gives up at DYN_COMM_TIMEOUT_S = 3 s."""
     _release_parked()
     outs = comm_ranks.launch("stall", 2, str(tmp_path / "w"), models["syn9"], timeout=240, extra={"DYN_COMM_TIMEOUT_S": "3"})
     for rc, res, err in outs:
         assert res is not None, err
     root = outs[0][1]
     assert root["die_rows_rc"] == DYN_ERR_DEVICE and "did not complete within" in root["die_msg"] and "aborted" in root["die_msg"], root
-    assert 2.5 < root["die_rows_s"] < 15.0
+    assert 2.5 < root["die_rows_s"] < 8.5
     assert root["die_after_rc"] == DYN_ERR_DEVICE and root["die_after_s"] < 1.0
