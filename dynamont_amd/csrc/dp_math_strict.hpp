@@ -384,6 +384,22 @@ DYN_HD double div_by_const(double a, double b, double y) {
   return fma_(r, y, q);
 }
 
+// The same quotient in FOUR operations (round 6). With y = RN(1/b) and y_lo = RN(RN(1 - y b) y) -- `recip_lo`: the residual
+// 1 - y b is exact in one FMA, |1 - y b| <= 2^-53 -- the pair (y, y_lo) carries 1/b to ~2^-104 relative, so
+//   q~ = fma(a, y, RN(a y_lo))
+// is a/b rounded ONCE up to ~2^-104 |a/b|: faithful for every a (it is RN(a/b) itself except for the handful of dividends per
+// divisor whose quotient lies within 2^-104 of a rounding midpoint -- which no run-time test tells apart for less than it
+// saves). One step of Markstein's iteration on a FAITHFUL quotient, r = a - q~ b (exact), q = RN(q~ + r y),
+// is RN(a/b) for every a (Handbook of Floating-Point Arithmetic, Thm. 4.9; same excluded divisor, same no-overflow condition
+// as above): mul, fma, fma, fma instead of mul, fma, fma, fma, fma.
+DYN_HD double recip_lo(double b, double y) { return fma_(-y, b, 1.0) * y; }
+DYN_HD double div_by_const4(double a, double b, double y, double y_lo) {
+  const double t = a * y_lo;
+  const double q = fma_(a, y, t);
+  const double r = fma_(-q, b, a);
+  return fma_(r, y, q);
+}
+
 // is the significand of b all ones? (the one case Markstein's theorem excludes)
 inline bool div_by_const_excluded(double b) { return (bits_of(b) & 0x000fffffffffffffull) == 0x000fffffffffffffull; }
 
@@ -399,6 +415,28 @@ DYN_HD void log_normal_pdf_cert_vec(double x, const EmisV<M>& p, const double (&
   for (int j = 0; j < M; ++j) r[j] = fma_(-q[j], stdev[j], a[j]);
 #pragma unroll
   for (int j = 0; j < M; ++j) q[j] = fma_(r[j], p.inv_stdev[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = fma_(-q[j], stdev[j], a[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(r[j], p.inv_stdev[j], q[j]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = (-0.5 * q[j]) * q[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = q[j] + p.neg_log_stdev[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) out[j] = q[j] - HALF_LOG_2PI;
+}
+
+// the same with the four-operation quotient: y_lo[j] = recip_lo(stdev[j], p.inv_stdev[j])
+template <int M>
+DYN_HD void log_normal_pdf_cert4_vec(double x, const EmisV<M>& p, const double (&stdev)[M], const double (&y_lo)[M], double (&out)[M]) {
+  double a[M], q[M], r[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) a[j] = x - p.mean[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) r[j] = a[j] * y_lo[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) q[j] = fma_(a[j], p.inv_stdev[j], r[j]);
 #pragma unroll
   for (int j = 0; j < M; ++j) r[j] = fma_(-q[j], stdev[j], a[j]);
 #pragma unroll

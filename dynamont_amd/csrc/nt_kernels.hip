@@ -235,11 +235,17 @@ __device__ __forceinline__ void set_emis(EmisV<CPL>& p, int j, const Emis& e) {
 }
 
 // stdev: ARITH_STRICT only (the divisor of the reference's quotient, beside its reciprocal in p)
+// y_lo: ARITH_STRICT only (the low part of 1/stdev: the exact quotient in four operations, dp_math_strict.hpp; -DDYN_QUOT5 keeps
+// round 4's five)
 template <int ARITH, int NS>
-__device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, const double (&stdev)[NS], double (&out)[CPL]) {
+__device__ __forceinline__ void emission_vec(double x, const EmisV<CPL>& p, const double (&stdev)[NS], const double (&y_lo)[NS], double (&out)[CPL]) {
   if constexpr (ARITH == ARITH_STRICT) {
     static_assert(NS == CPL, "strict emission needs every cell's stdev");
+#ifdef DYN_QUOT5
     dynmath::log_normal_pdf_cert_vec<CPL>(x, p, stdev, out);
+#else
+    dynmath::log_normal_pdf_cert4_vec<CPL>(x, p, stdev, y_lo, out);
+#endif
   } else if constexpr (ARITH == ARITH_FOLDED) {
     double u[CPL];
 #pragma unroll
@@ -456,9 +462,13 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
   double bE[CPL], bM[CPL], bE2[CPL], bM2[CPL], e[CPL];
   EmisV<CPL> p;
   double p_stdev[ARITH == ARITH_STRICT ? CPL : 1];  // certified arithmetic: the divisor itself, beside its reciprocal
+  double p_ylo[ARITH == ARITH_STRICT ? CPL : 1];    // ... and the low part of the reciprocal (two operations per hand-over)
   auto set_p = [&](int j, const Emis& em) {
     set_emis<ARITH>(p, j, em);
-    if constexpr (ARITH == ARITH_STRICT) p_stdev[j] = em.stdev;
+    if constexpr (ARITH == ARITH_STRICT) {
+      p_stdev[j] = em.stdev;
+      p_ylo[j] = dynmath::recip_lo(em.stdev, em.inv_stdev);
+    }
   };
   // the exact quotient of the certified emission must not overflow (dp_math_strict.hpp); such a sample makes the reference's
   // z*z infinite, every cell of its row -inf and Z = -inf: the same verdict as an infinite sample
@@ -487,7 +497,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
     const double xs = (idx >= 0) ? sg[idx] : 0.0;
     bad_sample |= !(fabs(xs) <= SAMPLE_MAX);  // inf or NaN
     const int ilo = base < 0 ? -base : 0;
-    emission_vec<ARITH>(readlane_f64(xs, 63), p, p_stdev, e);  // e(thi+1, n) from sig[thi]
+    emission_vec<ARITH>(readlane_f64(xs, 63), p, p_stdev, p_ylo, e);  // e(thi+1, n) from sig[thi]
     // one lattice row: reads (bE_in, bM_in) = row t+1, writes (bE_out, bM_out) = row t; the loop is unrolled by two and
     // ping-pongs between the two pairs (see forward_sweep: no register moves at the loop's back edge)
     auto row = [&](int i, const double (&bE_in)[CPL], const double (&bM_in)[CPL], double (&bE_out)[CPL], double (&bM_out)[CPL]) {
@@ -540,7 +550,7 @@ __device__ __forceinline__ double backward_sweep(const ReadDesc& rd, const WaveC
       //  in every row)
       {
         const double xnext = readlane_f64(xs, i > 0 ? i - 1 : 0);
-        emission_vec<ARITH>(xnext, p, p_stdev, e);
+        emission_vec<ARITH>(xnext, p, p_stdev, p_ylo, e);
       }
       if constexpr (ARITH == ARITH_FOLDED) dynmath::log_plus_finish3<CPL>(L, bE_out);  // train(): no decision hangs on it
       else if constexpr (ARITH == ARITH_STRICT) log_plus_finish_certified(L, bE_out, strict_tab(s_tab), nfb);
@@ -681,6 +691,7 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   RowState sa, sb;
   EmisV<CPL> p;
   double p_stdev[STRICT ? CPL : 1];  // STRICT instantiation: the divisor of the reference's emission, beside 1/stdev
+  double p_ylo[STRICT ? CPL : 1];    // ... and the low part of 1/stdev (dp_math_strict.hpp: the exact quotient in four operations)
   // POST = false is align(calc_probabilities=false): Z both ways and their agreement, no decision taken -- the cheap
   // arithmetic of train()'s backward sweep (two-operation emission, degree-3 softplus polynomial; Z moves by 1e-12
   // relative, the bar is 1e-9)
@@ -689,17 +700,24 @@ __device__ __forceinline__ double forward_sweep(const ReadDesc& rd, const WaveCt
   auto set_p = [&](int j, const Emis& e, auto with_stdev) {
     if constexpr (!POST) set_emis<ARITH_FOLDED>(p, j, e);
     else p.set(j, e);
-    if constexpr (STRICT && decltype(with_stdev)::value) p_stdev[j] = e.stdev;
+    if constexpr (STRICT && decltype(with_stdev)::value) {
+      p_stdev[j] = e.stdev;
+      p_ylo[j] = dynmath::recip_lo(e.stdev, e.inv_stdev);
+    }
   };
   // emission of one sample against the lane's cells, in the flavour of the row it belongs to
   auto emission = [&](bool strict_row, double x, double (&out)[CPL]) {
     if constexpr (STRICT) {
       if (strict_row) {
+#ifdef DYN_QUOT5
         dynmath::log_normal_pdf_cert_vec<CPL>(x, p, p_stdev, out);
+#else
+        dynmath::log_normal_pdf_cert4_vec<CPL>(x, p, p_stdev, p_ylo, out);
+#endif
         return;
       }
     }
-    if constexpr (!POST) emission_vec<ARITH_FOLDED>(x, p, p_stdev, out);
+    if constexpr (!POST) emission_vec<ARITH_FOLDED>(x, p, p_stdev, p_ylo, out);
     else log_normal_pdf_vec<CPL>(x, p, out);
   };
   const double x0 = sg[0];

@@ -195,6 +195,7 @@ long cmp_div(const double* sd, long nsd, long per, uint64_t seed, double* bad) {
         a = std::ldexp(1.0 + g.uni(), (int)(r %% 90) - 60) * ((r & 128) ? -1.0 : 1.0);
       }
       if (!same(div_by_const(a, b, y), a / b)) { if (!c) { bad[0] = a; bad[1] = b; } ++c; }
+      if (!same(div_by_const4(a, b, y, recip_lo(b, y)), a / b)) { if (!c) { bad[0] = a; bad[1] = b; } ++c; }   // round 6: four operations
     }
   }
   return c;
@@ -205,7 +206,11 @@ long cmp_pdf_cert(const double* x, const double* mean, const double* sd, long n,
     EmisV<7> p; double st[7], o[7];
     for (int j = 0; j < 7; ++j) { Emis e = make_emis(mean[i + j], sd[i + j], std::log(sd[i + j])); p.set(j, e); st[j] = e.stdev; }
     for (int j = 0; j < 7; ++j) {
+      double yl[7], o4[7];
+      for (int k = 0; k < 7; ++k) yl[k] = recip_lo(st[k], p.inv_stdev[k]);
+      log_normal_pdf_cert4_vec<7>(x[i + j], p, st, yl, o4);
       log_normal_pdf_cert_vec<7>(x[i + j], p, st, o);
+      if (!same(o4[j], o[j])) { if (!c) *bad = x[i + j]; ++c; }
       const double want = ref_pdf(x[i + j], mean[i + j], sd[i + j]);
       if (!same(o[j], want) || !same(log_normal_pdf_cert(x[i + j], make_emis(mean[i + j], sd[i + j], std::log(sd[i + j]))), want)) { if (!c) *bad = x[i + j]; ++c; }
     }
