@@ -47,6 +47,23 @@ def launch(scenario, n, workdir, model, timeout=420, extra=None):
     return outs
 
 
+_LOOPBACK = None
+
+
+def rccl_loopback_ok(workdir):
+    """(cached) True when two ranks on this box's one device get a communicator and an all-reduce through RCCL's socket
+    transport over loopback; else the reason. Boxes of the pool do; a box without a usable `lo` interface would not."""
+    global _LOOPBACK
+    if _LOOPBACK is None:
+        try:
+            outs = launch("probe", 2, workdir, "-", timeout=120, extra={"DYN_COMM_TIMEOUT_S": "60"})
+            ok = all(rc == 0 and res is not None and res["sum"] == 3.0 for rc, res, _ in outs)
+            _LOOPBACK = True if ok else "RCCL over loopback sockets unavailable on this box: " + " | ".join(e[-300:] for _, _, e in outs)
+        except Exception as e:   # noqa: BLE001
+            _LOOPBACK = "RCCL loopback probe failed: %s" % e
+    return _LOOPBACK
+
+
 def exchange_id(workdir, rank):
     from dynamont_amd._dynamont import RcclComm
     path = os.path.join(workdir, "id.bin")
@@ -85,6 +102,12 @@ def run_rank(scenario, rank, n, workdir, model):
     from dynamont_amd._dynamont import RcclComm
     assert "torch" not in sys.modules
     L = N.lib()
+    if scenario == "probe":   # can RCCL connect two ranks on this box at all? (communicator + one all-reduce, no aligner)
+        comm = RcclComm(exchange_id(workdir, rank), rank, n, 0)
+        got = comm.allreduce(np.array([1.0 + rank]), "sum")
+        comm.close()
+        print("RESULT " + json.dumps({"rank": rank, "sum": float(got[0])}), flush=True)
+        return
     _, mean, sd = synth.read_model_file(model)
     reads = synth.make_reads(7000 + rank, 12 + 5 * rank, "rna004", mean, sd, (60, 400))
     al = Aligner(model, "rna004", device=0)

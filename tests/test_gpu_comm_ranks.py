@@ -20,6 +20,13 @@ def _load(workdir, name, rank):
     return np.load(os.path.join(workdir, "%s_rank%d.npz" % (name, rank)))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _rccl_over_loopback(tmp_path_factory):
+    ok = comm_ranks.rccl_loopback_ok(str(tmp_path_factory.mktemp("rccl_probe")))
+    if ok is not True:
+        pytest.skip(ok)
+
+
 def _release_parked():
     import dynamont_amd
     dynamont_amd.release_cached_memory()   # pools parked by earlier tests of this process: leave the children the memory

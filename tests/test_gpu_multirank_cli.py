@@ -20,14 +20,23 @@ from dynamont_amd.segmentation import utils as U
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("native_lib")]
 
 
+def _exchange(tmp_path_factory=None):
+    """dyn_comm over real RCCL where two ranks can be connected on this box (every box of the pool), else torch / gloo"""
+    import tempfile
+
+    import comm_ranks
+    return "dyn_comm" if comm_ranks.rccl_loopback_ok(tempfile.mkdtemp(prefix="rccl_probe_")) is True else "torch"
+
+
 def _torchrun(module, args, port, ranks=2):
-    env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", DYN_DIST_EXCHANGE="dyn_comm", PYTHONPATH=ROOT)
+    exchange = _exchange()
+    env = dict(os.environ, DYN_DIST_BACKEND="gloo", DYN_DIST_ONE_DEVICE="1", DYN_DIST_EXCHANGE=exchange, PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(port), "-m", module] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     # the same exchange implementation `bench.py --gpus N` names (test_bench_gpus_n_launches_its_own_ranks below)
-    assert "exchange: dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp)" in r.stderr, r.stderr[-3000:]
+    assert ("exchange: dyn_comm_* (dynamont_amd/csrc/rccl_comm.cpp)" if exchange == "dyn_comm" else "exchange: torch.distributed (gloo)") in r.stderr, r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("ranks", [2, 4])   # (a GPU box lets one job put 6 processes on its card: pytest itself + 4 ranks stay inside)
@@ -93,6 +102,8 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path, ranks):
     a box with one device instead of measuring one GPU and calling it N. (4 ranks: a GPU box lets one job put 6 processes on its
     card, this test runner included; gloo at world 8 runs on the CPU, tests/test_parallel_gloo.py.)"""
     import json
+    if _exchange() != "dyn_comm":
+        pytest.skip("RCCL over loopback sockets unavailable on this box: bench.py --gpus N has no other exchange to rehearse with")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(DYN_BENCH_ONE_DEVICE="1", DYN_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "cfg2_small",
