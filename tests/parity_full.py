@@ -55,7 +55,7 @@ def main_train(a):
     tmp = tempfile.mkdtemp(prefix="parity_")
     model = synth.write_model(os.path.join(tmp, f"syn{k}.model"), k, seed=7, stdev=0.15)
     _, mean, sd = synth.read_model_file(model)
-    _READS = synth.make_reads(cfg["seed"], n, pore, mean, sd, cfg["n_bases"])
+    _READS = synth.make_reads(cfg["seed"], n, pore, mean, sd, cfg["n_bases"], polya=cfg.get("polya"))
     al = Aligner(model, pore, device=0)
     sig, so, sq, qo = synth.pack_reads(_READS)
     t = al.train_async(sig, so, sq, qo, pooled=False)
@@ -96,7 +96,7 @@ def main_train(a):
 def main():
     global _READS
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="cfg4_share", choices=["cfg2", "cfg4_share", "cfg3", "cfg5_share"])
+    ap.add_argument("--workload", default="cfg4_share", choices=["cfg2", "cfg2_polya", "cfg4_share", "cfg3", "cfg5_share"])
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--procs", type=int, default=min(16, os.cpu_count() or 1))
@@ -105,7 +105,7 @@ def main():
     if a.train:
         return main_train(a)
     from dynamont_amd import Aligner, synth
-    cfgname, n = {"cfg2": ("cfg2", 1024), "cfg4_share": ("cfg4", 4096), "cfg3": ("cfg3", 4096)}[a.workload]
+    cfgname, n = {"cfg2": ("cfg2", 1024), "cfg2_polya": ("cfg2_polya", 1024), "cfg4_share": ("cfg4", 4096), "cfg3": ("cfg3", 4096)}[a.workload]
     n = a.reads or n
     cfg = synth.CONFIGS[cfgname]
     pore = cfg["pore"]
@@ -113,7 +113,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="parity_")
     model = synth.write_model(os.path.join(tmp, f"syn{k}.model"), k, seed=7, stdev=0.15)
     _, mean, sd = synth.read_model_file(model)
-    _READS = synth.make_reads(cfg["seed"], n, pore, mean, sd, cfg["n_bases"])
+    _READS = synth.make_reads(cfg["seed"], n, pore, mean, sd, cfg["n_bases"], polya=cfg.get("polya"))
     al = Aligner(model, pore, device=0)
     t0 = time.time()
     sig, so, sq, qo = synth.pack_reads(_READS)
