@@ -443,3 +443,31 @@ def test_console_scripts_carry_the_reference_names_and_resolve(capsys):
         assert e.value.code == 0
         text = capsys.readouterr().out
         assert "--raw" in text and "--basecalls" in text and "--pore" in text
+
+
+def test_bench_contract_without_a_gpu():
+    """bench.py: the driver's flags parse, the N = 1 default is BASELINE configs[1], every workload it names exists in the
+    generator, and without a GPU it refuses loudly instead of measuring something else (no CPU path to fall back to)."""
+    import importlib.util
+    import subprocess
+
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"]
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert (a.gpus, a.steps, a.warmup, a.mode, a.strict) == (1, 20, 5, "align", "ties") and a.workload is None
+    for name, (cfgname, _per_batch, _n) in bench.WORKLOADS.items():
+        assert cfgname in synth.CONFIGS, name
+    assert synth.CONFIGS["cfg2"] == dict(pore="rna004", n_reads=1024, n_bases=2000, seed=2)
+    assert bench.KBWD_BYTES_PER_CELL + bench.KFWD_BYTES_PER_CELL == 20.125 and bench.HBM_PEAK_GBPS == 8000.0
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-e2e", "--reads", "4", "--batches", "1"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
