@@ -1698,11 +1698,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   uint32_t* ctl = sa.ctl;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
   uint64_t cyc_busy = 0, cyc_idle = 0, cyc_pages = 0, n_done = 0;
+  uint64_t cyc_head = 0, t0 = t_start;  // idle before this wave's first read; start of the current turn
   uint32_t cur = 0, tail_seen = 0;   // the ticket this wave looks at; tickets it knows to be published
   bool have = false;
   SessionTicket tk{};
   for (;;) {
-    const uint64_t t0 = __builtin_amdgcn_s_memtime();      // shader clock: phase shares
+    t0 = __builtin_amdgcn_s_memtime();                     // shader clock: phase shares
     const uint64_t r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: durations
     // An aborted session takes no more reads: the waves that idled into the watchdog have left, the host publishes what is
     // incomplete again elsewhere (session_recover) -- a few busy waves must not work the queue off on their own meanwhile.
@@ -1776,6 +1777,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     cyc_idle += t1 - t0;
+    if (n_done == 0) cyc_head = t1 - t_start;
     WaveStats ws;
     ReadIO io{};
     io.st = reinterpret_cast<ReadState*>(out_base + tk.st_off);
@@ -1815,7 +1817,12 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   if (PAGED && held) pages_give(sa.pool, w, 0, held);  // (a wave that claimed a read may still be waiting for these)
   if (w.lane == 0) {
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(ctl + SESSION_STATS);
-    const unsigned long long life = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
+    const uint64_t t_end = __builtin_amdgcn_s_memtime();
+    const unsigned long long life = (unsigned long long)(t_end - t_start);
+    // where the idle share sits: before a wave's first read (the first ticket's inputs on their way), and in its LAST turn (no
+    // read left to claim: the other waves' last reads, the host's close) -- what is left of stats[1] lies between tickets
+    atomicAdd(&stats[6], (unsigned long long)cyc_head);
+    atomicAdd(&stats[7], (unsigned long long)(t_end - t0));
     atomicAdd(&stats[0], (unsigned long long)cyc_busy);
     atomicAdd(&stats[1], (unsigned long long)cyc_idle);
     atomicAdd(&stats[2], life);

@@ -159,7 +159,8 @@ constexpr int SESSION_TSTATS = 2;        // first statistics word of a ticket's 
 constexpr int SESSION_TCTL_WORDS = 32;
 // session control words (device memory, 32-bit): next global read index, tickets published, closed, abort; 64-bit statistics
 // from word SESSION_STATS on: wave-cycles busy (claim to release), idle, lifetime, longest lifetime, reads done, [5] the part
-// of idle spent getting pages (paged sessions)
+// of idle spent getting pages (paged sessions), [6] idle before a wave's first read (part of idle), [7] a wave's last turn (no read
+// left to claim; NOT part of idle: lifetime - busy - idle)
 constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS = 8, SESSION_CTL_WORDS = 32;
 
 struct SessionArgs {

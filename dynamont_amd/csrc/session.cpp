@@ -68,6 +68,13 @@ int session_collect(dyn_aligner* a, int blk) {
   t.wave_cycles_life += st[2];
   a->sess_page_wait_cycles += st[5];
   t.waves += ss.pend_waves[blk];
+  // DYN_TRACE_HOST=1: where the waves' idle share of this session sat (shares of the summed wave lifetimes)
+  static const bool trace = std::getenv("DYN_TRACE_HOST") != nullptr;
+  if (trace && st[2]) {
+    const double life = (double)st[2];
+    std::fprintf(stderr, "[dyn] session: %.1f ms, %u tickets, waves busy %.4f; idle before a wave's first read %.4f, between reads %.4f (pages %.4f), in its last turn %.4f\n",
+                 ms, (unsigned)ss.pend_tickets[blk], st[0] / life, st[6] / life, (double)(st[1] - st[6]) / life, st[5] / life, st[7] / life);
+  }
   if (cw[dynk::S_ABORT]) t.aborted += 1;
   ss.pending[blk] = false;
   return DYN_OK;

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE (uses the CPU oracle; run by hand on a GPU box, not collected by pytest):
 
-    python tests/fuzz_parity.py > gpurun_out/fuzz.txt
+    python tests/fuzz_parity.py [seed = 20261004] [reads per pore and band = 150] > gpurun_out/fuzz.txt
 
 3 000 random short reads (k .. 400 bases, dwell 0.5 .. 10) over the five pore types and four random band widths each
 against the oracle: integer columns identical, posteriors within 1e-6, Z within 1e-9 relative, failures with the
@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 from dynamont_amd import Aligner, synth
 from oracle.pyoracle import Oracle
 d = tempfile.mkdtemp()
-rng = np.random.default_rng(20261004)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 20261004
+PER = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+rng = np.random.default_rng(SEED)
 tot = bad = err = bad_train = bad_z = 0
 for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
     k = synth.PORES[pore][2]
@@ -21,7 +23,7 @@ for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
     _, mean, sd = synth.read_model_file(path)
     for band in (int(x) for x in rng.choice([6, 16, 50, 100, 200, 300, 400, 446], 4, replace=False)):
         reads = []
-        for i in range(150):
+        for i in range(PER):
             nb = int(rng.integers(k, 400))
             reads += synth.make_reads(int(rng.integers(1 << 30)), 1, pore, mean, sd, nb, dwell=float(rng.choice([0.5, 2.0, 3.5, 7.0, 10.0])))
         al = Aligner(path, pore, band=band, device=0)
