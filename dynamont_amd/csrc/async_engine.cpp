@@ -617,6 +617,22 @@ int Pipeline::back_stage(dyn_batch* b, const std::shared_ptr<BatchGroup>& grp) {
       if (!again) break;  // complete after all
     }
     if (rc != DYN_OK) return rc;
+    // The last ticket in flight is complete and nothing waits behind it: the resident waves would only poll while this thread
+    // runs the per-segment kernels and the copies out (config 3: ~100 ms for a batch's rows) -- they are told to leave NOW, not
+    // when the pipeline has run dry (close_idle_session, which remains for the other ways a pipeline empties). A ticket that
+    // arrives a moment later opens the next session, as it would have after the back stage.
+    if (!std::getenv("DYN_SESSION_LATE_CLOSE")) {
+      std::lock_guard<std::mutex> lk(a->mu);
+      bool last;
+      {
+        std::lock_guard<std::mutex> lk2(m);
+        last = in_flight == 1;
+      }
+      if (last && a->sess_open_hint.load()) {
+        P_TRY(b, hipSetDevice(a->device));
+        (void)session_close(a);
+      }
+    }
     // the per-segment kernels and the copies out, beside the resident waves
     const double f0 = now_ms();
     rc = session_finish_enqueue(b, a->s_out);

@@ -1698,7 +1698,7 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   uint32_t* ctl = sa.ctl;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
   uint64_t cyc_busy = 0, cyc_idle = 0, cyc_pages = 0, n_done = 0;
-  uint64_t cyc_head = 0, t0 = t_start;  // idle before this wave's first read; start of the current turn
+  uint64_t cyc_head = 0, cyc_head_pages = 0, t0 = t_start;  // idle before this wave's first read; start of the current turn
   uint32_t cur = 0, tail_seen = 0;   // the ticket this wave looks at; tickets it knows to be published
   bool have = false;
   SessionTicket tk{};
@@ -1777,7 +1777,10 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     cyc_idle += t1 - t0;
-    if (n_done == 0) cyc_head = t1 - t_start;
+    if (n_done == 0) {
+      cyc_head = t1 - t_start;
+      cyc_head_pages = cyc_pages;
+    }
     WaveStats ws;
     ReadIO io{};
     io.st = reinterpret_cast<ReadState*>(out_base + tk.st_off);
@@ -1823,6 +1826,9 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     // read left to claim: the other waves' last reads, the host's close) -- what is left of stats[1] lies between tickets
     atomicAdd(&stats[6], (unsigned long long)cyc_head);
     atomicAdd(&stats[7], (unsigned long long)(t_end - t0));
+    if (PAGED) atomicAdd(&stats[8], (unsigned long long)cyc_head_pages);
+    atomicAdd(&stats[9], (unsigned long long)(((t_end - t0) >> 10) * ((t_end - t0) >> 10)));  // (shape of the end: E[x^2] / E[x]^2)
+    atomicMax(&stats[10], (unsigned long long)(t_end - t0));
     atomicAdd(&stats[0], (unsigned long long)cyc_busy);
     atomicAdd(&stats[1], (unsigned long long)cyc_idle);
     atomicAdd(&stats[2], life);

@@ -72,8 +72,9 @@ int session_collect(dyn_aligner* a, int blk) {
   static const bool trace = std::getenv("DYN_TRACE_HOST") != nullptr;
   if (trace && st[2]) {
     const double life = (double)st[2];
-    std::fprintf(stderr, "[dyn] session: %.1f ms, %u tickets, waves busy %.4f; idle before a wave's first read %.4f, between reads %.4f (pages %.4f), in its last turn %.4f\n",
-                 ms, (unsigned)ss.pend_tickets[blk], st[0] / life, st[6] / life, (double)(st[1] - st[6]) / life, st[5] / life, st[7] / life);
+    std::fprintf(stderr, "[dyn] session: %.1f ms, %u tickets, waves busy %.4f; idle before a wave's first read %.4f (pages %.4f), between reads %.4f (pages %.4f), in its last turn %.4f (longest %.1f %% of the session, E[x^2]/E[x]^2 %.2f)\n",
+                 ms, (unsigned)ss.pend_tickets[blk], st[0] / life, st[6] / life, st[8] / life, (double)(st[1] - st[6]) / life, (double)(st[5] - st[8]) / life, st[7] / life,
+                 100.0 * st[10] * ss.pend_waves[blk] / life, st[7] ? (double)st[9] * 1048576.0 * ss.pend_waves[blk] / ((double)st[7] * (double)st[7]) : 0.0);
   }
   if (cw[dynk::S_ABORT]) t.aborted += 1;
   ss.pending[blk] = false;
@@ -350,8 +351,10 @@ int session_publish(dyn_batch* b) {
       // order -- each wave takes one -- so their pages are asked for together either way; taken LONGEST FIRST the long ones among
       // them start as early as they can and the waves finish within a short read of each other, instead of one 100 k-sample read,
       // claimed last, keeping 1 023 waves waiting for the session's close (config 3: ~5 % of an 8-batch run; measured A/B below).
-      if (!std::getenv("DYN_SESSION_NO_TAIL_LPT") && order.size() > ss.n_waves) {
-        auto tail = order.end() - (ptrdiff_t)ss.n_waves;
+      const char* lpt_env = std::getenv("DYN_SESSION_TAIL_LPT_READS");  // experiments: the length of that tail
+      const size_t lpt_reads = std::min<size_t>(order.size(), lpt_env ? (size_t)std::atoll(lpt_env) : (size_t)ss.n_waves);
+      if (!std::getenv("DYN_SESSION_NO_TAIL_LPT") && order.size() > ss.n_waves && lpt_reads > 1) {
+        auto tail = order.end() - (ptrdiff_t)lpt_reads;
         std::stable_sort(tail, order.end(), [&](uint32_t x, uint32_t y) { return rank[x] < rank[y]; });
       }
     }
