@@ -18,9 +18,11 @@ raw, bam, _ = synth.write_dataset(os.path.join(d, "in"), "ds", reads, "rna004", 
 samples = sum(len(r.signal) for r in reads) * max(1, n_reads // distinct)
 del reads
 cli = ["-r", os.path.join(d, "in"), "-b", bam, "--mode", "basic", "-p", "rna004", "--model_path", model] + sys.argv[2:]
-for run in range(3):
+RUNS = int(os.environ.get("COLD_RUNS", "3"))          # COLD_RUNS=1 COLD_TRACE_ALL=1: one run on the VRAM as found, every trace line
+TRACE_ALL = bool(os.environ.get("COLD_TRACE_ALL"))
+for run in range(RUNS):
     env = dict(os.environ, PYTHONPATH=ROOT, DYN_CLI_TRACE="1", DYN_CLI_T0=repr(time.time()))
-    if run == 2:
+    if run == 2 or TRACE_ALL:
         env["DYN_TRACE_HOST"] = "1"
     t0 = time.perf_counter()
     r = subprocess.run([sys.executable, "-m", "dynamont_amd.segmentation.segment"] + cli + ["-o", os.path.join(d, "out%d.csv" % run)], env=env,
@@ -28,5 +30,5 @@ for run in range(3):
     dt = time.perf_counter() - t0
     print("==== run %d: rc %d, %.3f s wall = %.1f Msamp/s" % (run, r.returncode, dt, samples / dt / 1e6))
     lines = r.stderr.splitlines()
-    keep = [l for l in lines if l.startswith("[cli")] if run < 2 else [l for l in lines if l.startswith("[cli") or "create:" in l or "destroy" in l or "publish 1" in l or "publish 2" in l or "publish 3" in l][:60]
+    keep = lines if TRACE_ALL else [l for l in lines if l.startswith("[cli")] if run < 2 else [l for l in lines if l.startswith("[cli") or "create:" in l or "destroy" in l or "publish 1" in l or "publish 2" in l or "publish 3" in l][:60]
     print("\n".join(keep))
