@@ -1698,7 +1698,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
   uint32_t* ctl = sa.ctl;
   const uint64_t t_start = __builtin_amdgcn_s_memtime();
   uint64_t cyc_busy = 0, cyc_idle = 0, cyc_pages = 0, n_done = 0;
-  uint64_t cyc_head = 0, cyc_head_pages = 0, t0 = t_start;  // idle before this wave's first read; start of the current turn
+  uint64_t cyc_head = 0, cyc_head_pages = 0, t0 = t_start;
+  uint64_t last_read = 0, last_pages = 0;  // the wave's last read: its queue index and what it waited for pages  // idle before this wave's first read; start of the current turn
   uint32_t cur = 0, tail_seen = 0;   // the ticket this wave looks at; tickets it knows to be published
   bool have = false;
   SessionTicket tk{};
@@ -1760,7 +1761,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
         if (held) pages_give(sa.pool, w, 0, held);
         held = 0;
         const bool got = pages_take(sa.pool, w, rd.n_pages, slot + 1u);
-        cyc_pages += __builtin_amdgcn_s_memtime() - tp;   // (part of cyc_idle; apart: what the page pool costs)
+        last_pages = __builtin_amdgcn_s_memtime() - tp;
+        cyc_pages += last_pages;   // (part of cyc_idle; apart: what the page pool costs)
         if (!got) {
           // waited for pages for seconds: the session is over; what is incomplete is published again (session_recover)
           if (w.lane == 0) ctl_store(&ctl[S_ABORT], 3u);
@@ -1777,6 +1779,8 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     cyc_idle += t1 - t0;
+    last_read = g;
+    if (!PAGED) last_pages = 0;
     if (n_done == 0) {
       cyc_head = t1 - t_start;
       cyc_head_pages = cyc_pages;
@@ -1829,6 +1833,13 @@ __global__ DYN_ONE_WAVE_PER_SIMD void k_session(const SessionArgs sa, const char
     if (PAGED) atomicAdd(&stats[8], (unsigned long long)cyc_head_pages);
     atomicAdd(&stats[9], (unsigned long long)(((t_end - t0) >> 10) * ((t_end - t0) >> 10)));  // (shape of the end: E[x^2] / E[x]^2)
     atomicMax(&stats[10], (unsigned long long)(t_end - t0));
+    // the read that ended LAST: (end of the wave's work in 1 024-cycle units) << 24 | queue index; its page wait rides on the
+    // same key in the next word (both maxima are taken by the same wave unless two waves end within 1 024 cycles)
+    if (n_done) {
+      const unsigned long long key = (unsigned long long)((t0 - t_start) >> 10) << 24;
+      atomicMax(&stats[11], key | (unsigned long long)(last_read & 0xffffffu));
+      atomicMax(&stats[12], key | (unsigned long long)(min((unsigned long long)(last_pages >> 10), 0xffffffull)));
+    }
     atomicAdd(&stats[0], (unsigned long long)cyc_busy);
     atomicAdd(&stats[1], (unsigned long long)cyc_idle);
     atomicAdd(&stats[2], life);

@@ -160,8 +160,8 @@ constexpr int SESSION_TCTL_WORDS = 32;
 // session control words (device memory, 32-bit): next global read index, tickets published, closed, abort; 64-bit statistics
 // from word SESSION_STATS on: wave-cycles busy (claim to release), idle, lifetime, longest lifetime, reads done, [5] the part
 // of idle spent getting pages (paged sessions), [6] idle before a wave's first read (part of idle), [7] a wave's last turn (no read
-// left to claim; NOT part of idle: lifetime - busy - idle), [8] the pages part of [6], [9] sum of ([7] >> 10)^2, [10] max of [7]
-constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS = 8, SESSION_CTL_WORDS = 32;
+// left to claim; NOT part of idle: lifetime - busy - idle), [8] the pages part of [6], [9] sum of ([7] >> 10)^2, [10] max of [7], [11] / [12] the read that ended last (k_session)
+constexpr int S_HEAD = 0, S_TAIL = 1, S_CLOSED = 2, S_ABORT = 3, SESSION_STATS = 8, SESSION_CTL_WORDS = 40;
 
 struct SessionArgs {
   const SessionTicket* ring;   // [ring_size]; slot i holds ticket i of the session (never reused within one)

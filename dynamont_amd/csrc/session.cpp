@@ -75,6 +75,9 @@ int session_collect(dyn_aligner* a, int blk) {
     std::fprintf(stderr, "[dyn] session: %.1f ms, %u tickets, waves busy %.4f; idle before a wave's first read %.4f (pages %.4f), between reads %.4f (pages %.4f), in its last turn %.4f (longest %.1f %% of the session, E[x^2]/E[x]^2 %.2f)\n",
                  ms, (unsigned)ss.pend_tickets[blk], st[0] / life, st[6] / life, st[8] / life, (double)(st[1] - st[6]) / life, (double)(st[5] - st[8]) / life, st[7] / life,
                  100.0 * st[10] * ss.pend_waves[blk] / life, st[7] ? (double)st[9] * 1048576.0 * ss.pend_waves[blk] / ((double)st[7] * (double)st[7]) : 0.0);
+    std::fprintf(stderr, "[dyn] session: the read that ended last was number %llu of %llu in the queue; it had waited %.2f %% of the session for its pages\n",
+                 (unsigned long long)(st[11] & 0xffffffu), (unsigned long long)ss.pend_reads[blk],
+                 (st[11] >> 24) == (st[12] >> 24) ? 100.0 * (double)((st[12] & 0xffffffu) << 10) * ss.pend_waves[blk] / life : -1.0);
   }
   if (cw[dynk::S_ABORT]) t.aborted += 1;
   ss.pending[blk] = false;
