@@ -224,6 +224,7 @@ struct dyn_csv_sink {
   }
 
   // DYN_SINK_TRACE=1: where the sink thread's time goes (ms summed over the batches), printed at close
+  double t_last_wait_done = 0;
   double t_wait = 0, t_format = 0, t_compact = 0, t_append = 0, t_errors = 0;
   std::atomic<uint64_t> us_compress{0}, us_write{0}, us_resize{0}, us_gather{0}, us_compress_cpu{0};
   static double thread_cpu_ms() {
@@ -238,6 +239,7 @@ struct dyn_csv_sink {
     const int rc = dyn_batch_wait(it.ticket);
     const double c1 = now_ms();
     t_wait += c1 - c0;
+    t_last_wait_done = c1;
     if (rc != DYN_OK) {
       std::lock_guard<std::mutex> lk(m);
       fail(std::string("batch failed: ") + dyn_aligner_last_error(it.a));
@@ -448,16 +450,35 @@ int dyn_csv_sink_close(dyn_csv_sink* s, uint64_t* csv_bytes, uint64_t* compresse
     s->closing = true;
   }
   s->cv_items.notify_all();
+  const double q0 = dyn_csv_sink::now_ms();
   s->t_sink.join();
+  const double q1 = dyn_csv_sink::now_ms();
   for (auto& t : s->t_comp) t.join();
+  const double q2 = dyn_csv_sink::now_ms();
   s->t_writer.join();
+  const double q3 = dyn_csv_sink::now_ms();
   if (std::fclose(s->out) != 0) s->fail("closing the output file failed");
+  if (const char* e = std::getenv("DYN_SINK_TRACE"); e && *e == '1')
+    std::fprintf(stderr, "[csv sink] close: the sink thread's last batches %.1f ms (of which behind the last ticket's results: %.1f), compressors %.1f, writer %.1f, fclose %.1f\n",
+                 q1 - q0, q1 - s->t_last_wait_done, q2 - q1, q3 - q2, dyn_csv_sink::now_ms() - q3);
   if (csv_bytes) *csv_bytes = s->csv_bytes;
   if (compressed_bytes) *compressed_bytes = s->zst_bytes;
   if (error_lines) *error_lines = s->error_lines.load();
   const bool failed = s->failed;
   if (failed && err && errcap) std::snprintf(err, (size_t)errcap, "%s", s->error.c_str());
+  // (releasing the row buffers -- ~0.5 GB of touched pages -- costs 55-60 ms; a detached thread for it moves the wait into the
+  // caller's next release of memory: the address space is torn down under one lock. Packing the reads of a formatter thread
+  // back to back instead of a worst-case slot per read changes nothing either: the pages are 4 KB, not huge. Measured, round 6)
+  const bool trace_close = [] { const char* e = std::getenv("DYN_SINK_TRACE"); return e && *e == '1'; }();
+  const double d0 = dyn_csv_sink::now_ms();
+  size_t blob_bytes = 0;
+  for (auto& b : s->spare) blob_bytes += b ? b->cap : 0;
+  s->spare.clear();
+  const double d1 = dyn_csv_sink::now_ms();
   delete s;
+  if (trace_close)
+    std::fprintf(stderr, "[csv sink] close: releasing the row buffers (%.0f MB reserved) %.1f ms, the rest of the sink %.1f ms\n", blob_bytes / 1e6, d1 - d0,
+                 dyn_csv_sink::now_ms() - d1);
   return failed ? DYN_ERR_RUNTIME : DYN_OK;
 }
 

@@ -636,13 +636,16 @@ class _NativePipeline:
             return
         csv, zst, nerr = C.c_uint64(), C.c_uint64(), C.c_uint64()
         err = C.create_string_buffer(1024)
+        _stamp("closing the sink (every batch submitted; the last tickets are on the GPU)")
         rc = self.L.dyn_csv_sink_close(self.h, C.byref(csv), C.byref(zst), C.byref(nerr), err, 1024)
+        _stamp("sink closed: the file is complete")
         self.h = None
         LAST_RUN.update(csv_bytes=int(csv.value), compressed_bytes=int(zst.value), error_lines=int(nerr.value), batches=self.submitted,
                         depth=self.depth, compress_threads=self.threads)
         for t, *_ in self.keep.values():
             t.close()
         self.keep = {}
+        _stamp("tickets released")
         print("Done segmenting reads.", file=sys.stderr)
         if rc != self.N.DYN_OK:
             raise RuntimeError(err.value.decode())
