@@ -324,6 +324,45 @@ def test_order_and_chunking_invariance(models, al9):
         assert np.abs(a["probabilities"] - c["probabilities"]).max() <= PROB_TIGHT
 
 
+def test_a_read_whose_lattice_exceeds_the_budget_fails_alone(models):
+    """A read whose lattice alone does not fit the handle's memory budget gets its own status (the reference would raise
+    std::bad_alloc for that read only and report its line, segment.py:172-176); every other read of the batch is computed and
+    equals the oracle -- synchronous batch, train() and the asynchronous pipeline; the Z-only call keeps no lattice and computes
+    that read too."""
+    path = models["syn9"]
+    _, mean, sd = synth.read_model_file(path)
+    small_reads = synth.make_reads(811, 6, "rna004", mean, sd, (150, 300))
+    big = synth.make_reads(812, 1, "rna004", mean, sd, 2000)[0]       # ~20 k samples: ~70-110 MB of lattice
+    reads = small_reads[:3] + [big] + small_reads[3:]
+    sigs, seqs = [r.signal for r in reads], [r.sequence for r in reads]
+    al = Aligner(path, "rna004", device=0)
+    al.set_mem_budget(48 << 20)
+    orc = Oracle(path, synth.PORES["rna004"][0])
+    msg = "Read too large for the device memory budget"
+
+    def check(res, probs=True):
+        for i, r in enumerate(reads):
+            if i == 3 and probs:  # (the Z-only call stores no lattice: it computes this read as well)
+                assert res.status[i] == 8 and res.error(i) == msg
+                continue
+            assert res.status[i] == 0, (i, res.error(i))
+            want = orc.align(r.signal, r.sequence, probs)
+            assert abs(res.Z[i] - want["Z"]) <= 1e-9 * abs(want["Z"])
+            if probs:
+                got = res.read(i)
+                assert np.array_equal(got["sequence_positions"], want["sequence_positions"])
+                assert np.array_equal(got["signal_positions"], want["signal_positions"])
+                assert np.abs(got["probabilities"] - want["probabilities"]).max() <= PROB_TIGHT
+
+    check(al.align_batch(sigs, seqs, True))
+    check(al.align_batch(sigs, seqs, False), probs=False)
+    tr = al.train_batch(sigs, seqs)
+    assert tr.status[3] == 8 and tr.error(3) == msg and all(tr.status[i] == 0 for i in range(len(reads)) if i != 3)
+    with al.align_async(*synth.pack_reads(reads), True) as t:
+        check(t.wait())
+    al.close()
+
+
 @pytest.mark.parametrize("pore", ["rna004", "dna_r9"])
 def test_in_place_posterior_layout_against_oracle(models, pore):
     """The layout of footprint-limited batches, forced with a small memory budget."""
