@@ -430,7 +430,12 @@ def roofline_of(m: dict, workload: str, mode: str, args, profile: dict) -> dict:
         "wave_time_share": {"backward": round(share("ms_backward"), 4), "forward": round(share("ms_forward"), 4),
                             # one launch per batch: the launches' own counters; resident queue: wave-cycles of paged sessions
                             # spent getting pages / lifetime wave-cycles (dyn_aligner_session_page_wait)
-                            "waiting_for_pages": round(kern["wave_wait_share"] / n_launch + (sess.get("wave_cycles_pages", 0) / sess["wave_cycles_life"] if sess["wave_cycles_life"] else 0.0), 4)},
+                            "waiting_for_pages": round(kern["wave_wait_share"] / n_launch + (sess.get("wave_cycles_pages", 0) / sess["wave_cycles_life"] if sess["wave_cycles_life"] else 0.0), 4),
+                            # resident queue: where the idle share sat, counted by the waves (dyn_aligner_session_idle_split):
+                            # before a wave's first read, and in its LAST turn (no read left to claim: what a finite run pays
+                            # once per session and a stream does not)
+                            "before_first_read": round(sess.get("wave_cycles_before_first_read", 0) / sess["wave_cycles_life"], 4) if sess["wave_cycles_life"] else None,
+                            "last_turn": round(sess.get("wave_cycles_last_turn", 0) / sess["wave_cycles_life"], 4) if sess["wave_cycles_life"] else None},
         "phases": {"backward_sweep": {"bytes_per_cell": KBWD_BYTES_PER_CELL, "ms": round(kernel_ms_total * share("ms_backward"), 3),
                                       "frac": round(cells_total * KBWD_BYTES_PER_CELL / (kernel_ms_total * share("ms_backward") * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if share("ms_backward") else None},
                    "forward_sweep": {"bytes_per_cell": bpc_f, "ms": round(kernel_ms_total * share("ms_forward"), 3),
@@ -663,6 +668,7 @@ def main():
                 "strict_reads_per_step": mm["launches"]["reads_strict"] / max(1, mm["steps_done"]),
                 "roofline_frac": rf["frac"], "bytes_per_cell": rf["bytes_per_cell"], "kernel": rf["kernel"].split(" (")[0],
                 "wave_occupancy": rf["wave_occupancy"], "waiting_for_pages": rf["wave_time_share"]["waiting_for_pages"],
+                "before_first_read": rf["wave_time_share"]["before_first_read"], "last_turn": rf["wave_time_share"]["last_turn"],
                 "kernel_ms_total": rf["kernel_ms_total"], "cells_total": rf["cells_total"],
                 "launches": rf["launches"], "batches_per_launch": rf["batches_per_launch"], "batches_in_flight": mm["depth"], "note": note}
 

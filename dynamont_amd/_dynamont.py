@@ -502,6 +502,10 @@ class Aligner:
         pw = C.c_uint64(0)
         self._L.dyn_aligner_session_page_wait(self._h, C.byref(pw))   # paged sessions: the part of `idle` spent getting pages
         d["wave_cycles_pages"] = int(pw.value)
+        sp = (C.c_uint64 * 4)()
+        self._L.dyn_aligner_session_idle_split(self._h, sp)   # where the idle share sat: first read, its pages, last turn, longest
+        d["wave_cycles_before_first_read"], d["wave_cycles_before_first_read_pages"] = int(sp[0]), int(sp[1])
+        d["wave_cycles_last_turn"], d["wave_cycles_longest_last_turn"] = int(sp[2]), int(sp[3])
         return d
 
     def set_train_zcheck(self, on: bool) -> None:

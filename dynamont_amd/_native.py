@@ -90,6 +90,7 @@ SIGNATURES = {
     "dyn_aligner_model": (C.c_int, [C.c_void_p, c_double_p]),
     "dyn_aligner_session_stats": (C.c_int, [C.c_void_p, C.POINTER(DynSessionStats)]),
     "dyn_aligner_session_page_wait": (C.c_int, [C.c_void_p, c_u64_p]),
+    "dyn_aligner_session_idle_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "dyn_aligner_set_session_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "dyn_aligner_set_mem_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "dyn_aligner_set_strict": (C.c_int, [C.c_void_p, C.c_int]),

@@ -170,6 +170,7 @@ struct dyn_aligner {
   dyneng::PinnedBuf sess_hctl;       // D2H target of a control block
   dyneng::Session sess;
   dyn_session_stats sess_total{};    // closed and collected sessions
+  uint64_t sess_idle_split[4] = {0, 0, 0, 0};  // wave-cycles: before a wave's first read, of which pages, last turn, longest last turn
   uint64_t sess_page_wait_cycles = 0;  // part of sess_total.wave_cycles_idle: waves of PAGED sessions getting their pages
   // the idle watchdog of the resident waves, seconds (DYN_SESSION_IDLE_S)
   double sess_idle_s = 20.0;

@@ -67,6 +67,10 @@ int session_collect(dyn_aligner* a, int blk) {
   t.wave_cycles_idle += st[1];
   t.wave_cycles_life += st[2];
   a->sess_page_wait_cycles += st[5];
+  a->sess_idle_split[0] += st[6];
+  a->sess_idle_split[1] += st[8];
+  a->sess_idle_split[2] += st[7];
+  a->sess_idle_split[3] += st[10];
   t.waves += ss.pend_waves[blk];
   // DYN_TRACE_HOST=1: where the waves' idle share of this session sat (shares of the summed wave lifetimes)
   static const bool trace = std::getenv("DYN_TRACE_HOST") != nullptr;
@@ -573,6 +577,17 @@ extern "C" int dyn_aligner_session_page_wait(dyn_aligner* a, uint64_t* wave_cycl
     if (int rc = session_quiesce(a)) return rc;
   }
   *wave_cycles_waiting_for_pages = a->sess_page_wait_cycles;
+  return DYN_OK;
+}
+
+extern "C" int dyn_aligner_session_idle_split(dyn_aligner* a, uint64_t out4[4]) {
+  if (!a || !out4) return DYN_ERR_INVALID_ARGUMENT;
+  if (!a->host_only && a->s_session) {
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (int rc = need_device(a)) return rc;
+    if (int rc = session_quiesce(a)) return rc;
+  }
+  for (int k = 0; k < 4; ++k) out4[k] = a->sess_idle_split[k];
   return DYN_OK;
 }
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DYN_ABI_VERSION 7 /* 7: dyn_aligner_session_page_wait, dyn_comm_gather_bytes / _gathered_bytes / _allreduce_f64 (additive). 7: half bands 224 .. 2 046 are computed (wide_band.hip). 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
+#define DYN_ABI_VERSION 8 /* 8: dyn_aligner_session_idle_split (additive). 7: dyn_aligner_session_page_wait, dyn_comm_gather_bytes / _gathered_bytes / _allreduce_f64 (additive). 7: half bands 224 .. 2 046 are computed (wide_band.hip). 5: any band constructs (DYN_READ_BAND_TOO_WIDE per read); dyn_bam_*, dyn_csv_sink_wait / _open_part */
 
 /* device argument of dyn_aligner_create: bind no GPU. Such a handle serves the host-side
  * contract only (model loading, dyn_aligner_info/_model, dyn_validate_batch); every compute
@@ -249,6 +249,13 @@ int dyn_aligner_session_stats(dyn_aligner* a, dyn_session_stats* out);
  * waiting for the free list to hold their request, taking it. Same units and the same closing behaviour as above. No
  * counterpart in the reference (it allocates eight T x B matrices per read, NT_aligner_api.cpp:249-262). */
 int dyn_aligner_session_page_wait(dyn_aligner* a, uint64_t* wave_cycles_waiting_for_pages);
+/* (ABI 8, additive) Where the resident waves' idle share sat, counted by the waves themselves (wave-cycles, summed over the
+ * handle's sessions like dyn_session_stats; closes an open session first): out4[0] before a wave's first read (part of
+ * wave_cycles_idle), out4[1] the part of out4[0] spent getting pages, out4[2] in a wave's LAST turn -- no read left to claim,
+ * polling for the session's close; part of wave_cycles_life - busy - idle --, out4[3] the sum over the sessions of the longest
+ * last turn of any wave. A finite run pays out4[2] once per session ("Paged sessions"); a stream does not.
+ * No counterpart in the reference. */
+int dyn_aligner_session_idle_split(dyn_aligner* a, uint64_t out4[4]);
 /* enabled = 0: no resident read queue on this handle (one launch per batch, as DYN_NO_SESSION=1 does for a process).
  * enabled = 1: sessions of n_cus - reserved_cus workgroups, one per compute unit. A resident session leaves 9.5 KB of LDS and 152
  * registers per lane free on every CU it occupies: the library's own small kernels run beside it. A kernel whose workgroups need
