@@ -185,6 +185,13 @@ def test_page_starved_tickets_share_the_pool_of_a_paged_session(models, monkeypa
             t.close()
     s = al.session_stats()
     assert s["aborted"] == 0 and s["sessions"] >= 1 and s["tickets"] == 12
+    # the waves' own account of their idle share (dyn_aligner_session_idle_split): the parts fit inside the wholes
+    assert 0 < s["wave_cycles_pages"] <= s["wave_cycles_idle"]
+    assert s["wave_cycles_before_first_read_pages"] <= s["wave_cycles_before_first_read"] <= s["wave_cycles_idle"]
+    assert s["wave_cycles_before_first_read_pages"] <= s["wave_cycles_pages"]
+    not_busy_not_idle = s["wave_cycles_life"] - s["wave_cycles_busy"] - s["wave_cycles_idle"]
+    assert 0 < s["wave_cycles_last_turn"] <= not_busy_not_idle
+    assert s["wave_cycles_longest_last_turn"] * s["waves"] >= s["wave_cycles_last_turn"]   # (summed over the sessions alike)
     al.close()
 
 
