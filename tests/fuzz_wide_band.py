@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from dynamont_amd import Aligner, synth
 from oracle.pyoracle import Oracle
 d = tempfile.mkdtemp()
-rng = np.random.default_rng(20261005)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 20261005)  # python tests/fuzz_wide_band.py [seed]
 tot = wide = bad = bad_zbits = bad_z = bad_train = err = 0
 for pore in ("rna002", "rna004", "dna_r9", "dna_r10_260bps", "dna_r10_400bps"):
     k = synth.PORES[pore][2]
